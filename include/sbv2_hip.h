@@ -1,0 +1,117 @@
+/* sbv2_hip.h — C ABI of libsbv2_hip.so: the MI355X-native replacement for the two ONNX Runtime sessions of sbv2_core.
+ *
+ * Drop-in boundary.  Every entry point cites the reference interface it replaces; paths are relative
+ * to the reference repository (tuna2134/sbv2-api @ 2025-03-07).
+ *
+ * Conventions
+ *   - return value 0 = ok; non-zero = error, message via sbv2_last_error() (thread local).  The Rust shim maps this to
+ *     sbv2_core::error::Error::OtherError(String) (crates/sbv2_core/src/error.rs:29-30); nothing panics across the FFI.
+ *   - inputs are borrowed for the duration of the call (the reference passes views: model.rs:68-90, bert.rs:13-14);
+ *     outputs are either caller-allocated or owned buffers released with sbv2_pcm_free (the reference returns owned
+ *     arrays: model.rs:108, bert.rs:21).
+ *   - a handle is used by one caller at a time (`&mut Session` in the reference: bert.rs:7, model.rs:54).
+ *   - model bytes are a weight container ("SBV2W001", see sbv2-api_amd/synth.py); they need not outlive *_create.
+ */
+#ifndef SBV2_HIP_H
+#define SBV2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sbv2_bert sbv2_bert;         /* replaces the `Session` held in TTSModelHolder.bert (tts.rs:40-46) */
+typedef struct sbv2_vits sbv2_vits;         /* replaces the `Session` held in TTSModel.vits2 (tts.rs:32-38) */
+typedef struct sbv2_pipeline sbv2_pipeline; /* new: batched, device-resident bert -> vits path */
+
+/* Message of the last failing call on this thread (never NULL). */
+const char* sbv2_last_error(void);
+/* Number of visible HIP devices (0 when no GPU / no driver). */
+int sbv2_device_count(void);
+
+/* ---- load_model(model_file, bert = true)  crates/sbv2_core/src/model.rs:6-50 ---------------------------------- */
+int sbv2_bert_create(const uint8_t* model, size_t model_len, int device, sbv2_bert** out);
+void sbv2_bert_destroy(sbv2_bert* h);
+int64_t sbv2_bert_hidden(const sbv2_bert* h); /* 1024 for deberta-v2-large */
+
+/* ---- bert::predict(session, token_ids, attention_masks) -> Array2<f32>[S, 1024]  crates/sbv2_core/src/bert.rs:6-24
+ * out: caller-allocated S * hidden floats, row-major [S][hidden]. */
+int sbv2_bert_predict(sbv2_bert* h, const int64_t* token_ids, const int64_t* attention_mask, int64_t S, float* out);
+/* new: n utterances at once; ids / mask concatenated, lens[n]; out = concatenated [sum S][hidden].
+ * Row block i equals what sbv2_bert_predict returns for utterance i alone. */
+int sbv2_bert_predict_batch(sbv2_bert* h, int64_t n, const int64_t* token_ids, const int64_t* attention_mask,
+                            const int64_t* lens, float* out);
+
+/* ---- load_model(model_file, bert = false)  crates/sbv2_core/src/model.rs:6-50 --------------------------------- */
+int sbv2_vits_create(const uint8_t* model, size_t model_len, int device, sbv2_vits** out);
+void sbv2_vits_destroy(sbv2_vits* h);
+int64_t sbv2_vits_hop(const sbv2_vits* h);       /* samples per frame (512) */
+int64_t sbv2_vits_bert_dim(const sbv2_vits* h);  /* 1024 */
+int64_t sbv2_vits_style_dim(const sbv2_vits* h); /* 256 */
+
+/* ---- model::synthesize(session, bert_ori, x_tst, sid, tones, lang_ids, style_vector, sdp_ratio, length_scale,
+ *                        noise_scale, noise_scale_w) -> Array3<f32>[1, 1, L]      crates/sbv2_core/src/model.rs:53-111
+ * bert: [bert_dim][T] row-major (Array2 [1024, T], model.rs:56); x_tst/tones/lang: i64[T]; style: f32[style_dim].
+ * *pcm: owned buffer of *pcm_len samples (release with sbv2_pcm_free).  noise_seed selects the counter-based noise
+ * stream that replaces the graph's RandomNormalLike nodes (irrelevant when both noise scales are 0). */
+int sbv2_vits_synthesize(sbv2_vits* h, const float* bert, const int64_t* x_tst, const int64_t* tones,
+                         const int64_t* lang_ids, int64_t T, int64_t sid, const float* style_vector, float sdp_ratio,
+                         float length_scale, float noise_scale, float noise_scale_w, uint64_t noise_seed, float** pcm,
+                         int64_t* pcm_len);
+void sbv2_pcm_free(float* pcm);
+
+/* new: a batch of utterances in one call.  All per-token arrays are concatenated over utterances (utterance-major). */
+typedef struct sbv2_batch {
+    int64_t n;                       /* utterances */
+    const int64_t* t_lens;           /* [n] T_text of each utterance */
+    const int64_t* x_tst;            /* [sum T] phone ids */
+    const int64_t* tones;            /* [sum T] */
+    const int64_t* lang_ids;         /* [sum T] */
+    const int64_t* sids;             /* [n] */
+    const float* style_vectors;      /* [n][style_dim] */
+    const float* bert;               /* concatenated [bert_dim][T_i] blocks; NULL in sbv2_pipeline_* (features come from DeBERTa) */
+    float sdp_ratio, length_scale, noise_scale, noise_scale_w;
+    uint64_t noise_seed;
+    const int64_t* forced_durations; /* optional [sum T]: teacher-forced w_ceil (benchmark / parity mode), else NULL */
+} sbv2_batch;
+
+/* Runs the batch; results stay on the device until fetched.  pcm_lens: caller-allocated [n]. */
+int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* pcm_lens);
+/* Concatenated PCM of the last batch (sum of pcm_lens samples) -> host. */
+int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm);
+/* Device pointer to the concatenated PCM of the last batch (valid until the next call on the handle). */
+const float* sbv2_vits_pcm_device(sbv2_vits* h, int64_t* total);
+/* Predicted integer durations w_ceil (before any forcing) and log-durations of the last batch, concatenated [sum T]. */
+int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw);
+/* Debug/parity: keep named intermediates of the next calls (x_emb, x, stats, z_p, z, dec_pre, dec_stage<i>). */
+int sbv2_vits_set_trace(sbv2_vits* h, int on);
+int sbv2_vits_get_trace(sbv2_vits* h, const char* name, int64_t utt, float* out, int64_t cap, int64_t* rows, int64_t* cols);
+
+/* ---- new: the whole hot path for a batch, device resident:
+ *   bert::predict per utterance (tts.rs:210-212) -> feature repeat by word2ph (tts_util.rs:129-154) -> model::synthesize.
+ * token_ids / word2ph are concatenated over utterances; s_lens[n] gives S_i; sum(word2ph of utterance i) must equal t_lens[i]. */
+int sbv2_pipeline_create(sbv2_bert* bert, sbv2_vits* vits, sbv2_pipeline** out);
+void sbv2_pipeline_destroy(sbv2_pipeline* p);
+int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens,
+                      const int64_t* word2ph, int64_t* pcm_lens);
+
+/* ---- test hooks (no reference counterpart) ------------------------------------------------------------------------ */
+/* bucket(rel) for rel in [-(max_s-1), max_s-1] (transformers modeling_deberta_v2.py:57-69); host only, no GPU needed. */
+int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out);
+/* y[Cout][L] = conv1d(x[Cin][L], w[Cout][Cin][k], bias, dilation, 'same' padding) with optional leaky-ReLU on the input,
+ * through the production implicit-GEMM kernel; host buffers. */
+int sbv2_debug_conv1d(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k,
+                      int64_t L, int64_t dilation, float pre_slope, float* y);
+/* y[Cout][L*stride] = conv_transpose1d(x[Cin][L], w[Cin][Cout][k], bias, stride, padding) via the polyphase path. */
+int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout,
+                                int64_t k, int64_t L, int64_t stride, int64_t padding, float pre_slope, float* y);
+/* Times `iters` launches of one dilated conv (device buffers, random data) and returns the mean kernel time in ms. */
+int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters,
+                           float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBV2_HIP_H */

@@ -1,0 +1,367 @@
+// extern "C" boundary of libsbv2_hip.so (see include/sbv2_hip.h for what each entry point replaces).
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/sbv2_hip.h"
+#include "models.h"
+
+namespace sbv2 {
+const char* last_error_cstr();
+}
+using namespace sbv2;
+
+struct sbv2_bert {
+    std::unique_ptr<BertModel> m;
+};
+struct sbv2_vits {
+    std::unique_ptr<VitsModel> m;
+};
+struct sbv2_pipeline {
+    sbv2_bert* bert;
+    sbv2_vits* vits;
+};
+
+#define API_BEGIN try {
+#define API_END                                   \
+    return 0;                                     \
+    }                                             \
+    catch (const std::exception& e) {             \
+        set_last_error(e.what());                 \
+        return 1;                                 \
+    }                                             \
+    catch (...) {                                 \
+        set_last_error("unknown error");          \
+        return 1;                                 \
+    }
+
+static VitsBatch to_batch(const sbv2_batch* b) {
+    SBV2_REQUIRE(b && b->n >= 1 && b->t_lens && b->x_tst && b->tones && b->lang_ids && b->sids && b->style_vectors,
+                 "sbv2_batch has null fields");
+    VitsBatch v;
+    v.n = (int)b->n;
+    v.t_lens = b->t_lens;
+    v.phones = b->x_tst;
+    v.tones = b->tones;
+    v.langs = b->lang_ids;
+    v.sids = b->sids;
+    v.styles = b->style_vectors;
+    v.bert_host = b->bert;
+    v.sdp_ratio = b->sdp_ratio;
+    v.length_scale = b->length_scale;
+    v.noise_scale = b->noise_scale;
+    v.noise_scale_w = b->noise_scale_w;
+    v.seed = b->noise_seed;
+    v.forced_durations = b->forced_durations;
+    return v;
+}
+
+namespace {
+struct DevBuf {
+    float* p = nullptr;
+    explicit DevBuf(size_t n) { HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), sizeof(float) * std::max<size_t>(n, 4))); }
+    ~DevBuf() { (void)hipFree(p); }
+};
+Blob one_conv_blob(const float* w, const float* bias, std::vector<int64_t> dims, int64_t nbias) {
+    Blob b;
+    b.kind = 0;
+    HostTensor t;
+    t.dims = std::move(dims);
+    t.data = w;
+    b.tensors.emplace("c.weight", t);
+    if (bias) {
+        HostTensor tb;
+        tb.dims = {nbias};
+        tb.data = bias;
+        b.tensors.emplace("c.bias", tb);
+    }
+    return b;
+}
+}  // namespace
+
+extern "C" {
+
+const char* sbv2_last_error(void) { return last_error_cstr(); }
+
+int sbv2_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sbv2_bert_create(const uint8_t* model, size_t model_len, int device, sbv2_bert** out) {
+    API_BEGIN
+    SBV2_REQUIRE(out, "null output handle");
+    Blob blob = parse_blob(model, model_len);
+    std::unique_ptr<sbv2_bert> h(new sbv2_bert);
+    h->m.reset(new BertModel(blob, device));
+    *out = h.release();
+    API_END
+}
+void sbv2_bert_destroy(sbv2_bert* h) { delete h; }
+int64_t sbv2_bert_hidden(const sbv2_bert* h) { return h ? h->m->cfg().hidden : 0; }
+
+int sbv2_bert_predict_batch(sbv2_bert* h, int64_t n, const int64_t* token_ids, const int64_t* attention_mask, const int64_t* lens,
+                            float* out) {
+    API_BEGIN
+    SBV2_REQUIRE(h && token_ids && lens && out && n >= 1, "bad arguments");
+    h->m->forward((int)n, token_ids, attention_mask, lens);
+    h->m->copy_out(out);
+    API_END
+}
+int sbv2_bert_predict(sbv2_bert* h, const int64_t* token_ids, const int64_t* attention_mask, int64_t S, float* out) {
+    return sbv2_bert_predict_batch(h, 1, token_ids, attention_mask, &S, out);
+}
+
+int sbv2_vits_create(const uint8_t* model, size_t model_len, int device, sbv2_vits** out) {
+    API_BEGIN
+    SBV2_REQUIRE(out, "null output handle");
+    Blob blob = parse_blob(model, model_len);
+    std::unique_ptr<sbv2_vits> h(new sbv2_vits);
+    h->m.reset(new VitsModel(blob, device));
+    *out = h.release();
+    API_END
+}
+void sbv2_vits_destroy(sbv2_vits* h) { delete h; }
+int64_t sbv2_vits_hop(const sbv2_vits* h) { return h ? h->m->cfg().hop() : 0; }
+int64_t sbv2_vits_bert_dim(const sbv2_vits* h) { return h ? h->m->cfg().bert_dim : 0; }
+int64_t sbv2_vits_style_dim(const sbv2_vits* h) { return h ? h->m->cfg().style_dim : 0; }
+
+int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* pcm_lens) {
+    API_BEGIN
+    SBV2_REQUIRE(h && pcm_lens, "bad arguments");
+    VitsBatch v = to_batch(batch);
+    SBV2_REQUIRE(v.bert_host, "sbv2_batch.bert is required here");
+    h->m->forward(v);
+    for (int i = 0; i < v.n; ++i) pcm_lens[i] = h->m->pcm_lens()[i];
+    API_END
+}
+int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm) {
+    API_BEGIN
+    SBV2_REQUIRE(h && pcm, "bad arguments");
+    h->m->copy_pcm(pcm);
+    API_END
+}
+const float* sbv2_vits_pcm_device(sbv2_vits* h, int64_t* total) {
+    if (!h) return nullptr;
+    if (total) *total = h->m->pcm_total();
+    return h->m->pcm_device();
+}
+int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw) {
+    API_BEGIN
+    SBV2_REQUIRE(h, "bad arguments");
+    const auto& d = h->m->durations();
+    const auto& l = h->m->logw();
+    if (durations)
+        for (size_t i = 0; i < d.size(); ++i) durations[i] = d[i];
+    if (logw) std::memcpy(logw, l.data(), sizeof(float) * l.size());
+    API_END
+}
+int sbv2_vits_set_trace(sbv2_vits* h, int on) {
+    API_BEGIN
+    SBV2_REQUIRE(h, "bad arguments");
+    h->m->set_trace(on != 0);
+    API_END
+}
+int sbv2_vits_get_trace(sbv2_vits* h, const char* name, int64_t utt, float* out, int64_t cap, int64_t* rows, int64_t* cols) {
+    API_BEGIN
+    SBV2_REQUIRE(h && name && rows && cols, "bad arguments");
+    std::vector<float> v;
+    int r = 0, c = 0;
+    SBV2_REQUIRE(h->m->get_trace(name, (int)utt, v, r, c), std::string("no trace named ") + name);
+    *rows = r;
+    *cols = c;
+    if (out) {
+        SBV2_REQUIRE((int64_t)v.size() <= cap, "trace buffer too small");
+        std::memcpy(out, v.data(), sizeof(float) * v.size());
+    }
+    API_END
+}
+
+int sbv2_vits_synthesize(sbv2_vits* h, const float* bert, const int64_t* x_tst, const int64_t* tones, const int64_t* lang_ids, int64_t T,
+                         int64_t sid, const float* style_vector, float sdp_ratio, float length_scale, float noise_scale,
+                         float noise_scale_w, uint64_t noise_seed, float** pcm, int64_t* pcm_len) {
+    API_BEGIN
+    SBV2_REQUIRE(h && bert && pcm && pcm_len, "bad arguments");
+    sbv2_batch b;
+    std::memset(&b, 0, sizeof(b));
+    b.n = 1;
+    b.t_lens = &T;
+    b.x_tst = x_tst;
+    b.tones = tones;
+    b.lang_ids = lang_ids;
+    b.sids = &sid;
+    b.style_vectors = style_vector;
+    b.bert = bert;
+    b.sdp_ratio = sdp_ratio;
+    b.length_scale = length_scale;
+    b.noise_scale = noise_scale;
+    b.noise_scale_w = noise_scale_w;
+    b.noise_seed = noise_seed;
+    h->m->forward(to_batch(&b));
+    const int64_t n = h->m->pcm_total();
+    float* buf = static_cast<float*>(std::malloc(sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
+    SBV2_REQUIRE(buf, "out of host memory");
+    try {
+        h->m->copy_pcm(buf);
+    } catch (...) {
+        std::free(buf);
+        throw;
+    }
+    *pcm = buf;
+    *pcm_len = n;
+    API_END
+}
+void sbv2_pcm_free(float* pcm) { std::free(pcm); }
+
+int sbv2_pipeline_create(sbv2_bert* bert, sbv2_vits* vits, sbv2_pipeline** out) {
+    API_BEGIN
+    SBV2_REQUIRE(bert && vits && out, "bad arguments");
+    SBV2_REQUIRE(bert->m->device() == vits->m->device(), "bert and vits handles live on different devices");
+    SBV2_REQUIRE(bert->m->cfg().hidden == vits->m->cfg().bert_dim, "DeBERTa hidden size does not match the VITS bert_proj input");
+    *out = new sbv2_pipeline{bert, vits};
+    API_END
+}
+void sbv2_pipeline_destroy(sbv2_pipeline* p) { delete p; }
+
+int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens, const int64_t* word2ph,
+                      int64_t* pcm_lens) {
+    API_BEGIN
+    SBV2_REQUIRE(p && token_ids && s_lens && word2ph && pcm_lens, "bad arguments");
+    VitsBatch v = to_batch(batch);
+    BertModel& bm = *p->bert->m;
+    VitsModel& vm = *p->vits->m;
+    bm.forward(v.n, token_ids, nullptr, s_lens);
+    // tts_util.rs:129-154: token i's feature vector is repeated word2ph[i] times along the text axis
+    const SegLayout& bl = bm.layout();
+    std::vector<int> map;
+    int64_t e = 0;
+    for (int u = 0; u < v.n; ++u) {
+        SBV2_REQUIRE(s_lens[u] == bl.len[u], "internal: layout mismatch");
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < s_lens[u]; ++i, ++e) {
+            SBV2_REQUIRE(word2ph[e] >= 0, "negative word2ph");
+            for (int64_t r = 0; r < word2ph[e]; ++r) map.push_back(bl.start[u] + (int)i);
+            cnt += word2ph[e];
+        }
+        SBV2_REQUIRE(cnt == v.t_lens[u], "sum(word2ph) must equal the text length (tts_util.rs:122-127)");
+    }
+    v.bert_host = nullptr;
+    v.bert_dev = &bm.out();
+    v.bert_map = map.data();
+    // the two models run on their own streams: order them
+    HIP_CHECK(hipStreamSynchronize(bm.stream()));
+    vm.forward(v);
+    for (int i = 0; i < v.n; ++i) pcm_lens[i] = vm.pcm_lens()[i];
+    API_END
+}
+
+int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out) {
+    API_BEGIN
+    SBV2_REQUIRE(max_s >= 1 && out, "bad arguments");
+    const std::vector<int> t = BertModel::bucket_table((int)max_s, (int)buckets, (int)max_rel);
+    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+    API_END
+}
+
+
+int sbv2_debug_conv1d(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k, int64_t L,
+                      int64_t dilation, float pre_slope, float* y) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    Blob b = one_conv_blob(w, bias, {cout, cin, k}, cout);
+    WeightStore ws(b);
+    PackedConv pc = ws.conv("c");
+    Plane X{nullptr, (int)cin, (int)L, round_up((int)L, 64)}, Y{nullptr, (int)cout, (int)L, round_up((int)L, 64)};
+    DevBuf dx((size_t)cin * X.ld), dy((size_t)cout * Y.ld);
+    X.p = dx.p;
+    Y.p = dy.p;
+    HIP_CHECK(hipMemcpy2D(X.p, sizeof(float) * X.ld, x, sizeof(float) * L, sizeof(float) * L, cin, hipMemcpyHostToDevice));
+    conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, pre_slope);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy2D(y, sizeof(float) * L, Y.p, sizeof(float) * Y.ld, sizeof(float) * L, cout, hipMemcpyDeviceToHost));
+    API_END
+}
+
+int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k,
+                                int64_t L, int64_t stride, int64_t padding, float pre_slope, float* y) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(bias, "bias required");
+    Blob b = one_conv_blob(w, bias, {cin, cout, k}, cout);
+    WeightStore ws(b);
+    PackedUpsample up = ws.upsample("c", (int)stride, (int)padding);
+    const int Lo = (int)(L * stride);
+    Plane X{nullptr, (int)cin, (int)L, round_up((int)L, 64)}, Y{nullptr, (int)cout, Lo, round_up(Lo, 64)};
+    DevBuf dx((size_t)cin * X.ld), dy((size_t)cout * Y.ld);
+    X.p = dx.p;
+    Y.p = dy.p;
+    HIP_CHECK(hipMemcpy2D(X.p, sizeof(float) * X.ld, x, sizeof(float) * L, sizeof(float) * L, cin, hipMemcpyHostToDevice));
+    for (const auto& g : up.groups) {
+        ConvParams p;
+        p.A = g.w;
+        p.lda = g.lda;
+        p.a_tap_stride = (int64_t)up.cin * g.lda;
+        p.B = X.p;
+        p.ldb = X.ld;
+        p.nb = X.L;
+        p.C = Y.p;
+        p.ldc = Y.ld;
+        p.M = g.nph * up.cout;
+        p.N = X.L;
+        p.K = up.cin;
+        p.ntaps = g.ntaps;
+        for (int t = 0; t < g.ntaps; ++t) p.shift[t] = g.shift[t];
+        p.bias = up.bias;
+        p.bias_mode = BIAS_ROW;
+        p.pre_slope = pre_slope;
+        p.out_stride = (int)stride;
+        p.phase_rows = up.cout;
+        for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
+        launch_conv(p, nullptr);
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy2D(y, sizeof(float) * Lo, Y.p, sizeof(float) * Y.ld, sizeof(float) * Lo, cout, hipMemcpyDeviceToHost));
+    API_END
+}
+
+int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters, float* ms) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(ms && iters >= 1, "bad arguments");
+    std::vector<float> w((size_t)cout * cin * k), bias((size_t)cout, 0.1f);
+    uint32_t st = 12345u;
+    auto rnd = [&]() {
+        st = st * 1664525u + 1013904223u;
+        return ((st >> 8) * (1.0f / 16777216.0f) - 0.5f);
+    };
+    for (auto& v : w) v = rnd() * 0.1f;
+    Blob b = one_conv_blob(w.data(), bias.data(), {cout, cin, k}, cout);
+    WeightStore ws(b);
+    PackedConv pc = ws.conv("c");
+    Plane X{nullptr, (int)cin, (int)L, round_up((int)L, 64)}, Y{nullptr, (int)cout, (int)L, round_up((int)L, 64)};
+    DevBuf dx((size_t)cin * X.ld), dy((size_t)cout * Y.ld);
+    X.p = dx.p;
+    Y.p = dy.p;
+    {
+        std::vector<float> hx((size_t)cin * X.ld);
+        for (auto& v : hx) v = rnd() * 2.f;
+        HIP_CHECK(hipMemcpy(X.p, hx.data(), sizeof(float) * hx.size(), hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, 0.1f);
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, 0.1f);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+// DeBERTa-v2 encoder (the graph behind `bert::predict`, crates/sbv2_core/src/bert.rs:6-24, exported by
+// scripts/convert/convert_deberta.py:22-35 as hidden_states[-3] of AutoModelForMaskedLM).
+//
+// Batched over utterances by PACKING tokens (no padding): every projection / FFN is one GEMM over all tokens of the
+// batch; attention runs as grouped GEMMs over (utterance, head).  Activations are channel-major planes [hidden][tokens].
+// The relative-position projections key_proj(LN(rel_emb)) / query_proj(LN(rel_emb)) are input independent and are
+// computed once at load time.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "models.h"
+
+namespace sbv2 {
+
+// modeling_deberta_v2.py:57-69 (float32 arithmetic like torch)
+std::vector<int> BertModel::bucket_table(int maxS, int buckets, int max_rel) {
+    std::vector<int> tab(2 * maxS - 1);
+    const int mid = buckets / 2;
+    for (int rel = -(maxS - 1); rel <= maxS - 1; ++rel) {
+        int b = rel;
+        if (buckets > 0 && max_rel > 0) {
+            const float r = (float)rel;
+            const float sign = r > 0 ? 1.f : (r < 0 ? -1.f : 0.f);
+            const float abs_pos = (rel < mid && rel > -mid) ? (float)(mid - 1) : std::fabs(r);
+            if (abs_pos <= (float)mid) {
+                b = rel;
+            } else {
+                const float lp = std::ceil(std::log(abs_pos / (float)mid) / std::log((float)(max_rel - 1) / (float)mid) * (float)(mid - 1)) +
+                                 (float)mid;
+                b = (int)(lp * sign);
+            }
+        }
+        tab[rel + maxS - 1] = b;
+    }
+    return tab;
+}
+
+BertModel::BertModel(const Blob& blob, int device) : device_(device) {
+    SBV2_REQUIRE(blob.kind == 1, "weight container is not a DeBERTa (kind 1) model");
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreate(&stream_));
+    const std::string& js = blob.config_json;
+    cfg_.vocab = (int)json_number(js, "vocab_size");
+    cfg_.hidden = (int)json_number(js, "hidden");
+    cfg_.layers = (int)json_number(js, "layers");
+    cfg_.heads = (int)json_number(js, "heads");
+    cfg_.inter = (int)json_number(js, "intermediate");
+    cfg_.buckets = (int)json_number(js, "position_buckets");
+    cfg_.max_rel = (int)json_number(js, "max_relative_positions");
+    cfg_.eps = (float)json_number(js, "ln_eps");
+    SBV2_REQUIRE(cfg_.hidden % cfg_.heads == 0 && (cfg_.hidden / cfg_.heads) % 4 == 0, "head size must be a multiple of 4");
+    ws_.reset(new WeightStore(blob));
+    emb_ = ws_->tensor("deberta.embeddings.word_embeddings.weight");
+    emb_g_ = ws_->tensor("deberta.embeddings.LayerNorm.weight");
+    emb_b_ = ws_->tensor("deberta.embeddings.LayerNorm.bias");
+
+    // LayerNorm of the relative embeddings on the host (modeling_deberta_v2.py:595-599), stored as a plane [H][2*span]
+    const int H = cfg_.hidden;
+    const int span = cfg_.buckets > 0 ? cfg_.buckets : cfg_.max_rel;
+    const HostTensor& re = blob.get("deberta.encoder.rel_embeddings.weight");
+    const HostTensor& rg = blob.get("deberta.encoder.LayerNorm.weight");
+    const HostTensor& rb = blob.get("deberta.encoder.LayerNorm.bias");
+    SBV2_REQUIRE(re.dims[0] >= 2 * span && re.dims[1] == H, "rel_embeddings shape");
+    Plane rel;
+    rel.C = H;
+    rel.L = 2 * span;
+    rel.ld = round_up(2 * span, 64);
+    std::vector<float> hp((size_t)H * rel.ld, 0.f);
+    for (int r = 0; r < 2 * span; ++r) {
+        const float* row = re.data + (size_t)r * H;
+        float mean = 0.f;
+        for (int c = 0; c < H; ++c) mean += row[c];
+        mean /= H;
+        float var = 0.f;
+        for (int c = 0; c < H; ++c) var += (row[c] - mean) * (row[c] - mean);
+        const float rstd = 1.0f / std::sqrt(var / H + cfg_.eps);
+        for (int c = 0; c < H; ++c) hp[(size_t)c * rel.ld + r] = (row[c] - mean) * rstd * rg.data[c] + rb.data[c];
+    }
+    rel.p = ws_->upload(hp.data(), hp.size());
+
+    layers_.resize(cfg_.layers);
+    for (int i = 0; i < cfg_.layers; ++i) {
+        const std::string p = "deberta.encoder.layer." + std::to_string(i) + ".";
+        Layer& L = layers_[i];
+        L.q = ws_->linear(p + "attention.self.query_proj");
+        L.k = ws_->linear(p + "attention.self.key_proj");
+        L.v = ws_->linear(p + "attention.self.value_proj");
+        L.o = ws_->linear(p + "attention.output.dense");
+        L.ln1_g = ws_->tensor(p + "attention.output.LayerNorm.weight");
+        L.ln1_b = ws_->tensor(p + "attention.output.LayerNorm.bias");
+        L.ffn1 = ws_->linear(p + "intermediate.dense");
+        L.ffn2 = ws_->linear(p + "output.dense");
+        L.ln2_g = ws_->tensor(p + "output.LayerNorm.weight");
+        L.ln2_b = ws_->tensor(p + "output.LayerNorm.bias");
+        // share_att_key: positions go through the layer's own key/query projections (:292-299)
+        std::vector<float> zero((size_t)H * rel.ld, 0.f);
+        L.pos_k = rel;
+        L.pos_k.p = ws_->upload(zero.data(), zero.size());
+        L.pos_q = rel;
+        L.pos_q.p = ws_->upload(zero.data(), zero.size());
+        conv_plain(L.k, rel, L.pos_k, 1, 0, nullptr, 1, stream_);
+        conv_plain(L.q, rel, L.pos_q, 1, 0, nullptr, 1, stream_);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+BertModel::~BertModel() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens) {
+    HIP_CHECK(hipSetDevice(device_));
+    SBV2_REQUIRE(n >= 1, "empty batch");
+    arena_.reset();
+    const int H = cfg_.hidden, nh = cfg_.heads, d = H / nh;
+    const int span = cfg_.buckets > 0 ? cfg_.buckets : cfg_.max_rel;
+    std::vector<int> L(n);
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        SBV2_REQUIRE(lens[i] >= 1 && lens[i] < (1 << 20), "bad sequence length");
+        L[i] = (int)lens[i];
+        total += lens[i];
+    }
+    std::vector<unsigned char> am((size_t)total, 1);
+    if (mask)
+        for (int64_t e = 0; e < total; ++e) am[e] = mask[e] != 0;
+    layout_ = make_layout(L, 0, arena_, am.data());
+    const SegLayout& lay = layout_;
+    const int N = lay.L;
+    const int maxT = lay.max_len();
+
+    // token ids in the packed layout (-1 in alignment gaps)
+    std::vector<int> hid(N, -1);
+    {
+        int64_t e = 0;
+        for (int i = 0; i < n; ++i)
+            for (int t = 0; t < L[i]; ++t, ++e) {
+                SBV2_REQUIRE(ids[e] >= 0 && ids[e] < cfg_.vocab, "token id out of range");
+                hid[lay.start[i] + t] = (int)ids[e];
+            }
+    }
+    int* d_ids = arena_.array<int>(N);
+    HIP_CHECK(hipMemcpyAsync(d_ids, hid.data(), sizeof(int) * N, hipMemcpyHostToDevice, stream_));
+    // valid-token mask (layout) is all that LayerNorm outputs are multiplied with; the attention mask has its own array
+    std::vector<unsigned char> valid(N, 0);
+    for (int i = 0; i < n; ++i)
+        for (int t = 0; t < L[i]; ++t) valid[lay.start[i] + t] = 1;
+    unsigned char* d_valid = arena_.array<unsigned char>(N);
+    HIP_CHECK(hipMemcpyAsync(d_valid, valid.data(), N, hipMemcpyHostToDevice, stream_));
+
+    // relative-position window used by this batch
+    const std::vector<int> tab = bucket_table(maxT, cfg_.buckets, cfg_.max_rel);
+    auto clampi = [&](int v) { return std::min(std::max(v, 0), 2 * span - 1); };
+    int dmin = 2 * span, dmax = 0;
+    for (int v : tab) {
+        dmin = std::min(dmin, std::min(clampi(v + span), clampi(-v + span)));
+        dmax = std::max(dmax, std::max(clampi(v + span), clampi(-v + span)));
+    }
+    const int win_lo = dmin / 4 * 4;
+    const int wlen = dmax - win_lo + 1;
+    const int win_ld = round_up(wlen, 4);
+    int* d_tab = arena_.array<int>(tab.size());
+    HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, stream_));
+
+    // attention problem descriptors
+    const int lds = round_up(maxT, 4);
+    const int ng = n * nh;
+    Plane X = arena_.plane(H, N), Q = arena_.plane(H, N), Kp = arena_.plane(H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
+    Plane F = arena_.plane(cfg_.inter, N);
+    float* VT = arena_.array<float>((size_t)N * H);
+    std::vector<AttnGroup> ag(ng);
+    std::vector<GemmGroup> g_st(ng), g_c2p(ng), g_p2c(ng), g_pv(ng);
+    int64_t s_off = 0, c_off = 0, p_off = 0;
+    const int ldp = layers_[0].pos_k.ld;
+    for (int u = 0; u < n; ++u)
+        for (int h = 0; h < nh; ++h) {
+            const int gi = u * nh + h;
+            const int T = L[u];
+            AttnGroup& a = ag[gi];
+            a.qk_off = (int64_t)h * d * X.ld + lay.start[u];
+            a.s_off = s_off;
+            a.aux_off = c_off;
+            a.aux2_off = p_off;
+            a.T = T;
+            a.lds = lds;
+            a.col0 = lay.start[u];
+            a.head = h;
+            g_st[gi] = GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, d, T};                                   // S^T = K^T Q
+            g_c2p[gi] = GemmGroup{(int64_t)h * d * ldp + win_lo, a.qk_off, c_off, 0, wlen, T, d, T};          // posK^T Q
+            g_p2c[gi] = GemmGroup{a.qk_off, (int64_t)h * d * ldp + win_lo, p_off, 0, T, wlen, d, wlen};       // K^T posQ
+            g_pv[gi] = GemmGroup{(int64_t)lay.start[u] * H + h * d, s_off, a.qk_off, 0, d, T, T, T};          // V P^T
+            s_off += (int64_t)T * lds;
+            c_off += (int64_t)wlen * lds;
+            p_off += (int64_t)T * win_ld;
+        }
+    float* S = arena_.array<float>((size_t)s_off);
+    float* C2P = arena_.array<float>((size_t)c_off);
+    float* P2C = arena_.array<float>((size_t)p_off);
+    AttnGroup* d_ag = arena_.array<AttnGroup>(ng);
+    GemmGroup* d_g = arena_.array<GemmGroup>((size_t)4 * ng);
+    HIP_CHECK(hipMemcpyAsync(d_ag, ag.data(), sizeof(AttnGroup) * ng, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_g, g_st.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_g + ng, g_c2p.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_g + 2 * ng, g_p2c.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_g + 3 * ng, g_pv.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));  // host staging vectors go out of scope below
+
+    const float inv_scale = 1.0f / std::sqrt((float)d * 3.0f);  // c2p + p2c => scale_factor 3 (:226-232)
+
+    deberta_embed_ln(d_ids, emb_, H, emb_g_, emb_b_, cfg_.eps, X, stream_);
+    fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);  // alignment-gap columns are never written by P.V
+    if (mask) {
+        // embeddings * mask (:550-559): tokens with attention_mask 0 become zero columns (a column gather with -1 entries)
+        std::vector<int> map(N, -1);
+        int64_t e = 0;
+        for (int i = 0; i < n; ++i)
+            for (int t = 0; t < L[i]; ++t, ++e)
+                if (mask[e]) map[lay.start[i] + t] = lay.start[i] + t;
+        int* d_map = arena_.array<int>(N);
+        HIP_CHECK(hipMemcpy(d_map, map.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+        gather_cols(X, d_map, A, stream_);
+        std::swap(X, A);
+    }
+
+    auto grouped = [&](const float* Aop, int lda, const float* Bop, int ldb, float* Cop, int ldc, const GemmGroup* grp, int maxM, int maxN,
+                       float alpha) {
+        ConvParams p;
+        p.A = Aop;
+        p.lda = lda;
+        p.B = Bop;
+        p.ldb = ldb;
+        p.C = Cop;
+        p.ldc = ldc;
+        p.alpha = alpha;
+        p.groups = grp;
+        p.ngroups = ng;
+        p.maxM = maxM;
+        p.maxN = maxN;
+        launch_conv(p, stream_);
+    };
+
+    for (int li = 0; li < cfg_.layers; ++li) {
+        const Layer& Ly = layers_[li];
+        conv_plain(Ly.q, X, Q, 1, 0, nullptr, 1, stream_);
+        conv_plain(Ly.k, X, Kp, 1, 0, nullptr, 1, stream_);
+        linear_tokmajor(Ly.v, X, VT, H, stream_);
+        grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxT, maxT, inv_scale);
+        grouped(Ly.pos_k.p, ldp, Q.p, Q.ld, C2P, lds, d_g + ng, wlen, maxT, 1.0f);
+        grouped(Kp.p, Kp.ld, Ly.pos_q.p, ldp, P2C, win_ld, d_g + 2 * ng, maxT, wlen, 1.0f);
+        deberta_softmax(d_ag, ng, maxT, S, C2P, P2C, d_tab, maxT - 1, span, win_lo, win_ld, inv_scale, lay.d_mask, stream_);
+        grouped(VT, H, S, lds, ctx.p, ctx.ld, d_g + 3 * ng, d, maxT, 1.0f);
+        conv_plain(Ly.o, ctx, A, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &X);
+        layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
+        conv_plain(Ly.ffn1, A, F, 1, 0, nullptr, 1, stream_, ACT_GELU);
+        conv_plain(Ly.ffn2, F, X, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &A);
+        layernorm_ch(X, X, Ly.ln2_g, Ly.ln2_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
+    }
+    out_ = X;
+}
+
+void BertModel::copy_out(float* host) {
+    HIP_CHECK(hipSetDevice(device_));
+    const int H = cfg_.hidden;
+    int64_t total = 0;
+    for (int v : layout_.len) total += v;
+    float* d_out = arena_.array<float>((size_t)total * H);
+    int64_t off = 0;
+    for (int i = 0; i < layout_.n; ++i) {
+        transpose_out(out_, layout_.start[i], layout_.len[i], d_out + off * H, stream_);
+        off += layout_.len[i];
+    }
+    HIP_CHECK(hipMemcpyAsync(host, d_out, sizeof(float) * (size_t)total * H, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+}  // namespace sbv2

@@ -1,0 +1,160 @@
+// Arena, weight-blob parser, error plumbing (host only).
+#include "common.h"
+
+#include <cstring>
+
+namespace sbv2 {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+size_t Arena::capacity() const {
+    size_t t = 0;
+    for (auto& c : chunks_) t += c.cap;
+    return t;
+}
+void Arena::release() {
+    for (auto& c : chunks_) (void)hipFree(c.base);
+    chunks_.clear();
+    cur_ = 0;
+}
+void Arena::reset() {
+    if (chunks_.size() > 1) {  // grew during the last pass: one allocation of the total size from now on
+        const size_t total = capacity();
+        HIP_CHECK(hipDeviceSynchronize());
+        release();
+        Chunk c{nullptr, total + total / 8, 0};
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.base), c.cap));
+        chunks_.push_back(c);
+    }
+    for (auto& c : chunks_) c.off = 0;
+    cur_ = 0;
+}
+void Arena::rewind(const Mark& m) {
+    if (chunks_.empty()) return;
+    for (size_t i = m.chunk + 1; i < chunks_.size(); ++i) chunks_[i].off = 0;
+    chunks_[m.chunk].off = m.off;
+    cur_ = m.chunk;
+}
+void* Arena::alloc(size_t bytes) {
+    bytes = (bytes + 255) / 256 * 256;
+    for (; cur_ < chunks_.size(); ++cur_) {
+        Chunk& c = chunks_[cur_];
+        if (c.off + bytes <= c.cap) {
+            void* p = c.base + c.off;
+            c.off += bytes;
+            return p;
+        }
+    }
+    Chunk c{nullptr, std::max(bytes, (size_t)256 << 20), 0};
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.base), c.cap));
+    c.off = bytes;
+    chunks_.push_back(c);
+    cur_ = chunks_.size() - 1;
+    return c.base;
+}
+Plane Arena::plane(int C, int L) {
+    Plane pl;
+    pl.C = C;
+    pl.L = L;
+    pl.ld = round_up(L, 64);
+    pl.p = static_cast<float*>(alloc(sizeof(float) * (size_t)C * pl.ld));
+    return pl;
+}
+
+const HostTensor& Blob::get(const std::string& name) const {
+    auto it = tensors.find(name);
+    if (it == tensors.end()) throw Error("weight blob has no tensor '" + name + "'");
+    return it->second;
+}
+
+Blob parse_blob(const uint8_t* b, size_t n) {
+    SBV2_REQUIRE(b && n >= 24 && std::memcmp(b, "SBV2W001", 8) == 0,
+                 "model bytes are not an SBV2W001 weight container (ONNX import is not built yet)");
+    Blob out;
+    uint32_t nt;
+    uint64_t jl;
+    std::memcpy(&out.kind, b + 8, 4);
+    std::memcpy(&nt, b + 12, 4);
+    std::memcpy(&jl, b + 16, 8);
+    size_t pos = 24;
+    SBV2_REQUIRE(pos + jl <= n, "truncated weight container");
+    out.config_json.assign(reinterpret_cast<const char*>(b + pos), jl);
+    pos += jl;
+    for (uint32_t i = 0; i < nt; ++i) {
+        SBV2_REQUIRE(pos + 2 <= n, "truncated weight container");
+        uint16_t nl;
+        std::memcpy(&nl, b + pos, 2);
+        pos += 2;
+        SBV2_REQUIRE(pos + nl + 4 <= n, "truncated weight container");
+        std::string name(reinterpret_cast<const char*>(b + pos), nl);
+        pos += nl;
+        uint32_t nd;
+        std::memcpy(&nd, b + pos, 4);
+        pos += 4;
+        SBV2_REQUIRE(nd <= 8 && pos + 8 * (size_t)nd + 8 <= n, "truncated weight container");
+        HostTensor t;
+        for (uint32_t d = 0; d < nd; ++d) {
+            uint64_t v;
+            std::memcpy(&v, b + pos, 8);
+            pos += 8;
+            t.dims.push_back((int64_t)v);
+        }
+        uint64_t off;
+        std::memcpy(&off, b + pos, 8);
+        pos += 8;
+        SBV2_REQUIRE(off % 4 == 0 && off + (uint64_t)t.numel() * 4 <= n, "tensor data out of range");
+        t.data = reinterpret_cast<const float*>(b + off);
+        out.tensors.emplace(std::move(name), std::move(t));
+    }
+    return out;
+}
+
+static size_t find_key(const std::string& js, const std::string& key) {
+    const std::string pat = "\"" + key + "\"";
+    size_t p = js.find(pat);
+    if (p == std::string::npos) throw Error("config has no key '" + key + "'");
+    p = js.find(':', p + pat.size());
+    SBV2_REQUIRE(p != std::string::npos, "malformed config json");
+    return p + 1;
+}
+double json_number(const std::string& js, const std::string& key) { return std::strtod(js.c_str() + find_key(js, key), nullptr); }
+std::vector<int> json_int_array(const std::string& js, const std::string& key) {
+    size_t p = js.find('[', find_key(js, key));
+    std::vector<int> v;
+    ++p;
+    while (p < js.size() && js[p] != ']') {
+        char* end;
+        long x = std::strtol(js.c_str() + p, &end, 10);
+        if (end == js.c_str() + p) { ++p; continue; }
+        v.push_back((int)x);
+        p = end - js.c_str();
+    }
+    return v;
+}
+std::vector<std::vector<int>> json_int_array2(const std::string& js, const std::string& key) {
+    size_t p = js.find('[', find_key(js, key));
+    std::vector<std::vector<int>> out;
+    ++p;
+    int depth = 1;
+    while (p < js.size() && depth > 0) {
+        if (js[p] == '[') {
+            out.emplace_back();
+            ++depth; ++p;
+        } else if (js[p] == ']') {
+            --depth; ++p;
+        } else if ((js[p] >= '0' && js[p] <= '9') || js[p] == '-') {
+            char* end;
+            long x = std::strtol(js.c_str() + p, &end, 10);
+            SBV2_REQUIRE(!out.empty(), "malformed nested int array");
+            out.back().push_back((int)x);
+            p = end - js.c_str();
+        } else {
+            ++p;
+        }
+    }
+    return out;
+}
+
+}  // namespace sbv2

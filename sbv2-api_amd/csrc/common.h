@@ -1,0 +1,148 @@
+// Shared host-side declarations for libsbv2_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sbv2 {
+
+void set_last_error(const std::string& msg);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            throw ::sbv2::Error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                                std::to_string(__LINE__) + ")");                                 \
+    } while (0)
+
+#define SBV2_REQUIRE(cond, msg)                                                          \
+    do {                                                                                 \
+        if (!(cond)) throw ::sbv2::Error(std::string(msg) + " [" #cond "]");             \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------------
+// Device memory: one growable arena per model handle.  Activations are "planes": [C][ld] f32,
+// channel-major with the time/token axis contiguous (the layout every kernel here assumes).
+// ---------------------------------------------------------------------------------------------
+struct Plane {
+    float* p = nullptr;
+    int C = 0;   // rows (channels)
+    int L = 0;   // valid columns
+    int ld = 0;  // row pitch in floats (multiple of 4, base 16-byte aligned)
+    Plane rows(int c0, int n) const { return Plane{p + (size_t)c0 * ld, n, L, ld}; }
+};
+
+class Arena {
+  public:
+    struct Mark {
+        size_t chunk, off;
+    };
+    ~Arena() { release(); }
+    // Start a new forward pass: keeps the memory, consolidates into one chunk if the last pass had to grow.
+    void reset();
+    void* alloc(size_t bytes);
+    Plane plane(int C, int L);
+    template <class T>
+    T* array(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+    Mark mark() const { return Mark{cur_, chunks_.empty() ? 0 : chunks_[cur_].off}; }
+    void rewind(const Mark& m);  // stack discipline: everything allocated after `m` is dead
+    void release();
+    size_t capacity() const;
+
+  private:
+    struct Chunk {
+        char* base;
+        size_t cap, off;
+    };
+    std::vector<Chunk> chunks_;
+    size_t cur_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Weight blob ("SBV2W001", see sbv2-api_amd/synth.py)
+// ---------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> dims;
+    const float* data = nullptr;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : dims) n *= d;
+        return n;
+    }
+};
+
+struct Blob {
+    uint32_t kind = 0;
+    std::string config_json;
+    std::map<std::string, HostTensor> tensors;
+    const HostTensor& get(const std::string& name) const;
+    bool has(const std::string& name) const { return tensors.count(name) != 0; }
+};
+
+Blob parse_blob(const uint8_t* bytes, size_t n);
+// minimal JSON helpers for the flat config object
+double json_number(const std::string& js, const std::string& key);
+std::vector<int> json_int_array(const std::string& js, const std::string& key);
+std::vector<std::vector<int>> json_int_array2(const std::string& js, const std::string& key);
+
+// ---------------------------------------------------------------------------------------------
+// The grouped implicit-GEMM convolution (gemm_conv.hip): C[m][n] (+)= sum_tap sum_k A_tap[k][m] * pre(B[k][n + shift_tap])
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTaps = 12;
+constexpr int kMaxPhases = 8;
+
+struct GemmGroup {
+    int64_t a_off, b_off, c_off, r_off;  // element offsets added to A, B, C, R
+    int M, N, K;
+    int nb;  // valid B columns for this group: B[k][j] is read as 0 unless 0 <= j < nb
+};
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum BiasMode { BIAS_NONE = 0, BIAS_ROW = 1, BIAS_COL = 2 };
+
+struct ConvParams {
+    const float* A = nullptr;  // [tap][K][lda]: k-major, m contiguous
+    int lda = 0;
+    int64_t a_tap_stride = 0;
+    const float* B = nullptr;  // [K][ldb]: k-major, n contiguous
+    int ldb = 0;
+    float* C = nullptr;
+    int ldc = 0;
+    int M = 0, N = 0, K = 0;
+    int nb = 0;  // valid B columns (zero fill outside)
+    int ntaps = 1;
+    int shift[kMaxTaps] = {0};
+    const float* bias = nullptr;
+    int bias_mode = BIAS_NONE;
+    float pre_slope = 1.0f;  // leaky-ReLU slope applied to B while staging (1 = identity)
+    int act = ACT_NONE;
+    float alpha = 1.0f, beta = 1.0f;
+    const float* R = nullptr;  // residual, same indexing as C
+    int ldr = 0;
+    int accumulate = 0;                    // C += result
+    const unsigned char* mask = nullptr;   // output column c is kept iff mask[c / mask_div]
+    int mask_div = 1;
+    int out_stride = 1;      // polyphase transposed conv: column = n * out_stride + phase_off[m / phase_rows]
+    int phase_rows = 1 << 30;  // row = m % phase_rows
+    int phase_off[kMaxPhases] = {0};
+    const GemmGroup* groups = nullptr;  // device pointer; when set, blockIdx.z selects the group
+    int ngroups = 1;
+    int maxM = 0, maxN = 0;  // grid extents when grouped
+};
+
+void launch_conv(const ConvParams& p, hipStream_t stream);
+
+}  // namespace sbv2

@@ -1,0 +1,320 @@
+// Grouped implicit-GEMM 1-D convolution on the gfx950 f32 matrix cores.
+//
+//   C[m][n] (+)= epilogue( sum_tap sum_k A_tap[k][m] * pre(B[k][n + shift_tap]) )
+//
+// Both operands are k-major ("planes": [K][ld], the m / n axis contiguous), so the same kernel serves
+//   * Conv1d / dilated Conv1d (A = weights packed [tap][Cin][Cout], B = activation plane, shifts = taps),
+//   * ConvTranspose1d as polyphase convolutions (row m = phase * Cout + co, strided output columns),
+//   * Linear / 1x1 conv (one tap), with either operand in the "weight" role (bias per row or per column),
+//   * the attention products Q^T K, P V, position terms (A and B both activation planes, grouped by
+//     (utterance, head) through GemmGroup descriptors).
+//
+// What the reference does here: nothing — these are the Conv/MatMul/Gemm nodes ONNX Runtime executes
+// inside `session.run` (crates/sbv2_core/src/model.rs:91, bert.rs:11).
+//
+// Machine mapping (MI355X_MICROARCH.md / cdna_hip_programming.md §3 "FP32-input MFMA"):
+//   v_mfma_f32_32x32x2_f32 (or 16x16x4 for 16-row problems): exact f32, 64 FLOP/clk/SIMD.
+//   A lane layout  A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]  -> with k-major LDS
+//   tiles every operand fetch is a conflict-free ds_read_b32 of 32 consecutive dwords per half-wave.
+//   One workgroup = 4 waves computes an MT x NT tile; per input-channel chunk (KC rows) the B window
+//   [KC][NT + tap span] is staged ONCE in LDS (leaky-ReLU fused into the staging) and re-used by every tap;
+//   the per-tap weight tile [KC][MT] is double-buffered; global loads for step s+1 are issued before the
+//   MFMA block of step s and written to LDS after it (one barrier per step).
+#include "common.h"
+
+namespace sbv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kMaxSpan = 64;  // max (max shift - floor4(min shift)), host-checked
+
+struct KernelParams {
+    ConvParams p;
+    int xw;       // LDS pitch of the B window (floats)
+    int wshift0;  // floor4(min shift)
+    int mask_shift;
+};
+
+template <int MF>
+struct Mfma;
+template <>
+struct Mfma<32> {
+    using acc_t = f32x16;
+    static constexpr int KS = 2, NACC = 16;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <>
+struct Mfma<16> {
+    using acc_t = f32x4;
+    static constexpr int KS = 4, NACC = 4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+__device__ __forceinline__ float4 load4_guard(const float* src, int j, int lo, int hi) {
+    // src points at column j; columns outside [lo, hi) read as zero.  src is 16-byte aligned when j % 4 == 0.
+    if (j >= lo && j + 3 < hi) return *reinterpret_cast<const float4*>(src);
+    float4 v;
+    v.x = (j >= lo && j < hi) ? src[0] : 0.f;
+    v.y = (j + 1 >= lo && j + 1 < hi) ? src[1] : 0.f;
+    v.z = (j + 2 >= lo && j + 2 < hi) ? src[2] : 0.f;
+    v.w = (j + 3 >= lo && j + 3 < hi) ? src[3] : 0.f;
+    return v;
+}
+
+template <int MF, int TM, int TN, int WM, int WN, int KC>
+__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams kp) {
+    using MM = Mfma<MF>;
+    constexpr int MT = MF * TM * WM;
+    constexpr int NT = MF * TN * WN;
+    constexpr int F4W = KC * MT / 4;
+    constexpr int NW = (F4W + kThreads - 1) / kThreads;
+    constexpr int NX = (KC * (NT + kMaxSpan + (MF == 16 ? 32 : 0)) / 4 + kThreads - 1) / kThreads;  // MF16 pads the pitch to 16 mod 32
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    const ConvParams& p = kp.p;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int XW = kp.xw;
+    float* ws = smem;                 // [2][KC][MT]
+    float* xs = smem + 2 * KC * MT;   // [2][KC][XW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave / WN) * (MF * TM);
+    const int wn0 = (wave % WN) * (MF * TN);
+
+    int M = p.M, N = p.N, K = p.K, nb = p.nb;
+    const float* Ag = p.A;
+    const float* Bg = p.B;
+    float* Cg = p.C;
+    const float* Rg = p.R;
+    if (p.groups) {
+        const GemmGroup g = p.groups[blockIdx.z];
+        M = g.M; N = g.N; K = g.K; nb = g.nb;
+        Ag += g.a_off; Bg += g.b_off; Cg += g.c_off;
+        if (Rg) Rg += g.r_off;
+    }
+    const int m0 = blockIdx.y * MT;
+    const int n0 = blockIdx.x * NT;
+    if (m0 >= M || n0 >= N) return;
+
+    const int ntaps = p.ntaps;
+    const int nchunks = (K + KC - 1) / KC;
+    const int nsteps = nchunks * ntaps;
+    const int wstart = n0 + kp.wshift0;
+    const int xw4 = XW >> 2;
+    const int f4x = KC * xw4;
+    const float slope = p.pre_slope;
+
+    typename MM::acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MM::NACC; ++r) acc[i][j][r] = 0.f;
+
+    float4 rw[NW];
+    float4 rx[NX];
+
+    auto load_w = [&](int tap, int k0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + i * kThreads;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < F4W) {
+                const int kr = idx / (MT / 4);
+                const int m = m0 + (idx % (MT / 4)) * 4;
+                const int k = k0 + kr;
+                if (k < K && m < M) v = load4_guard(Ag + (int64_t)tap * p.a_tap_stride + (int64_t)k * p.lda + m, m, 0, M);
+            }
+            rw[i] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + i * kThreads;
+            if (idx < F4W) *reinterpret_cast<float4*>(ws + buf * (KC * MT) + idx * 4) = rw[i];
+        }
+    };
+    auto load_x = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * kThreads;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < f4x) {
+                const int kr = idx / xw4;
+                const int j = wstart + (idx - kr * xw4) * 4;
+                const int k = k0 + kr;
+                if (k < K) v = load4_guard(Bg + (int64_t)k * p.ldb + j, j, 0, nb);
+                if (slope != 1.0f) {
+                    v.x = v.x >= 0.f ? v.x : v.x * slope;
+                    v.y = v.y >= 0.f ? v.y : v.y * slope;
+                    v.z = v.z >= 0.f ? v.z : v.z * slope;
+                    v.w = v.w >= 0.f ? v.w : v.w * slope;
+                }
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * kThreads;
+            if (idx < f4x) *reinterpret_cast<float4*>(xs + buf * (KC * XW) + idx * 4) = rx[i];
+        }
+    };
+
+    load_x(0);
+    load_w(0, 0);
+    store_x(0);
+    store_w(0);
+    __syncthreads();
+
+    const int lrow = lane / MF;  // k row inside one MFMA k-step
+    const int lcol = lane % MF;
+    int tap = 0, chunk = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == ntaps) { ntap = 0; nchunk = chunk + 1; }
+        const bool has_next = s + 1 < nsteps;
+        const bool new_chunk = has_next && ntap == 0;
+        if (has_next) load_w(ntap, nchunk * KC);
+        if (new_chunk) load_x(nchunk * KC);
+
+        const float* wsb = ws + (s & 1) * (KC * MT) + wm0 + lcol;
+        const float* xsb = xs + (chunk & 1) * (KC * XW) + wn0 + lcol + (p.shift[tap] - kp.wshift0);
+#pragma unroll
+        for (int kk = 0; kk < KC / MM::KS; ++kk) {
+            const int kr = kk * MM::KS + lrow;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = wsb[kr * MT + i * MF];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = xsb[kr * XW + j * MF];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MM::run(a[i], b[j], acc[i][j]);
+        }
+
+        if (has_next) store_w((s + 1) & 1);
+        if (new_chunk) store_x(nchunk & 1);
+        __syncthreads();
+        tap = ntap;
+        chunk = nchunk;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    const bool phased = p.phase_rows < (1 << 30);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < MM::NACC; ++r) {
+            const int m = m0 + wm0 + i * MF + MM::row(lane, r);
+            if (m >= M) continue;
+            int orow = m, po = 0, ostride = 1;
+            if (phased) {
+                const int ph = m / p.phase_rows;
+                orow = m - ph * p.phase_rows;
+                ostride = p.out_stride;
+#pragma unroll
+                for (int q = 0; q < kMaxPhases; ++q) po = (ph == q) ? p.phase_off[q] : po;
+            }
+            const float brow = (p.bias_mode == BIAS_ROW) ? p.bias[orow] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * MF + lcol;
+                if (n >= N) continue;
+                float v = acc[i][j][r] + brow;
+                if (p.bias_mode == BIAS_COL) v += p.bias[n];
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                v *= p.alpha;
+                const int ocol = n * ostride + po;
+                if (Rg) v += Rg[(int64_t)orow * p.ldr + ocol];
+                v *= p.beta;
+                float* dst = Cg + (int64_t)orow * p.ldc + ocol;
+                if (p.accumulate) v += *dst;
+                if (p.mask) {
+                    const int mi = kp.mask_shift >= 0 ? (ocol >> kp.mask_shift) : (ocol / p.mask_div);
+                    if (!p.mask[mi]) v = 0.f;
+                }
+                *dst = v;
+            }
+        }
+    }
+}
+
+template <int MF, int TM, int TN, int WM, int WN, int KC>
+static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stream) {
+    constexpr int MT = MF * TM * WM;
+    constexpr int NT = MF * TN * WN;
+    KernelParams kp = kp0;
+    const ConvParams& p = kp.p;
+    int smin = p.shift[0], smax = p.shift[0];
+    for (int t = 1; t < p.ntaps; ++t) {
+        smin = std::min(smin, p.shift[t]);
+        smax = std::max(smax, p.shift[t]);
+    }
+    const int w0 = (smin >= 0) ? (smin / 4) * 4 : -(((-smin) + 3) / 4) * 4;
+    int span = round_up(smax - w0, 4);
+    SBV2_REQUIRE(span <= kMaxSpan, "conv tap span too large for the staged window");
+    int xw = NT + span;
+    if (MF == 16) {  // rows k and k+1 of a half-wave must land on different bank halves: pitch = 16 (mod 32)
+        while ((xw & 31) != 16) xw += 4;
+    }
+    kp.xw = xw;
+    kp.wshift0 = w0;
+    const size_t lds = sizeof(float) * (2 * KC * MT + 2 * KC * xw);
+    dim3 grid((Nx + NT - 1) / NT, (Mx + MT - 1) / MT, p.groups ? p.ngroups : 1);
+    auto kern = conv_gemm_kernel<MF, TM, TN, WM, WN, KC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, stream, kp);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_conv(const ConvParams& p, hipStream_t stream) {
+    SBV2_REQUIRE(p.ntaps >= 1 && p.ntaps <= kMaxTaps, "bad tap count");
+    SBV2_REQUIRE((p.lda & 3) == 0 && (p.ldb & 3) == 0, "operand pitch must be a multiple of 4 floats");
+    KernelParams kp;
+    kp.p = p;
+    kp.mask_shift = -1;
+    if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
+        int s = 0;
+        while ((1 << s) < p.mask_div) ++s;
+        kp.mask_shift = s;
+    }
+    const int Mx = p.groups ? p.maxM : p.M;
+    const int Nx = p.groups ? p.maxN : p.N;
+    if (Mx <= 0 || Nx <= 0) return;
+    const int64_t z = p.groups ? p.ngroups : 1;
+    auto blocks = [&](int mt, int nt) { return z * ((Mx + mt - 1) / mt) * (int64_t)((Nx + nt - 1) / nt); };
+    // tile choice: largest tile that still gives >= 2 workgroups per CU; 16-row MFMA for 16-row problems
+    if (Mx <= 16) return launch_cfg<16, 1, 4, 1, 4, 16>(kp, Mx, Nx, stream);
+    if (Mx <= 32) {
+        if (blocks(32, 256) >= 512) return launch_cfg<32, 1, 2, 1, 4, 16>(kp, Mx, Nx, stream);
+        return launch_cfg<32, 1, 1, 1, 4, 16>(kp, Mx, Nx, stream);
+    }
+    const bool fits128 = Mx > 64 && (Mx % 128 == 0 || Mx % 128 > 64);  // a 128-row tile wastes < half of its last tile
+    if (fits128 && blocks(128, 256) >= 512) return launch_cfg<32, 2, 4, 2, 2, 16>(kp, Mx, Nx, stream);
+    if (fits128 && blocks(128, 128) >= 512) return launch_cfg<32, 2, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+    if (blocks(64, 256) >= 512) return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
+    if (blocks(64, 128) >= 256) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+    return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
+}
+
+}  // namespace sbv2

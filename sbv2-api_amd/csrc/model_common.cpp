@@ -1,0 +1,193 @@
+// Weight packing and launch helpers shared by the DeBERTa and VITS model objects.
+#include <algorithm>
+#include <cstring>
+
+#include "models.h"
+
+namespace sbv2 {
+
+WeightStore::~WeightStore() {
+    for (void* p : allocs_) (void)hipFree(p);
+}
+
+float* WeightStore::upload(const float* host, size_t n) {
+    float* d = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), std::max<size_t>(n, 4) * sizeof(float)));
+    allocs_.push_back(d);
+    HIP_CHECK(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+    bytes_ += n * sizeof(float);
+    return d;
+}
+
+float* WeightStore::tensor(const std::string& name) {
+    const HostTensor& t = blob_.get(name);
+    return upload(t.data, (size_t)t.numel());
+}
+
+PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
+    const HostTensor& t = blob_.get(prefix + ".weight");
+    SBV2_REQUIRE(t.dims.size() == 3, "conv weight must be [Cout][Cin][k]: " + prefix);
+    PackedConv pc;
+    pc.cout = (int)t.dims[0];
+    pc.cin = (int)t.dims[1];
+    pc.k = (int)t.dims[2];
+    SBV2_REQUIRE(pc.k <= kMaxTaps, "kernel size exceeds the compiled tap limit: " + prefix);
+    pc.lda = round_up(pc.cout, 4);
+    std::vector<float> h((size_t)pc.k * pc.cin * pc.lda, 0.f);
+    for (int co = 0; co < pc.cout; ++co)
+        for (int ci = 0; ci < pc.cin; ++ci)
+            for (int j = 0; j < pc.k; ++j) h[((size_t)j * pc.cin + ci) * pc.lda + co] = t.data[((size_t)co * pc.cin + ci) * pc.k + j];
+    pc.w = upload(h.data(), h.size());
+    if (bias && blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias");
+    return pc;
+}
+
+PackedConv WeightStore::linear(const std::string& prefix) {
+    const HostTensor& t = blob_.get(prefix + ".weight");
+    SBV2_REQUIRE(t.dims.size() == 2, "linear weight must be [out][in]: " + prefix);
+    PackedConv pc;
+    pc.cout = (int)t.dims[0];
+    pc.cin = (int)t.dims[1];
+    pc.k = 1;
+    pc.lda = round_up(pc.cout, 4);
+    std::vector<float> h((size_t)pc.cin * pc.lda, 0.f);
+    for (int co = 0; co < pc.cout; ++co)
+        for (int ci = 0; ci < pc.cin; ++ci) h[(size_t)ci * pc.lda + co] = t.data[(size_t)co * pc.cin + ci];
+    pc.w = upload(h.data(), h.size());
+    if (blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias");
+    return pc;
+}
+
+// ConvTranspose1d y[co][s*q + r] = b[co] + sum_ci sum_t W[ci][co][s*t + r + p] * x[ci][q - t]; output phases r that use the
+// same set of t are computed by one launch whose rows are (phase, co).
+PackedUpsample WeightStore::upsample(const std::string& prefix, int stride, int padding) {
+    const HostTensor& t = blob_.get(prefix + ".weight");
+    SBV2_REQUIRE(t.dims.size() == 3, "transposed conv weight must be [Cin][Cout][k]: " + prefix);
+    PackedUpsample u;
+    u.cin = (int)t.dims[0];
+    u.cout = (int)t.dims[1];
+    u.stride = stride;
+    const int k = (int)t.dims[2];
+    SBV2_REQUIRE(k - 2 * padding == stride, "transposed conv must upsample exactly by its stride (k - 2p == s): " + prefix);
+    SBV2_REQUIRE(stride <= 64, "stride too large");
+    std::vector<std::vector<int>> tsets(stride);
+    for (int r = 0; r < stride; ++r)
+        for (int tt = -k; tt <= k; ++tt) {
+            const int j = stride * tt + r + padding;
+            if (j >= 0 && j < k) tsets[r].push_back(tt);
+        }
+    std::vector<bool> done(stride, false);
+    for (int r = 0; r < stride; ++r) {
+        if (done[r]) continue;
+        std::vector<int> phases;
+        for (int r2 = r; r2 < stride && (int)phases.size() < kMaxPhases; ++r2)
+            if (!done[r2] && tsets[r2] == tsets[r]) {
+                phases.push_back(r2);
+                done[r2] = true;
+            }
+        PackedUpsample::Grp g;
+        g.ntaps = (int)tsets[r].size();
+        SBV2_REQUIRE(g.ntaps >= 1 && g.ntaps <= kMaxTaps, "bad polyphase tap count");
+        g.nph = (int)phases.size();
+        const int M = g.nph * u.cout;
+        g.lda = round_up(M, 4);
+        std::vector<float> h((size_t)g.ntaps * u.cin * g.lda, 0.f);
+        for (int ti = 0; ti < g.ntaps; ++ti) {
+            g.shift[ti] = -tsets[r][ti];
+            for (int pi = 0; pi < g.nph; ++pi) {
+                const int j = stride * tsets[r][ti] + phases[pi] + padding;
+                for (int ci = 0; ci < u.cin; ++ci)
+                    for (int co = 0; co < u.cout; ++co)
+                        h[((size_t)ti * u.cin + ci) * g.lda + pi * u.cout + co] = t.data[((size_t)ci * u.cout + co) * k + j];
+            }
+        }
+        for (int pi = 0; pi < kMaxPhases; ++pi) g.phase_off[pi] = pi < g.nph ? phases[pi] : 0;
+        g.w = upload(h.data(), h.size());
+        u.groups.push_back(g);
+    }
+    u.bias = tensor(prefix + ".bias");
+    return u;
+}
+
+SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, const unsigned char* extra_mask) {
+    SegLayout l;
+    l.n = (int)lens.size();
+    int pos = 0;
+    for (int v : lens) {
+        const int st = round_up(pos, 4);
+        l.start.push_back(st);
+        l.len.push_back(v);
+        pos = st + v + gap;
+    }
+    l.L = round_up(std::max(pos, 4), 4);
+    std::vector<int> seg(l.L, -1);
+    std::vector<unsigned char> mask(l.L, 0);
+    size_t e = 0;
+    for (int i = 0; i < l.n; ++i)
+        for (int t = 0; t < l.len[i]; ++t, ++e) {
+            seg[l.start[i] + t] = i;
+            mask[l.start[i] + t] = extra_mask ? extra_mask[e] : 1;
+        }
+    l.d_seg_of = arena.array<int>(l.L);
+    l.d_mask = arena.array<unsigned char>(l.L);
+    l.d_start = arena.array<int>(l.n);
+    l.d_len = arena.array<int>(l.n);
+    HIP_CHECK(hipMemcpy(l.d_seg_of, seg.data(), sizeof(int) * l.L, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(l.d_mask, mask.data(), l.L, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(l.d_start, l.start.data(), sizeof(int) * l.n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(l.d_len, l.len.data(), sizeof(int) * l.n, hipMemcpyHostToDevice));
+    return l;
+}
+
+void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div, hipStream_t s,
+                int act, float pre_slope, const Plane* res, float alpha, float beta, int accumulate) {
+    SBV2_REQUIRE(x.C == w.cin && y.C == w.cout, "conv channel mismatch");
+    ConvParams p;
+    p.A = w.w;
+    p.lda = w.lda;
+    p.a_tap_stride = w.tap_stride();
+    p.B = x.p;
+    p.ldb = x.ld;
+    p.nb = x.L;
+    p.C = y.p;
+    p.ldc = y.ld;
+    p.M = w.cout;
+    p.N = y.L;
+    p.K = w.cin;
+    p.ntaps = w.k;
+    for (int j = 0; j < w.k; ++j) p.shift[j] = j * dil - pad_l;
+    p.bias = w.bias;
+    p.bias_mode = w.bias ? BIAS_ROW : BIAS_NONE;
+    p.pre_slope = pre_slope;
+    p.act = act;
+    p.alpha = alpha;
+    p.beta = beta;
+    if (res) {
+        p.R = res->p;
+        p.ldr = res->ld;
+    }
+    p.accumulate = accumulate;
+    p.mask = mask;
+    p.mask_div = mask_div;
+    launch_conv(p, s);
+}
+
+void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s) {
+    SBV2_REQUIRE(w.k == 1 && x.C == w.cin, "token-major linear: shape mismatch");
+    ConvParams p;
+    p.A = x.p;  // A[k = cin][m = token]
+    p.lda = x.ld;
+    p.B = w.w;  // B[k = cin][n = cout]
+    p.ldb = w.lda;
+    p.nb = w.cout;
+    p.C = y;
+    p.ldc = ldy;
+    p.M = x.L;
+    p.N = w.cout;
+    p.K = w.cin;
+    p.bias = w.bias;
+    p.bias_mode = w.bias ? BIAS_COL : BIAS_NONE;
+    launch_conv(p, s);
+}
+
+}  // namespace sbv2

@@ -1,0 +1,242 @@
+// Host-side model objects behind the C ABI: weights resident in HBM, per-call workspace arena,
+// batched forward passes expressed as sequences of kernel launches on one HIP stream.
+#pragma once
+#include "common.h"
+#include "ops.h"
+
+#include <memory>
+
+namespace sbv2 {
+
+// Weights in the layout gemm_conv expects: [tap][Cin][lda] (k-major, Cout contiguous).
+struct PackedConv {
+    float* w = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, k = 1, lda = 0;
+    int64_t tap_stride() const { return (int64_t)cin * lda; }
+};
+// One ConvTranspose1d split into groups of output phases that share the same input taps.
+struct PackedUpsample {
+    struct Grp {
+        float* w = nullptr;
+        int lda = 0, ntaps = 0, nph = 0;
+        int shift[kMaxTaps];
+        int phase_off[kMaxPhases];
+    };
+    std::vector<Grp> groups;
+    float* bias = nullptr;
+    int cin = 0, cout = 0, stride = 1;
+};
+
+// Packed segments along the time axis: utterance i occupies columns [start[i], start[i]+len[i]); every start is a
+// multiple of 4 and at least `gap` zero columns separate neighbours (the zero padding of every 'same' convolution).
+struct SegLayout {
+    int n = 0, L = 0;
+    std::vector<int> start, len;
+    int* d_seg_of = nullptr;
+    unsigned char* d_mask = nullptr;
+    int* d_start = nullptr;
+    int* d_len = nullptr;
+    int max_len() const {
+        int m = 0;
+        for (int v : len) m = std::max(m, v);
+        return m;
+    }
+};
+SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, const unsigned char* extra_mask = nullptr);
+
+class WeightStore {
+  public:
+    explicit WeightStore(const Blob& b) : blob_(b) {}
+    ~WeightStore();
+    float* upload(const float* host, size_t n);
+    float* tensor(const std::string& name);                      // raw copy
+    PackedConv conv(const std::string& prefix, bool bias = true);  // <prefix>.weight [Cout][Cin][k] (+ .bias)
+    PackedConv linear(const std::string& prefix);                // <prefix>.weight [Cout][Cin] + .bias
+    PackedUpsample upsample(const std::string& prefix, int stride, int padding);  // weight [Cin][Cout][k]
+    size_t bytes() const { return bytes_; }
+    const Blob& blob() const { return blob_; }
+
+  private:
+    const Blob& blob_;
+    std::vector<void*> allocs_;
+    size_t bytes_ = 0;
+};
+
+// helpers shared by both models
+void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div, hipStream_t s,
+                int act = ACT_NONE, float pre_slope = 1.0f, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f,
+                int accumulate = 0);
+// y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
+void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s);
+
+struct BertConfig {
+    int vocab, hidden, layers, heads, inter, buckets, max_rel;
+    float eps;
+};
+
+class BertModel {
+  public:
+    BertModel(const Blob& blob, int device);
+    ~BertModel();
+    int device() const { return device_; }
+    const BertConfig& cfg() const { return cfg_; }
+    // ids/mask concatenated over utterances; result stays on the device (out_, layout_)
+    void forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens);
+    void copy_out(float* host);  // [sum S][hidden], utterances concatenated
+    const Plane& out() const { return out_; }
+    const SegLayout& layout() const { return layout_; }
+    hipStream_t stream() const { return stream_; }
+    static std::vector<int> bucket_table(int maxS, int buckets, int max_rel);  // bucket(rel) for rel in [-(maxS-1), maxS-1]
+
+  private:
+    struct Layer {
+        PackedConv q, k, v, o, ffn1, ffn2;
+        float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+        Plane pos_k, pos_q;  // key_proj / query_proj of the LayerNorm'ed relative embeddings: [H][2*span]
+    };
+    int device_;
+    BertConfig cfg_;
+    std::unique_ptr<WeightStore> ws_;
+    float *emb_, *emb_g_, *emb_b_;
+    std::vector<Layer> layers_;
+    Arena arena_;
+    hipStream_t stream_ = nullptr;
+    Plane out_;
+    SegLayout layout_;
+};
+
+struct VitsConfig {
+    int n_vocab, n_tones, n_langs, n_speakers, hidden, inter, filter, heads, enc_layers, enc_kernel, window, gin, style_dim,
+        bert_dim, cond_layer_idx, flow_n, flow_layers, flow_kernel, dp_filter, dp_kernel, sdp_kernel, sdp_flows, sdp_bins,
+        sdp_dds_layers;
+    float sdp_tail;
+    std::vector<int> up_rates, up_kernels, res_kernels;
+    std::vector<std::vector<int>> res_dilations;
+    int up_initial;
+    int hop() const {
+        int h = 1;
+        for (int r : up_rates) h *= r;
+        return h;
+    }
+};
+
+struct VitsBatch {
+    int n = 0;
+    const int64_t* t_lens = nullptr;   // [n]
+    const int64_t* phones = nullptr;   // concatenated
+    const int64_t* tones = nullptr;
+    const int64_t* langs = nullptr;
+    const int64_t* sids = nullptr;     // [n]
+    const float* styles = nullptr;     // [n][style_dim]
+    const float* bert_host = nullptr;  // concatenated [bert_dim][T_i] blocks, or null when bert_dev is given
+    const Plane* bert_dev = nullptr;   // device plane [bert_dim][*] ...
+    const int* bert_map = nullptr;     // ... with HOST map: text column (packed, no gaps, utterance-major) -> source column
+    float sdp_ratio = 0.f, length_scale = 1.f, noise_scale = 0.f, noise_scale_w = 0.f;
+    uint64_t seed = 0;
+    const int64_t* forced_durations = nullptr;  // concatenated, optional
+};
+
+class VitsModel {
+  public:
+    VitsModel(const Blob& blob, int device);
+    ~VitsModel();
+    int device() const { return device_; }
+    const VitsConfig& cfg() const { return cfg_; }
+    void forward(const VitsBatch& b);
+    // results of the last forward
+    const std::vector<int64_t>& pcm_lens() const { return pcm_lens_; }
+    const std::vector<int64_t>& pcm_offs() const { return pcm_offs_; }
+    const float* pcm_device() const { return pcm_; }
+    int64_t pcm_total() const { return pcm_total_; }
+    void copy_pcm(float* host);  // concatenated
+    const std::vector<int>& durations() const { return dur_host_; }   // concatenated predicted w_ceil
+    const std::vector<float>& logw() const { return logw_host_; }
+    hipStream_t stream() const { return stream_; }
+    void set_trace(bool on) { trace_ = on; }
+    // copies a traced plane of the last forward for utterance `utt`: returns rows/cols
+    bool get_trace(const std::string& name, int utt, std::vector<float>& out, int& rows, int& cols);
+
+  private:
+    struct Attn {
+        PackedConv q, k, v, o;
+        float *erk, *erv;
+    };
+    struct EncLayer {
+        Attn attn;
+        float *n1g, *n1b, *n2g, *n2b;
+        PackedConv ffn1, ffn2;
+    };
+    struct Encoder {
+        float *spk_w = nullptr, *spk_b = nullptr;  // [hidden][gin] row-major (linear_vec)
+        std::vector<EncLayer> layers;
+    };
+    struct DDS {
+        std::vector<float*> sep_w, sep_b, n1g, n1b, n2g, n2b;
+        std::vector<PackedConv> pw;
+    };
+    struct ConvFlow {
+        float *pre_w, *pre_b;
+        DDS dds;
+        PackedConv proj;
+    };
+    struct Coupling {
+        PackedConv pre, post;
+        Encoder enc;
+    };
+    struct ResBranch {
+        std::vector<PackedConv> c1, c2;
+        std::vector<int> dil;
+        int k;
+    };
+    struct Stage {
+        PackedUpsample up;
+        std::vector<ResBranch> branches;
+        int ch, rate;
+    };
+    struct TraceEntry {
+        Plane p;
+        const SegLayout* lay;
+        int div;  // columns per layout unit (upsampling factor)
+    };
+
+    Encoder load_encoder(const std::string& prefix, int n_layers);
+    DDS load_dds(const std::string& prefix, int channels);
+    void run_encoder(const Encoder& e, Plane x, const SegLayout& lay, const float* spk_vec, Arena& ar);
+    void run_dds(const DDS& d, Plane x, const SegLayout& lay, Arena& ar);
+    void run_decoder(Plane z, const SegLayout& fl);
+    void trace(const std::string& name, Plane p, const SegLayout& lay, int div = 1);
+
+    int device_;
+    VitsConfig cfg_;
+    std::unique_ptr<WeightStore> ws_;
+    hipStream_t stream_ = nullptr;
+    Arena arena_, keep_;
+    // weights
+    float *emb_g_, *emb_, *tone_emb_, *lang_emb_, *style_w_, *style_b_;
+    PackedConv bert_proj_, enc_proj_;
+    Encoder enc_p_;
+    PackedConv dp_c1_, dp_c2_, dp_proj_;
+    float *dp_n1g_, *dp_n1b_, *dp_n2g_, *dp_n2b_, *dp_cond_w_, *dp_cond_b_;
+    PackedConv sdp_pre_, sdp_proj_;
+    float *sdp_cond_w_, *sdp_cond_b_, *sdp_ea_m_, *sdp_ea_logs_;
+    DDS sdp_dds_;
+    std::vector<ConvFlow> sdp_cf_;  // ConvFlow 2..n (index 0 = flows.3)
+    std::vector<Coupling> flows_;
+    PackedConv dec_pre_;
+    float *dec_cond_w_, *dec_cond_b_, *dec_post_w_;
+    float* dec_cond_vec_ = nullptr;  // cond(g) per utterance of the running forward
+    int dec_post_k_ = 7;
+    std::vector<Stage> stages_;
+    // last-forward results
+    float* pcm_ = nullptr;
+    int64_t pcm_total_ = 0;
+    std::vector<int64_t> pcm_lens_, pcm_offs_;
+    std::vector<int> dur_host_;
+    std::vector<float> logw_host_;
+    bool trace_ = false;
+    std::map<std::string, TraceEntry> traces_;
+    SegLayout tl_, fl_;
+};
+
+}  // namespace sbv2

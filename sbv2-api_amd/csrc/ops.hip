@@ -1,0 +1,568 @@
+// Non-GEMM kernels of the hot path: normalisation, softmax with relative-position terms, embeddings,
+// the stochastic-duration flow (depthwise conv, rational-quadratic spline), duration -> frame expansion,
+// and the final conv_post + tanh.  Activations are channel-major planes [C][ld] with the time axis
+// contiguous, so "one thread per column, loop over channels" is the coalesced pattern used throughout.
+//
+// These are the ONNX nodes (LayerNormalization / Softmax / Gather / Erf / Where / CumSum / ...) that the
+// reference leaves to ONNX Runtime inside session.run (crates/sbv2_core/src/model.rs:91, bert.rs:11); the
+// arithmetic follows oracle/sbv2_oracle.py function by function.
+#include "ops.h"
+
+#include <cfloat>
+
+namespace sbv2 {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------------
+// DeBERTa embeddings: gather + LayerNorm (modeling_deberta_v2.py:518-559), token-major row -> plane column
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamma,
+                                                           const float* beta, float eps, Plane out) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const int id = ids[n];
+    const int tid = threadIdx.x;
+    if (id < 0) {
+        for (int c = tid; c < H; c += 256) out.p[(size_t)c * out.ld + n] = 0.f;
+        return;
+    }
+    const float* row = emb + (size_t)id * H;
+    float s = 0.f;
+    for (int c = tid; c < H; c += 256) s += row[c];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / H;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < H; c += 256) {
+        const float d = row[c] - mean;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / H + eps);
+    for (int c = tid; c < H; c += 256) out.p[(size_t)c * out.ld + n] = (row[c] - mean) * rstd * gamma[c] + beta[c];
+}
+void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamma, const float* beta, float eps, Plane out,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_deberta_embed_ln, dim3(out.L), dim3(256), 0, s, ids, emb, H, gamma, beta, eps, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel LayerNorm over a plane: 32 columns x 8 channel groups per workgroup
+// ------------------------------------------------------------------------------------------------
+template <bool DW>
+__global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps,
+                                                       int act, const float* res, int ldr, const unsigned char* mask,
+                                                       const float* dw_w, const float* dw_b, int dil) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + tx;
+    const bool ok = n < in.L;
+    const int C = in.C;
+    auto val = [&](int c) -> float {
+        if (!DW) return in.p[(size_t)c * in.ld + n];
+        const float* r = in.p + (size_t)c * in.ld;
+        float v = dw_b[c];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = n + (j - 1) * dil;
+            if (q >= 0 && q < in.L) v += dw_w[c * 3 + j] * r[q];
+        }
+        return v;
+    };
+    float s = 0.f;
+    if (ok)
+        for (int c = ty; c < C; c += 8) s += val(c);
+    red[ty][tx] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) mean += red[g][tx];
+    mean /= C;
+    __syncthreads();
+    float q = 0.f;
+    if (ok)
+        for (int c = ty; c < C; c += 8) {
+            const float d = val(c) - mean;
+            q += d * d;
+        }
+    red[ty][tx] = q;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) var += red[g][tx];
+    const float rstd = 1.0f / sqrtf(var / C + eps);
+    if (!ok) return;
+    const bool keep = !mask || mask[n];
+    for (int c = ty; c < C; c += 8) {
+        float v = (val(c) - mean) * rstd * gamma[c] + beta[c];
+        if (act == ACT_GELU) v = gelu_exact(v);
+        if (res) v += res[(size_t)c * ldr + n];
+        out.p[(size_t)c * out.ld + n] = keep ? v : 0.f;
+    }
+}
+void layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
+                  const unsigned char* mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm_ch<false>, dim3((in.L + 31) / 32), dim3(256), 0, s, in, out, gamma, beta, eps, act, res, ldr,
+                       mask, nullptr, nullptr, 1);
+}
+void dds_dw_ln_gelu(Plane in, Plane out, const float* w, const float* b, int dil, const float* gamma, const float* beta,
+                    const unsigned char* mask, hipStream_t s) {
+    SBV2_REQUIRE(in.p != out.p, "depthwise conv cannot run in place");
+    hipLaunchKernelGGL(k_layernorm_ch<true>, dim3((in.L + 31) / 32), dim3(256), 0, s, in, out, gamma, beta, 1e-5f, (int)ACT_GELU,
+                       nullptr, 0, mask, w, b, dil);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DeBERTa disentangled-attention softmax (modeling_deberta_v2.py:233-253, 276-346).
+// S holds the TRANSPOSED content scores S[j][i] = k_j . q_i / scale; one thread owns query column i.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_deberta_softmax(const AttnGroup* groups, float* S, const float* c2pT, const float* p2c,
+                                                         const int* tab, int tab_center, int span, int win_lo, int win_ld,
+                                                         float inv_scale, const unsigned char* tok_mask) {
+    const AttnGroup g = groups[blockIdx.y];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= g.T) return;
+    float* Sg = S + g.s_off;
+    const float* cg = c2pT + g.aux_off;
+    const float* pg = p2c + g.aux2_off;
+    const bool mi = tok_mask[g.col0 + i] != 0;
+    const int hi = 2 * span - 1;
+    float mx = -FLT_MAX;
+    for (int j = 0; j < g.T; ++j) {
+        const int d1 = min(max(tab[tab_center + (i - j)] + span, 0), hi) - win_lo;
+        const int d2 = min(max(-tab[tab_center + (j - i)] + span, 0), hi) - win_lo;
+        float v = Sg[(size_t)j * g.lds + i] + cg[(size_t)d1 * g.lds + i] * inv_scale + pg[(size_t)j * win_ld + d2] * inv_scale;
+        if (!(mi && tok_mask[g.col0 + j])) v = -FLT_MAX;
+        Sg[(size_t)j * g.lds + i] = v;
+        mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < g.T; ++j) {
+        const float e = expf(Sg[(size_t)j * g.lds + i] - mx);
+        Sg[(size_t)j * g.lds + i] = e;
+        sum += e;
+    }
+    for (int j = 0; j < g.T; ++j) Sg[(size_t)j * g.lds + i] /= sum;
+}
+void deberta_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, const float* c2pT, const float* p2c, const int* tab,
+                     int tab_center, int span, int win_lo, int win_ld, float inv_scale, const unsigned char* tok_mask,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_deberta_softmax, dim3((maxT + 63) / 64, ngroups), dim3(64), 0, s, groups, S, c2pT, p2c, tab, tab_center,
+                       span, win_lo, win_ld, inv_scale, tok_mask);
+}
+
+// ------------------------------------------------------------------------------------------------
+// VITS window-relative attention softmax (attentions.MultiHeadAttention.attention).
+// S[j][i] = k_j . q_i / sqrt(dk) (transposed); adds q_i . emb_rel_k[j-i+w] / sqrt(dk) for |j-i| <= w, softmax over j,
+// and saves the +-w band of the probabilities for the relative-value term.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxWin = 4;
+__global__ __launch_bounds__(64) void k_vits_softmax(const AttnGroup* groups, float* S, const float* Q, int ldq, int dk,
+                                                      const float* erk, int w, float qscale, float* pwin) {
+    const AttnGroup g = groups[blockIdx.y];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= g.T) return;
+    float* Sg = S + g.s_off;
+    const float* q = Q + g.qk_off + i;
+    float rk[2 * kMaxWin + 1];
+#pragma unroll
+    for (int r = 0; r < 2 * kMaxWin + 1; ++r) rk[r] = 0.f;
+    for (int d = 0; d < dk; ++d) {
+        const float qv = q[(size_t)d * ldq];
+#pragma unroll
+        for (int r = 0; r < 2 * kMaxWin + 1; ++r)
+            if (r < 2 * w + 1) rk[r] += qv * erk[r * dk + d];
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * kMaxWin + 1; ++r) {
+        const int j = i + r - w;
+        if (r < 2 * w + 1 && j >= 0 && j < g.T) Sg[(size_t)j * g.lds + i] += rk[r] * qscale;
+    }
+    float mx = -FLT_MAX;
+    for (int j = 0; j < g.T; ++j) mx = fmaxf(mx, Sg[(size_t)j * g.lds + i]);
+    float sum = 0.f;
+    for (int j = 0; j < g.T; ++j) {
+        const float e = expf(Sg[(size_t)j * g.lds + i] - mx);
+        Sg[(size_t)j * g.lds + i] = e;
+        sum += e;
+    }
+    for (int j = 0; j < g.T; ++j) Sg[(size_t)j * g.lds + i] /= sum;
+    float* pw = pwin + g.aux_off;
+#pragma unroll
+    for (int r = 0; r < 2 * kMaxWin + 1; ++r) {
+        const int j = i + r - w;
+        if (r < 2 * w + 1) pw[(size_t)r * g.lds + i] = (j >= 0 && j < g.T) ? Sg[(size_t)j * g.lds + i] : 0.f;
+    }
+}
+void vits_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, const float* Q, int ldq, int dk, const float* erk,
+                  int window, float qscale, float* pwin, hipStream_t s) {
+    SBV2_REQUIRE(window <= kMaxWin, "relative attention window larger than the compiled maximum");
+    hipLaunchKernelGGL(k_vits_softmax, dim3((maxT + 63) / 64, ngroups), dim3(64), 0, s, groups, S, Q, ldq, dk, erk, window, qscale,
+                       pwin);
+}
+
+__global__ __launch_bounds__(64) void k_vits_relv_add(const AttnGroup* groups, float* ctx, int ldc, int dk, const float* erv, int w,
+                                                       const float* pwin) {
+    const AttnGroup g = groups[blockIdx.y];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= g.T) return;
+    const float* pw = pwin + g.aux_off;
+    float p[2 * kMaxWin + 1];
+#pragma unroll
+    for (int r = 0; r < 2 * kMaxWin + 1; ++r) p[r] = (r < 2 * w + 1) ? pw[(size_t)r * g.lds + i] : 0.f;
+    float* c = ctx + g.qk_off + i;
+    for (int d = 0; d < dk; ++d) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2 * kMaxWin + 1; ++r)
+            if (r < 2 * w + 1) a += p[r] * erv[r * dk + d];
+        c[(size_t)d * ldc] += a;
+    }
+}
+void vits_relv_add(const AttnGroup* groups, int ngroups, int maxT, float* ctx, int ldc, int dk, const float* erv, int window,
+                   const float* pwin, hipStream_t s) {
+    hipLaunchKernelGGL(k_vits_relv_add, dim3((maxT + 63) / 64, ngroups), dim3(64), 0, s, groups, ctx, ldc, dk, erv, window, pwin);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small per-utterance vector ops
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_add_segvec(Plane x, const float* vec, int vec_ld, const int* seg_of, int div,
+                                                     const unsigned char* mask) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (n >= x.L) return;
+    const int q = n / div;
+    const int sg = seg_of[q];
+    float* p = x.p + (size_t)c * x.ld + n;
+    *p = (sg >= 0 && (!mask || mask[q])) ? *p + vec[(size_t)sg * vec_ld + c] : 0.f;
+}
+void add_segvec(Plane x, const float* vec, int vec_ld, const int* seg_of, int div, const unsigned char* mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_segvec, dim3((x.L + 255) / 256, x.C), dim3(256), 0, s, x, vec, vec_ld, seg_of, div, mask);
+}
+
+__global__ __launch_bounds__(256) void k_linear_vec(const float* W, const float* bias, int M, int K, const float* v, int ldv,
+                                                     float* out, int ldo) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float a = 0.f;
+    for (int k = lane; k < K; k += 64) a += W[(size_t)m * K + k] * v[(size_t)b * ldv + k];
+    a = wave_sum(a);
+    if (lane == 0) out[(size_t)b * ldo + m] = a + (bias ? bias[m] : 0.f);
+}
+void linear_vec(const float* W, const float* bias, int M, int K, const float* v, int ldv, float* out, int ldo, int B,
+                hipStream_t s) {
+    hipLaunchKernelGGL(k_linear_vec, dim3((M + 3) / 4, B), dim3(256), 0, s, W, bias, M, K, v, ldv, out, ldo);
+}
+
+__global__ void k_gather_rows(const float* table, int K, const int* idx, float* out) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < K) out[(size_t)b * K + k] = table[(size_t)idx[b] * K + k];
+}
+void gather_rows(const float* table, int K, const int* idx, float* out, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_rows, dim3((K + 255) / 256, B), dim3(256), 0, s, table, K, idx, out);
+}
+
+// TextEncoder front (models_jp_extra.TextEncoder.forward): (emb + tone + lang + bert_proj + style_proj) * sqrt(H)
+__global__ __launch_bounds__(256) void k_text_embed(const int* phones, const int* tones, const int* langs, const int* seg_of,
+                                                     const float* emb, const float* tone_emb, const float* lang_emb,
+                                                     const float* bertproj, int ldb, const float* styleproj, int lds_, float scale,
+                                                     Plane out) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (n >= out.L) return;
+    const int sg = seg_of[n];
+    const int H = out.C;
+    const int ph = sg >= 0 ? phones[n] : 0, tn = sg >= 0 ? tones[n] : 0, lg = sg >= 0 ? langs[n] : 0;
+    for (int c = threadIdx.x >> 6; c < H; c += 4) {
+        float v = 0.f;
+        if (sg >= 0)
+            v = (emb[(size_t)ph * H + c] + tone_emb[(size_t)tn * H + c] + lang_emb[(size_t)lg * H + c] + bertproj[(size_t)c * ldb + n] +
+                 styleproj[(size_t)sg * lds_ + c]) * scale;
+        out.p[(size_t)c * out.ld + n] = v;
+    }
+}
+void text_embed(const int* phones, const int* tones, const int* langs, const int* seg_of, const float* emb, const float* tone_emb,
+                const float* lang_emb, const float* bertproj, int ldb, const float* styleproj, int lds_, float scale, Plane out,
+                hipStream_t s) {
+    hipLaunchKernelGGL(k_text_embed, dim3((out.L + 63) / 64), dim3(256), 0, s, phones, tones, langs, seg_of, emb, tone_emb, lang_emb,
+                       bertproj, ldb, styleproj, lds_, scale, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stochastic duration predictor pieces (modules.ConvFlow / transforms.py; oracle: conv_flow_reverse, rq_spline_inverse)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convflow_pre(const float* z0, const float* w, const float* b, Plane cond, Plane out,
+                                                       const unsigned char* mask) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (n >= out.L) return;
+    out.p[(size_t)c * out.ld + n] = mask[n] ? w[c] * z0[n] + b[c] + cond.p[(size_t)c * cond.ld + n] : 0.f;
+}
+void convflow_pre(const float* z0, const float* w, const float* b, Plane cond, Plane out, const unsigned char* mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_convflow_pre, dim3((out.L + 255) / 256, out.C), dim3(256), 0, s, z0, w, b, cond, out, mask);
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void k_spline_inverse(Plane params, float* z0, float* z1, float tail, float inv_sqrt_f,
+                                                        const unsigned char* mask, int L) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= L) return;
+    if (!mask[n]) {
+        z0[n] = 0.f;
+        z1[n] = 0.f;
+        return;
+    }
+    const float x = z1[n];
+    if (!(x >= -tail && x <= tail)) return;  // linear tails: identity
+    const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+    const float* P = params.p + n;
+    const size_t ld = params.ld;
+    float cw[NB + 1], ch[NB + 1], dv[NB + 1];
+    auto cum = [&](int base, float mn, float* c) {
+        float u[NB];
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            u[b] = P[(size_t)(base + b) * ld] * inv_sqrt_f;
+            mx = fmaxf(mx, u[b]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            u[b] = expf(u[b] - mx);
+            sum += u[b];
+        }
+        float run = 0.f;
+        c[0] = -tail;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            run += mn + (1.0f - mn * NB) * (u[b] / sum);
+            c[b + 1] = 2.0f * tail * run + (-tail);
+        }
+        c[NB] = tail;
+    };
+    cum(0, min_w, cw);
+    cum(NB, min_h, ch);
+    const float cst = logf(expf(1.0f - min_d) - 1.0f);
+    auto softplus = [](float v) { return v > 20.f ? v : log1pf(expf(v)); };
+    dv[0] = min_d + softplus(cst);
+    dv[NB] = dv[0];
+#pragma unroll
+    for (int b = 1; b < NB; ++b) dv[b] = min_d + softplus(P[(size_t)(2 * NB + b - 1) * ld]);
+    // bin search on the heights (inverse): count of locations <= x, last location nudged by 1e-6
+    int bin = -1;
+#pragma unroll
+    for (int b = 0; b <= NB; ++b) bin += (x >= (b == NB ? ch[b] + 1e-6f : ch[b])) ? 1 : 0;
+    bin = min(max(bin, 0), NB - 1);
+    float in_cw = 0.f, in_w = 0.f, in_ch = 0.f, in_h = 0.f, in_d = 0.f, in_d1 = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b == bin) {
+            in_cw = cw[b];
+            in_w = cw[b + 1] - cw[b];
+            in_ch = ch[b];
+            in_h = ch[b + 1] - ch[b];
+            in_d = dv[b];
+            in_d1 = dv[b + 1];
+        }
+    const float delta = in_h / in_w;
+    const float i1 = in_d + in_d1 - 2.0f * delta;
+    const float i2 = x - in_ch;
+    const float i3 = i2 * i1;
+    const float a = in_h * (delta - in_d) + i3;
+    const float b2 = in_h * in_d - i3;
+    const float c = -delta * i2;
+    const float disc = fmaxf(b2 * b2 - 4.0f * a * c, 0.f);
+    const float root = (2.0f * c) / (-b2 - sqrtf(disc));
+    z1[n] = root * in_w + in_cw;
+}
+void spline_inverse(Plane params, float* z0, float* z1, int nbins, float tail, float inv_sqrt_f, const unsigned char* mask, int L,
+                    hipStream_t s) {
+    SBV2_REQUIRE(nbins == 10, "only the 10-bin spline of the JP-Extra duration flow is compiled");
+    hipLaunchKernelGGL(k_spline_inverse<10>, dim3((L + 63) / 64), dim3(64), 0, s, params, z0, z1, tail, inv_sqrt_f, mask, L);
+}
+
+__global__ void k_swap_rows(float* a, float* b, int L) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < L) {
+        const float t = a[n];
+        a[n] = b[n];
+        b[n] = t;
+    }
+}
+void swap_rows(float* a, float* b, int L, hipStream_t s) { hipLaunchKernelGGL(k_swap_rows, dim3((L + 255) / 256), dim3(256), 0, s, a, b, L); }
+
+__global__ void k_flip_channels(Plane in, Plane out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (n < in.L) out.p[(size_t)c * out.ld + n] = in.p[(size_t)(in.C - 1 - c) * in.ld + n];
+}
+void flip_channels(Plane in, Plane out, hipStream_t s) {
+    hipLaunchKernelGGL(k_flip_channels, dim3((in.L + 255) / 256, in.C), dim3(256), 0, s, in, out);
+}
+
+__global__ void k_affine_reverse(float* z0, float* z1, const float* m, const float* logs, const unsigned char* mask, int L) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const bool k = mask[n];
+    z0[n] = k ? (z0[n] - m[0]) * expf(-logs[0]) : 0.f;
+    z1[n] = k ? (z1[n] - m[1]) * expf(-logs[1]) : 0.f;
+}
+void affine_reverse(float* z0, float* z1, const float* m, const float* logs, const unsigned char* mask, int L, hipStream_t s) {
+    hipLaunchKernelGGL(k_affine_reverse, dim3((L + 255) / 256), dim3(256), 0, s, z0, z1, m, logs, mask, L);
+}
+
+// w_ceil = ceil(exp(logw) * mask * length_scale)   (SynthesizerTrn.infer)
+__global__ void k_durations(const float* sdp, const float* dp, float ratio, float length_scale, const unsigned char* mask, int L,
+                            float* logw, int* dur) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const float lw = sdp[n] * ratio + dp[n] * (1.0f - ratio);
+    logw[n] = mask[n] ? lw : 0.f;
+    dur[n] = mask[n] ? (int)ceilf(expf(lw) * length_scale) : 0;
+}
+void durations(const float* sdp, const float* dp, float ratio, float length_scale, const unsigned char* mask, int L, float* logw,
+               int* dur, hipStream_t s) {
+    hipLaunchKernelGGL(k_durations, dim3((L + 255) / 256), dim3(256), 0, s, sdp, dp, ratio, length_scale, mask, L, logw, dur);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based normal noise, bit-compatible with sbv2-api_amd/synth.py hash_normal(noise_key(seed, utt, stream), n)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double hash_u01(uint64_t key, uint64_t e) {
+    uint64_t z = (e + key) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(float)(z >> 40) * (1.0 / 16777216.0);
+}
+__device__ __forceinline__ float hash_normal(uint64_t key, uint64_t e) {
+    const double u1 = hash_u01(key, e), u2 = hash_u01(key ^ 0x5851F42D4C957F2Dull, e);
+    return (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925286766559 * u2));
+}
+__device__ __forceinline__ uint64_t noise_key(uint64_t seed, int utt, int stream) {
+    return seed + (uint64_t)(2 * utt + stream) * 0x9E3779B97F4A7C15ull;
+}
+
+__global__ void k_noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, int L,
+                             uint64_t seed, int stream_id, float scale) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= L) return;
+    const int sg = seg_of[n];
+    float v = 0.f;
+    if (sg >= 0 && scale != 0.f) {
+        const uint64_t e = (uint64_t)r * seg_len[sg] + (n - seg_start[sg]);
+        v = hash_normal(noise_key(seed, sg, stream_id), e) * scale;
+    }
+    out[(size_t)r * ld + n] = v;
+}
+void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, int L, uint64_t seed,
+                int stream_id, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_noise_fill, dim3((L + 255) / 256, rows), dim3(256), 0, s, out, ld, rows, seg_of, seg_start, seg_len, L, seed,
+                       stream_id, scale);
+}
+
+// generate_path + the two matmuls + prior sampling: z_p[c][y] = m_p[c][tok(y)] + randn * exp(logs_p[c][tok(y)]) * noise_scale
+__global__ void k_expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame, const int* seg_of, const int* seg_start,
+                                const int* seg_len, uint64_t seed, float noise_scale, Plane out) {
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (y >= out.L) return;
+    const int tok = tok_of_frame[y];
+    float v = 0.f;
+    if (tok >= 0) {
+        v = m_p.p[(size_t)c * m_p.ld + tok];
+        if (noise_scale != 0.f) {
+            const int sg = seg_of[y];
+            const uint64_t e = (uint64_t)c * seg_len[sg] + (y - seg_start[sg]);
+            v += hash_normal(noise_key(seed, sg, 1), e) * noise_scale * expf(logs_p.p[(size_t)c * logs_p.ld + tok]);
+        }
+    }
+    out.p[(size_t)c * out.ld + y] = v;
+}
+void expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame, const int* seg_of, const int* seg_start, const int* seg_len,
+                   uint64_t seed, float noise_scale, const float* /*noise_inj*/, int /*ld_inj*/, Plane out, hipStream_t s) {
+    hipLaunchKernelGGL(k_expand_frames, dim3((out.L + 255) / 256, out.C), dim3(256), 0, s, m_p, logs_p, tok_of_frame, seg_of,
+                       seg_start, seg_len, seed, noise_scale, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generator tail: leaky_relu(0.01) -> conv_post (C -> 1, k taps, no bias) -> tanh, written de-gapped per utterance
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_post_tanh(Plane x, const float* w, int k, float slope, const int* seg_start,
+                                                         const int* seg_len, const int64_t* pcm_off, int up, float* pcm) {
+    const int sg = blockIdx.y;
+    const int64_t len = (int64_t)seg_len[sg] * up;
+    const int64_t sidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= len) return;
+    const int64_t col = (int64_t)seg_start[sg] * up + sidx;
+    const int half = k / 2;
+    float a = 0.f;
+    for (int c = 0; c < x.C; ++c) {
+        const float* r = x.p + (size_t)c * x.ld;
+        for (int j = 0; j < k; ++j) {
+            const int64_t q = col + j - half;
+            if (q >= 0 && q < x.L) {
+                float v = r[q];
+                v = v >= 0.f ? v : v * slope;
+                a += w[c * k + j] * v;
+            }
+        }
+    }
+    pcm[pcm_off[sg] + sidx] = tanhf(a);
+}
+void conv_post_tanh(Plane x, const float* w, int k, float slope, const int* seg_start, const int* seg_len, const int64_t* pcm_off,
+                    int nseg, int up, int64_t max_samples, float* pcm, hipStream_t s) {
+    // grid.x covers the longest utterance; blocks past an utterance's end exit
+    hipLaunchKernelGGL(k_conv_post_tanh, dim3((unsigned)((max_samples + 255) / 256), nseg), dim3(256), 0, s, x, w, k, slope, seg_start,
+                       seg_len, pcm_off, up, pcm);
+}
+
+__global__ void k_transpose_out(Plane in, int col0, int T, float* out) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (c < in.C && t < T) ? in.p[(size_t)c * in.ld + col0 + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        if (t < T && c < in.C) out[(size_t)t * in.C + c] = tile[tx][r];
+    }
+}
+void transpose_out(Plane in, int col0, int T, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_out, dim3((T + 31) / 32, (in.C + 31) / 32), dim3(256), 0, s, in, col0, T, out);
+}
+
+__global__ void k_gather_cols(Plane in, const int* map, Plane out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (n >= out.L) return;
+    const int q = map[n];
+    out.p[(size_t)c * out.ld + n] = q >= 0 ? in.p[(size_t)c * in.ld + q] : 0.f;
+}
+void gather_cols(Plane in, const int* map, Plane out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_cols, dim3((out.L + 255) / 256, out.C), dim3(256), 0, s, in, map, out);
+}
+
+void fill_zero(void* p, size_t bytes, hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
+
+}  // namespace sbv2

@@ -1,0 +1,572 @@
+// Style-Bert-VITS2 JP-Extra synthesizer (the graph behind `model::synthesize`, crates/sbv2_core/src/model.rs:53-111,
+// exported from SynthesizerTrn.infer by scripts/convert/convert_model.py:89-113).
+//
+// A batch of utterances is PACKED along the time axis (SegLayout): text-rate planes [C][sum T_text + gaps] and frame-rate
+// planes [C][sum T_frames + gaps]; the zero gaps play the role of every convolution's zero padding, every kernel re-zeroes
+// them through its column mask, and attention is grouped per (utterance, head).  So each utterance's result is the
+// reference's batch-1 result (the reference cannot batch: model.rs:66-79) while every launch covers the whole batch.
+// Stage by stage this follows oracle/sbv2_oracle.py::vits_forward.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "models.h"
+
+namespace sbv2 {
+
+static const int kTextGap = 16;   // >= 9: DDSConv depthwise dilation 3^2 with k=3
+static const int kFrameGap = 4;   // >= 25/8 frames: widest decoder tap offset (k=11, d=5) at the first upsampled rate
+
+namespace {
+struct AttnPlan {
+    int ng = 0, maxT = 0, lds = 0;
+    AttnGroup* d_ag = nullptr;
+    GemmGroup* d_st = nullptr;
+    GemmGroup* d_pv = nullptr;
+    float* S = nullptr;
+    float* PW = nullptr;
+};
+
+AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int window, Arena& ar) {
+    AttnPlan pl;
+    const int dk = H / heads;
+    pl.ng = lay.n * heads;
+    pl.maxT = lay.max_len();
+    pl.lds = round_up(pl.maxT, 4);
+    std::vector<AttnGroup> ag(pl.ng);
+    std::vector<GemmGroup> st(pl.ng), pv(pl.ng);
+    int64_t s_off = 0, w_off = 0;
+    for (int u = 0; u < lay.n; ++u)
+        for (int h = 0; h < heads; ++h) {
+            const int gi = u * heads + h;
+            const int T = lay.len[u];
+            AttnGroup& a = ag[gi];
+            a.qk_off = (int64_t)h * dk * ld + lay.start[u];
+            a.s_off = s_off;
+            a.aux_off = w_off;
+            a.aux2_off = 0;
+            a.T = T;
+            a.lds = pl.lds;
+            a.col0 = lay.start[u];
+            a.head = h;
+            st[gi] = GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, dk, T};                        // S^T = K^T Q
+            pv[gi] = GemmGroup{(int64_t)lay.start[u] * H + h * dk, s_off, a.qk_off, 0, dk, T, T, T};  // ctx = V P^T
+            s_off += (int64_t)T * pl.lds;
+            w_off += (int64_t)(2 * window + 1) * pl.lds;
+        }
+    pl.S = ar.array<float>((size_t)s_off);
+    pl.PW = ar.array<float>((size_t)w_off);
+    pl.d_ag = ar.array<AttnGroup>(pl.ng);
+    pl.d_st = ar.array<GemmGroup>(pl.ng);
+    pl.d_pv = ar.array<GemmGroup>(pl.ng);
+    HIP_CHECK(hipMemcpy(pl.d_ag, ag.data(), sizeof(AttnGroup) * pl.ng, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(pl.d_st, st.data(), sizeof(GemmGroup) * pl.ng, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(pl.d_pv, pv.data(), sizeof(GemmGroup) * pl.ng, hipMemcpyHostToDevice));
+    return pl;
+}
+
+void grouped_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc, const GemmGroup* grp, int ng, int maxM, int maxN,
+                  float alpha, hipStream_t s) {
+    ConvParams p;
+    p.A = A;
+    p.lda = lda;
+    p.B = B;
+    p.ldb = ldb;
+    p.C = C;
+    p.ldc = ldc;
+    p.alpha = alpha;
+    p.groups = grp;
+    p.ngroups = ng;
+    p.maxM = maxM;
+    p.maxN = maxN;
+    launch_conv(p, s);
+}
+}  // namespace
+
+VitsModel::Encoder VitsModel::load_encoder(const std::string& p, int n_layers) {
+    Encoder e;
+    e.spk_w = ws_->tensor(p + "spk_emb_linear.weight");
+    e.spk_b = ws_->tensor(p + "spk_emb_linear.bias");
+    e.layers.resize(n_layers);
+    for (int i = 0; i < n_layers; ++i) {
+        EncLayer& L = e.layers[i];
+        const std::string a = p + "attn_layers." + std::to_string(i) + ".";
+        L.attn.q = ws_->conv(a + "conv_q");
+        L.attn.k = ws_->conv(a + "conv_k");
+        L.attn.v = ws_->conv(a + "conv_v");
+        L.attn.o = ws_->conv(a + "conv_o");
+        L.attn.erk = ws_->tensor(a + "emb_rel_k");
+        L.attn.erv = ws_->tensor(a + "emb_rel_v");
+        L.n1g = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".gamma");
+        L.n1b = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".beta");
+        L.n2g = ws_->tensor(p + "norm_layers_2." + std::to_string(i) + ".gamma");
+        L.n2b = ws_->tensor(p + "norm_layers_2." + std::to_string(i) + ".beta");
+        L.ffn1 = ws_->conv(p + "ffn_layers." + std::to_string(i) + ".conv_1");
+        L.ffn2 = ws_->conv(p + "ffn_layers." + std::to_string(i) + ".conv_2");
+    }
+    return e;
+}
+
+VitsModel::DDS VitsModel::load_dds(const std::string& p, int) {
+    DDS d;
+    for (int i = 0; i < cfg_.sdp_dds_layers; ++i) {
+        const std::string s = std::to_string(i);
+        const HostTensor& w = ws_->blob().get(p + "convs_sep." + s + ".weight");
+        SBV2_REQUIRE(w.dims.size() == 3 && w.dims[2] == 3, "DDSConv depthwise kernel must be 3");
+        d.sep_w.push_back(ws_->tensor(p + "convs_sep." + s + ".weight"));
+        d.sep_b.push_back(ws_->tensor(p + "convs_sep." + s + ".bias"));
+        d.pw.push_back(ws_->conv(p + "convs_1x1." + s));
+        d.n1g.push_back(ws_->tensor(p + "norms_1." + s + ".gamma"));
+        d.n1b.push_back(ws_->tensor(p + "norms_1." + s + ".beta"));
+        d.n2g.push_back(ws_->tensor(p + "norms_2." + s + ".gamma"));
+        d.n2b.push_back(ws_->tensor(p + "norms_2." + s + ".beta"));
+    }
+    return d;
+}
+
+VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
+    SBV2_REQUIRE(blob.kind == 2, "weight container is not a VITS (kind 2) model");
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreate(&stream_));
+    const std::string& js = blob.config_json;
+    auto I = [&](const char* k) { return (int)json_number(js, k); };
+    cfg_.n_vocab = I("n_vocab"); cfg_.n_tones = I("n_tones"); cfg_.n_langs = I("n_langs"); cfg_.n_speakers = I("n_speakers");
+    cfg_.hidden = I("hidden"); cfg_.inter = I("inter"); cfg_.filter = I("filter"); cfg_.heads = I("heads");
+    cfg_.enc_layers = I("enc_layers"); cfg_.enc_kernel = I("enc_kernel"); cfg_.window = I("window"); cfg_.gin = I("gin");
+    cfg_.style_dim = I("style_dim"); cfg_.bert_dim = I("bert_dim"); cfg_.cond_layer_idx = I("cond_layer_idx");
+    cfg_.flow_n = I("flow_n"); cfg_.flow_layers = I("flow_layers"); cfg_.flow_kernel = I("flow_kernel");
+    cfg_.dp_filter = I("dp_filter"); cfg_.dp_kernel = I("dp_kernel"); cfg_.sdp_kernel = I("sdp_kernel");
+    cfg_.sdp_flows = I("sdp_flows"); cfg_.sdp_bins = I("sdp_bins"); cfg_.sdp_dds_layers = I("sdp_dds_layers");
+    cfg_.sdp_tail = (float)json_number(js, "sdp_tail");
+    cfg_.up_rates = json_int_array(js, "up_rates");
+    cfg_.up_kernels = json_int_array(js, "up_kernels");
+    cfg_.res_kernels = json_int_array(js, "res_kernels");
+    cfg_.res_dilations = json_int_array2(js, "res_dilations");
+    cfg_.up_initial = I("up_initial");
+    SBV2_REQUIRE(cfg_.sdp_kernel == 3, "DDSConv kernel must be 3");
+    SBV2_REQUIRE(cfg_.hidden % cfg_.heads == 0 && (cfg_.hidden / cfg_.heads) % 4 == 0, "head size must be a multiple of 4");
+    SBV2_REQUIRE(cfg_.inter % 8 == 0, "flow channels must be a multiple of 8");
+    SBV2_REQUIRE(cfg_.res_dilations.size() == cfg_.res_kernels.size(), "resblock config mismatch");
+
+    ws_.reset(new WeightStore(blob));
+    WeightStore& w = *ws_;
+    emb_g_ = w.tensor("emb_g.weight");
+    emb_ = w.tensor("enc_p.emb.weight");
+    tone_emb_ = w.tensor("enc_p.tone_emb.weight");
+    lang_emb_ = w.tensor("enc_p.language_emb.weight");
+    bert_proj_ = w.conv("enc_p.bert_proj");
+    style_w_ = w.tensor("enc_p.style_proj.weight");
+    style_b_ = w.tensor("enc_p.style_proj.bias");
+    enc_p_ = load_encoder("enc_p.encoder.", cfg_.enc_layers);
+    enc_proj_ = w.conv("enc_p.proj");
+    dp_c1_ = w.conv("dp.conv_1");
+    dp_c2_ = w.conv("dp.conv_2");
+    dp_proj_ = w.conv("dp.proj");
+    dp_n1g_ = w.tensor("dp.norm_1.gamma"); dp_n1b_ = w.tensor("dp.norm_1.beta");
+    dp_n2g_ = w.tensor("dp.norm_2.gamma"); dp_n2b_ = w.tensor("dp.norm_2.beta");
+    dp_cond_w_ = w.tensor("dp.cond.weight"); dp_cond_b_ = w.tensor("dp.cond.bias");
+    sdp_pre_ = w.conv("sdp.pre");
+    sdp_proj_ = w.conv("sdp.proj");
+    sdp_cond_w_ = w.tensor("sdp.cond.weight"); sdp_cond_b_ = w.tensor("sdp.cond.bias");
+    sdp_ea_m_ = w.tensor("sdp.flows.0.m"); sdp_ea_logs_ = w.tensor("sdp.flows.0.logs");
+    sdp_dds_ = load_dds("sdp.convs.", cfg_.hidden);
+    for (int i = 2; i <= cfg_.sdp_flows; ++i) {  // ConvFlow 1 is the "useless vflow" dropped in reverse mode
+        const std::string p = "sdp.flows." + std::to_string(2 * i - 1) + ".";
+        ConvFlow cf;
+        cf.pre_w = w.tensor(p + "pre.weight");
+        cf.pre_b = w.tensor(p + "pre.bias");
+        cf.dds = load_dds(p + "convs.", cfg_.hidden);
+        cf.proj = w.conv(p + "proj");
+        SBV2_REQUIRE(cf.proj.cout == 3 * cfg_.sdp_bins - 1, "ConvFlow projection size");
+        sdp_cf_.push_back(cf);
+    }
+    for (int i = 0; i < cfg_.flow_n; ++i) {
+        const std::string p = "flow.flows." + std::to_string(2 * i) + ".";
+        Coupling c;
+        c.pre = w.conv(p + "pre");
+        c.post = w.conv(p + "post");
+        c.enc = load_encoder(p + "enc.", cfg_.flow_layers);
+        flows_.push_back(c);
+    }
+    dec_pre_ = w.conv("dec.conv_pre");
+    dec_cond_w_ = w.tensor("dec.cond.weight");
+    dec_cond_b_ = w.tensor("dec.cond.bias");
+    dec_post_w_ = w.tensor("dec.conv_post.weight");
+    dec_post_k_ = (int)blob.get("dec.conv_post.weight").dims[2];
+    int C = cfg_.up_initial;
+    const int nk = (int)cfg_.res_kernels.size();
+    for (size_t i = 0; i < cfg_.up_rates.size(); ++i) {
+        Stage st;
+        st.rate = cfg_.up_rates[i];
+        st.up = w.upsample("dec.ups." + std::to_string(i), st.rate, (cfg_.up_kernels[i] - st.rate) / 2);
+        C /= 2;
+        st.ch = C;
+        for (int j = 0; j < nk; ++j) {
+            ResBranch rb;
+            rb.k = cfg_.res_kernels[j];
+            rb.dil = cfg_.res_dilations[j];
+            const std::string p = "dec.resblocks." + std::to_string(i * nk + j) + ".";
+            for (size_t n = 0; n < rb.dil.size(); ++n) {
+                rb.c1.push_back(w.conv(p + "convs1." + std::to_string(n)));
+                rb.c2.push_back(w.conv(p + "convs2." + std::to_string(n)));
+            }
+            st.branches.push_back(rb);
+        }
+        stages_.push_back(st);
+    }
+}
+
+VitsModel::~VitsModel() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void VitsModel::trace(const std::string& name, Plane p, const SegLayout& lay, int div) {
+    if (!trace_) return;
+    Plane c = keep_.plane(p.C, p.L);
+    HIP_CHECK(hipMemcpy2DAsync(c.p, sizeof(float) * c.ld, p.p, sizeof(float) * p.ld, sizeof(float) * p.L, p.C, hipMemcpyDeviceToDevice, stream_));
+    traces_[name] = TraceEntry{c, &lay, div};
+}
+
+bool VitsModel::get_trace(const std::string& name, int utt, std::vector<float>& out, int& rows, int& cols) {
+    auto it = traces_.find(name);
+    if (it == traces_.end()) return false;
+    const TraceEntry& t = it->second;
+    if (utt < 0 || utt >= t.lay->n) return false;
+    HIP_CHECK(hipSetDevice(device_));
+    rows = t.p.C;
+    cols = t.lay->len[utt] * t.div;
+    out.resize((size_t)rows * cols);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipMemcpy2D(out.data(), sizeof(float) * cols, t.p.p + (size_t)t.lay->start[utt] * t.div, sizeof(float) * t.p.ld,
+                          sizeof(float) * cols, rows, hipMemcpyDeviceToHost));
+    return true;
+}
+
+// attentions.Encoder (post-LN, window-relative attention, FFN with 'same' convolutions, speaker vector before layer 2)
+void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, const float* spk_vec, Arena& ar) {
+    const int H = x.C, heads = cfg_.heads, dk = H / heads, N = lay.L;
+    const Arena::Mark mk = ar.mark();
+    const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar);
+    Plane Q = ar.plane(H, N), K = ar.plane(H, N), ctx = ar.plane(H, N), Y = ar.plane(H, N);
+    SBV2_REQUIRE(Q.ld == x.ld, "plane pitch mismatch");
+    Plane F = ar.plane(e.layers[0].ffn1.cout, N);
+    float* VT = ar.array<float>((size_t)N * H);
+    fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);
+    const float qscale = 1.0f / std::sqrt((float)dk);
+    for (size_t i = 0; i < e.layers.size(); ++i) {
+        const EncLayer& L = e.layers[i];
+        if ((int)i == cfg_.cond_layer_idx && spk_vec) add_segvec(x, spk_vec, H, lay.d_seg_of, 1, lay.d_mask, stream_);
+        conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
+        conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
+        linear_tokmajor(L.attn.v, x, VT, H, stream_);
+        grouped_gemm(K.p, K.ld, Q.p, Q.ld, pl.S, pl.lds, pl.d_st, pl.ng, pl.maxT, pl.maxT, qscale, stream_);
+        vits_softmax(pl.d_ag, pl.ng, pl.maxT, pl.S, Q.p, Q.ld, dk, L.attn.erk, cfg_.window, qscale, pl.PW, stream_);
+        grouped_gemm(VT, H, pl.S, pl.lds, ctx.p, ctx.ld, pl.d_pv, pl.ng, dk, pl.maxT, 1.0f, stream_);
+        vits_relv_add(pl.d_ag, pl.ng, pl.maxT, ctx.p, ctx.ld, dk, L.attn.erv, cfg_.window, pl.PW, stream_);
+        conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
+        layernorm_ch(Y, x, L.n1g, L.n1b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
+        const int k = L.ffn1.k;
+        conv_plain(L.ffn1, x, F, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_RELU);
+        conv_plain(L.ffn2, F, Y, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_NONE, 1.0f, &x);
+        layernorm_ch(Y, x, L.n2g, L.n2b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
+    }
+    ar.rewind(mk);
+}
+
+// modules.DDSConv: x += gelu(LN(1x1(gelu(LN(depthwise(x * mask))))))  x 3, dilation 3^i
+void VitsModel::run_dds(const DDS& d, Plane x, const SegLayout& lay, Arena& ar) {
+    const Arena::Mark mk = ar.mark();
+    Plane a = ar.plane(x.C, x.L), b = ar.plane(x.C, x.L);
+    int dil = 1;
+    for (size_t i = 0; i < d.pw.size(); ++i) {
+        dds_dw_ln_gelu(x, a, d.sep_w[i], d.sep_b[i], dil, d.n1g[i], d.n1b[i], lay.d_mask, stream_);
+        conv_plain(d.pw[i], a, b, 1, 0, nullptr, 1, stream_);
+        layernorm_ch(b, x, d.n2g[i], d.n2b[i], 1e-5f, ACT_GELU, x.p, x.ld, lay.d_mask, stream_);
+        dil *= cfg_.sdp_kernel;
+    }
+    ar.rewind(mk);
+}
+
+// models_jp_extra.Generator
+void VitsModel::run_decoder(Plane z, const SegLayout& fl) {
+    const int n = fl.n;
+    const int Lf = fl.L;
+    Arena& ar = arena_;
+    Plane cur = ar.plane(cfg_.up_initial, Lf);
+    conv_plain(dec_pre_, z, cur, 1, dec_pre_.k / 2, fl.d_mask, 1, stream_);
+    add_segvec(cur, dec_cond_vec_, cfg_.up_initial, fl.d_seg_of, 1, fl.d_mask, stream_);
+    trace("dec_pre", cur, fl, 1);
+    int U = 1;
+    const int nk = (int)cfg_.res_kernels.size();
+    for (size_t si = 0; si < stages_.size(); ++si) {
+        const Stage& st = stages_[si];
+        U *= st.rate;
+        const int Lo = Lf * U;
+        Plane XS = ar.plane(st.ch, Lo);
+        const Arena::Mark mk = ar.mark();
+        Plane XU = ar.plane(st.ch, Lo), T1 = ar.plane(st.ch, Lo), YA = ar.plane(st.ch, Lo), YB = ar.plane(st.ch, Lo);
+        for (const auto& g : st.up.groups) {
+            ConvParams p;
+            p.A = g.w;
+            p.lda = g.lda;
+            p.a_tap_stride = (int64_t)st.up.cin * g.lda;
+            p.B = cur.p;
+            p.ldb = cur.ld;
+            p.nb = cur.L;
+            p.C = XU.p;
+            p.ldc = XU.ld;
+            p.M = g.nph * st.up.cout;
+            p.N = cur.L;
+            p.K = st.up.cin;
+            p.ntaps = g.ntaps;
+            for (int t = 0; t < g.ntaps; ++t) p.shift[t] = g.shift[t];
+            p.bias = st.up.bias;
+            p.bias_mode = BIAS_ROW;
+            p.pre_slope = 0.1f;
+            p.mask = fl.d_mask;
+            p.mask_div = U;
+            p.out_stride = st.rate;
+            p.phase_rows = st.up.cout;
+            for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
+            launch_conv(p, stream_);
+        }
+        for (int j = 0; j < nk; ++j) {
+            const ResBranch& rb = st.branches[j];
+            Plane y = XU;
+            const int nd = (int)rb.dil.size();
+            for (int q = 0; q < nd; ++q) {
+                const int d = rb.dil[q];
+                conv_plain(rb.c1[q], y, T1, d, d * (rb.k - 1) / 2, fl.d_mask, U, stream_, ACT_NONE, 0.1f);
+                if (q + 1 < nd) {
+                    Plane yn = (y.p == YA.p) ? YB : YA;
+                    conv_plain(rb.c2[q], T1, yn, 1, (rb.k - 1) / 2, fl.d_mask, U, stream_, ACT_NONE, 0.1f, &y);
+                    y = yn;
+                } else {
+                    conv_plain(rb.c2[q], T1, XS, 1, (rb.k - 1) / 2, fl.d_mask, U, stream_, ACT_NONE, 0.1f, &y, 1.0f, 1.0f / nk, j > 0);
+                }
+            }
+        }
+        ar.rewind(mk);
+        cur = XS;
+        trace("dec_stage" + std::to_string(si), cur, fl, U);
+    }
+    // compact PCM, one contiguous block per utterance
+    pcm_lens_.assign(n, 0);
+    pcm_offs_.assign(n, 0);
+    int64_t tot = 0, maxlen = 0;
+    for (int u = 0; u < n; ++u) {
+        pcm_offs_[u] = tot;
+        pcm_lens_[u] = (int64_t)fl.len[u] * U;
+        tot += pcm_lens_[u];
+        maxlen = std::max(maxlen, pcm_lens_[u]);
+    }
+    pcm_total_ = tot;
+    pcm_ = ar.array<float>((size_t)tot);
+    int64_t* d_off = ar.array<int64_t>(n);
+    HIP_CHECK(hipMemcpyAsync(d_off, pcm_offs_.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, stream_));
+    conv_post_tanh(cur, dec_post_w_, dec_post_k_, 0.01f, fl.d_start, fl.d_len, d_off, n, U, maxlen, pcm_, stream_);
+}
+
+void VitsModel::forward(const VitsBatch& b) {
+    HIP_CHECK(hipSetDevice(device_));
+    SBV2_REQUIRE(b.n >= 1, "empty batch");
+    arena_.reset();
+    keep_.reset();
+    traces_.clear();
+    Arena& ar = arena_;
+    const int n = b.n, H = cfg_.hidden, I = cfg_.inter;
+    std::vector<int> T(n);
+    int64_t total_t = 0;
+    for (int u = 0; u < n; ++u) {
+        SBV2_REQUIRE(b.t_lens[u] >= 1 && b.t_lens[u] < (1 << 20), "bad text length");
+        T[u] = (int)b.t_lens[u];
+        total_t += T[u];
+    }
+    tl_ = make_layout(T, kTextGap, ar);
+    const SegLayout& tl = tl_;
+    const int Lt = tl.L;
+
+    // ---- inputs -------------------------------------------------------------------------------------
+    std::vector<int> ph(Lt, 0), tn(Lt, 0), lg(Lt, 0), sid(n);
+    {
+        int64_t e = 0;
+        for (int u = 0; u < n; ++u) {
+            SBV2_REQUIRE(b.sids[u] >= 0 && b.sids[u] < cfg_.n_speakers, "speaker id out of range");
+            sid[u] = (int)b.sids[u];
+            for (int t = 0; t < T[u]; ++t, ++e) {
+                SBV2_REQUIRE(b.phones[e] >= 0 && b.phones[e] < cfg_.n_vocab && b.tones[e] >= 0 && b.tones[e] < cfg_.n_tones &&
+                                 b.langs[e] >= 0 && b.langs[e] < cfg_.n_langs,
+                             "phone / tone / language id out of range");
+                ph[tl.start[u] + t] = (int)b.phones[e];
+                tn[tl.start[u] + t] = (int)b.tones[e];
+                lg[tl.start[u] + t] = (int)b.langs[e];
+            }
+        }
+    }
+    int* d_ph = ar.array<int>(Lt);
+    int* d_tn = ar.array<int>(Lt);
+    int* d_lg = ar.array<int>(Lt);
+    int* d_sid = ar.array<int>(n);
+    float* d_style = ar.array<float>((size_t)n * cfg_.style_dim);
+    HIP_CHECK(hipMemcpy(d_ph, ph.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_tn, tn.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_lg, lg.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_sid, sid.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_style, b.styles, sizeof(float) * (size_t)n * cfg_.style_dim, hipMemcpyHostToDevice));
+
+    Plane bert = ar.plane(cfg_.bert_dim, Lt);
+    if (b.bert_host) {
+        fill_zero(bert.p, sizeof(float) * (size_t)bert.C * bert.ld, stream_);
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        int64_t off = 0;
+        for (int u = 0; u < n; ++u) {
+            HIP_CHECK(hipMemcpy2D(bert.p + tl.start[u], sizeof(float) * bert.ld, b.bert_host + off, sizeof(float) * T[u],
+                                  sizeof(float) * T[u], cfg_.bert_dim, hipMemcpyHostToDevice));
+            off += (int64_t)cfg_.bert_dim * T[u];
+        }
+    } else {
+        SBV2_REQUIRE(b.bert_dev && b.bert_map, "no BERT features given");
+        std::vector<int> map(Lt, -1);
+        int64_t e = 0;
+        for (int u = 0; u < n; ++u)
+            for (int t = 0; t < T[u]; ++t, ++e) map[tl.start[u] + t] = b.bert_map[e];
+        int* d_map = ar.array<int>(Lt);
+        HIP_CHECK(hipMemcpy(d_map, map.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
+        gather_cols(*b.bert_dev, d_map, bert, stream_);
+    }
+
+    // ---- per-utterance vectors: g = emb_g(sid) and every Linear / 1x1 conv applied to it ---------------
+    float* G = ar.array<float>((size_t)n * cfg_.gin);
+    gather_rows(emb_g_, cfg_.gin, d_sid, G, n, stream_);
+    auto gvec = [&](const float* w, const float* bias, int M) {
+        float* out = ar.array<float>((size_t)n * M);
+        linear_vec(w, bias, M, cfg_.gin, G, cfg_.gin, out, M, n, stream_);
+        return out;
+    };
+    float* v_style = ar.array<float>((size_t)n * H);
+    linear_vec(style_w_, style_b_, H, cfg_.style_dim, d_style, cfg_.style_dim, v_style, H, n, stream_);
+    float* v_encp = gvec(enc_p_.spk_w, enc_p_.spk_b, H);
+    float* v_dp = gvec(dp_cond_w_, dp_cond_b_, H);
+    float* v_sdp = gvec(sdp_cond_w_, sdp_cond_b_, H);
+    dec_cond_vec_ = gvec(dec_cond_w_, dec_cond_b_, cfg_.up_initial);
+    std::vector<float*> v_flow;
+    for (auto& c : flows_) v_flow.push_back(gvec(c.enc.spk_w, c.enc.spk_b, H));
+
+    // ---- TextEncoder ----------------------------------------------------------------------------------
+    Plane BP = ar.plane(H, Lt);
+    conv_plain(bert_proj_, bert, BP, 1, 0, nullptr, 1, stream_);
+    Plane X = ar.plane(H, Lt);
+    text_embed(d_ph, d_tn, d_lg, tl.d_seg_of, emb_, tone_emb_, lang_emb_, BP.p, BP.ld, v_style, H, std::sqrt((float)H), X, stream_);
+    trace("x_emb", X, tl);
+    run_encoder(enc_p_, X, tl, v_encp, ar);
+    trace("x", X, tl);
+    Plane ST = ar.plane(2 * I, Lt);
+    conv_plain(enc_proj_, X, ST, 1, 0, tl.d_mask, 1, stream_);
+    Plane m_p = ST.rows(0, I), logs_p = ST.rows(I, I);
+    trace("stats", ST, tl);
+
+    // ---- DurationPredictor -----------------------------------------------------------------------------
+    Plane XD = ar.plane(H, Lt);
+    HIP_CHECK(hipMemcpyAsync(XD.p, X.p, sizeof(float) * (size_t)H * X.ld, hipMemcpyDeviceToDevice, stream_));
+    add_segvec(XD, v_dp, H, tl.d_seg_of, 1, tl.d_mask, stream_);
+    Plane D1 = ar.plane(cfg_.dp_filter, Lt), D2 = ar.plane(cfg_.dp_filter, Lt), DPO = ar.plane(1, Lt);
+    conv_plain(dp_c1_, XD, D1, 1, cfg_.dp_kernel / 2, tl.d_mask, 1, stream_, ACT_RELU);
+    layernorm_ch(D1, D1, dp_n1g_, dp_n1b_, 1e-5f, ACT_NONE, nullptr, 0, tl.d_mask, stream_);
+    conv_plain(dp_c2_, D1, D2, 1, cfg_.dp_kernel / 2, tl.d_mask, 1, stream_, ACT_RELU);
+    layernorm_ch(D2, D2, dp_n2g_, dp_n2b_, 1e-5f, ACT_NONE, nullptr, 0, tl.d_mask, stream_);
+    conv_plain(dp_proj_, D2, DPO, 1, 0, tl.d_mask, 1, stream_);
+
+    // ---- StochasticDurationPredictor, reverse (executed even when sdp_ratio == 0, like the exported graph) ----
+    Plane XSd = ar.plane(H, Lt), COND = ar.plane(H, Lt), HH = ar.plane(H, Lt);
+    Plane PR = ar.plane(3 * cfg_.sdp_bins - 1, Lt), Z = ar.plane(2, Lt);
+    conv_plain(sdp_pre_, X, XSd, 1, 0, nullptr, 1, stream_);
+    add_segvec(XSd, v_sdp, H, tl.d_seg_of, 1, tl.d_mask, stream_);
+    run_dds(sdp_dds_, XSd, tl, ar);
+    conv_plain(sdp_proj_, XSd, COND, 1, 0, tl.d_mask, 1, stream_);
+    float* z0 = Z.p;
+    float* z1 = Z.p + Z.ld;
+    noise_fill(Z.p, Z.ld, 2, tl.d_seg_of, tl.d_start, tl.d_len, Lt, b.seed, 0, b.noise_scale_w, stream_);
+    const float inv_sqrt_f = 1.0f / std::sqrt((float)H);
+    for (int i = (int)sdp_cf_.size() - 1; i >= 0; --i) {
+        const ConvFlow& cf = sdp_cf_[i];
+        swap_rows(z0, z1, Lt, stream_);  // Flip
+        convflow_pre(z0, cf.pre_w, cf.pre_b, COND, HH, tl.d_mask, stream_);
+        run_dds(cf.dds, HH, tl, ar);
+        conv_plain(cf.proj, HH, PR, 1, 0, tl.d_mask, 1, stream_);
+        spline_inverse(PR, z0, z1, cfg_.sdp_bins, cfg_.sdp_tail, inv_sqrt_f, tl.d_mask, Lt, stream_);
+    }
+    swap_rows(z0, z1, Lt, stream_);
+    affine_reverse(z0, z1, sdp_ea_m_, sdp_ea_logs_, tl.d_mask, Lt, stream_);
+
+    // ---- durations (the one device -> host sync of the batch: T_frames is data dependent) ----------------
+    float* d_logw = ar.array<float>(Lt);
+    int* d_dur = ar.array<int>(Lt);
+    sbv2::durations(z0, DPO.p, b.sdp_ratio, b.length_scale, tl.d_mask, Lt, d_logw, d_dur, stream_);
+    std::vector<int> dur_p(Lt);
+    std::vector<float> logw_p(Lt);
+    HIP_CHECK(hipMemcpyAsync(dur_p.data(), d_dur, sizeof(int) * Lt, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(logw_p.data(), d_logw, sizeof(float) * Lt, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    dur_host_.assign((size_t)total_t, 0);
+    logw_host_.assign((size_t)total_t, 0.f);
+    std::vector<int> Tf(n);
+    std::vector<std::vector<int>> used(n);
+    {
+        int64_t e = 0;
+        for (int u = 0; u < n; ++u) {
+            int64_t sum = 0;
+            used[u].resize(T[u]);
+            for (int t = 0; t < T[u]; ++t, ++e) {
+                dur_host_[e] = dur_p[tl.start[u] + t];
+                logw_host_[e] = logw_p[tl.start[u] + t];
+                const int64_t dv = b.forced_durations ? b.forced_durations[e] : dur_host_[e];
+                SBV2_REQUIRE(dv >= 0 && dv < (1 << 20), "duration out of range");
+                used[u][t] = (int)dv;
+                sum += dv;
+            }
+            SBV2_REQUIRE(sum < (1 << 24), "utterance too long");
+            Tf[u] = (int)std::max<int64_t>(sum, 1);  // torch.clamp_min(sum, 1)
+        }
+    }
+    fl_ = make_layout(Tf, kFrameGap, ar);
+    const SegLayout& fl = fl_;
+    const int Lf = fl.L;
+    std::vector<int> tok(Lf, -1);
+    for (int u = 0; u < n; ++u) {
+        int y = fl.start[u];
+        for (int t = 0; t < T[u]; ++t)
+            for (int q = 0; q < used[u][t]; ++q) tok[y++] = tl.start[u] + t;
+    }
+    int* d_tok = ar.array<int>(Lf);
+    HIP_CHECK(hipMemcpy(d_tok, tok.data(), sizeof(int) * Lf, hipMemcpyHostToDevice));
+
+    // ---- alignment expansion + prior sample ---------------------------------------------------------------
+    Plane ZA = ar.plane(I, Lf), ZB = ar.plane(I, Lf);
+    expand_frames(m_p, logs_p, d_tok, fl.d_seg_of, fl.d_start, fl.d_len, b.seed, b.noise_scale, nullptr, 0, ZA, stream_);
+    trace("z_p", ZA, fl);
+
+    // ---- TransformerCouplingBlock, reverse ----------------------------------------------------------------
+    const int half = I / 2;
+    Plane Hf = ar.plane(H, Lf);
+    for (int i = cfg_.flow_n - 1; i >= 0; --i) {
+        const Coupling& c = flows_[i];
+        flip_channels(ZA, ZB, stream_);
+        std::swap(ZA, ZB);
+        conv_plain(c.pre, ZA.rows(0, half), Hf, 1, 0, fl.d_mask, 1, stream_);
+        run_encoder(c.enc, Hf, fl, v_flow[i], ar);
+        Plane x1 = ZA.rows(half, half);
+        conv_plain(c.post, Hf, x1, 1, 0, fl.d_mask, 1, stream_, ACT_NONE, 1.0f, &x1, -1.0f);  // x1 = (x1 - m) * mask
+    }
+    trace("z", ZA, fl);
+
+    run_decoder(ZA, fl);
+}
+
+void VitsModel::copy_pcm(float* host) {
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipMemcpyAsync(host, pcm_, sizeof(float) * (size_t)pcm_total_, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+}  // namespace sbv2

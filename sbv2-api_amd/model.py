@@ -1,0 +1,187 @@
+"""Host mirror of crates/sbv2_core/src/model.rs (`load_model`, `synthesize`) and bert.rs (`predict`) over the C ABI.
+
+Same names, argument order and meaning as the reference; numpy arrays stand in for ndarray.  The batched /
+pipeline entry points are the new capabilities (the reference is strictly batch 1).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Sbv2Batch, Sbv2Error, check, f32p, i64p
+
+__all__ = ["Session", "load_model", "predict", "synthesize", "predict_batch", "synthesize_batch", "Pipeline", "Sbv2Error"]
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(i64p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(f32p)
+
+
+class Session:
+    """Opaque model handle; stands in for `ort::session::Session` (model.rs:6, tts.rs:32-46)."""
+
+    def __init__(self, handle, bert):
+        self.handle, self.bert = handle, bert
+
+    def close(self):
+        if self.handle:
+            (_lib.lib().sbv2_bert_destroy if self.bert else _lib.lib().sbv2_vits_destroy)(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_model(model_file: bytes, bert: bool, device: int = 0) -> Session:
+    """model.rs:6-50 `load_model(model_file, bert)`; the EP list / thread options have no meaning here."""
+    l = _lib.lib()
+    h = C.c_void_p()
+    buf = (C.c_char * len(model_file)).from_buffer_copy(model_file) if not isinstance(model_file, (bytearray, memoryview)) else \
+        (C.c_char * len(model_file)).from_buffer(model_file)
+    fn = l.sbv2_bert_create if bert else l.sbv2_vits_create
+    check(fn(C.cast(buf, C.c_void_p), len(model_file), device, C.byref(h)))
+    return Session(h, bert)
+
+
+def predict(session: Session, token_ids, attention_masks) -> np.ndarray:
+    """bert.rs:6-24 `predict(session, token_ids, attention_masks) -> Array2<f32> [S, 1024]`."""
+    ids, pi = _i64(token_ids)
+    msk, pm = _i64(attention_masks)
+    if ids.shape != msk.shape or ids.ndim != 1:
+        raise Sbv2Error("token_ids and attention_masks must be 1-D and of equal length")
+    l = _lib.lib()
+    out = np.empty((ids.shape[0], l.sbv2_bert_hidden(session.handle)), np.float32)
+    check(l.sbv2_bert_predict(session.handle, pi, pm, ids.shape[0], out.ctypes.data_as(f32p)))
+    return out
+
+
+def predict_batch(session: Session, token_ids_list, attention_masks_list=None):
+    l = _lib.lib()
+    lens = np.array([len(t) for t in token_ids_list], np.int64)
+    ids, pi = _i64(np.concatenate([np.asarray(t, np.int64) for t in token_ids_list]))
+    pm = None
+    if attention_masks_list is not None:
+        msk, pm = _i64(np.concatenate([np.asarray(t, np.int64) for t in attention_masks_list]))
+    out = np.empty((int(lens.sum()), l.sbv2_bert_hidden(session.handle)), np.float32)
+    check(l.sbv2_bert_predict_batch(session.handle, len(lens), pi, pm, lens.ctypes.data_as(i64p), out.ctypes.data_as(f32p)))
+    return np.split(out, np.cumsum(lens)[:-1], axis=0)
+
+
+def synthesize(session: Session, bert_ori, x_tst, spk_ids, tones, lang_ids, style_vector, sdp_ratio, length_scale, noise_scale,
+               noise_scale_w, noise_seed: int = 0) -> np.ndarray:
+    """model.rs:53-111 `synthesize(...) -> Array3<f32> [1, 1, L]` (same argument order)."""
+    l = _lib.lib()
+    b, pb = _f32(bert_ori)
+    x, px = _i64(x_tst)
+    t, pt = _i64(tones)
+    g, pg = _i64(lang_ids)
+    s, ps = _f32(style_vector)
+    T = x.shape[0]
+    if b.shape != (l.sbv2_vits_bert_dim(session.handle), T) or t.shape != (T,) or g.shape != (T,):
+        raise Sbv2Error("input shapes do not agree (bert [1024, T], x_tst / tones / lang_ids [T])")
+    sid = int(np.asarray(spk_ids).reshape(-1)[0])
+    pcm = f32p()
+    n = C.c_int64()
+    check(l.sbv2_vits_synthesize(session.handle, pb, px, pt, pg, T, sid, ps, sdp_ratio, length_scale, noise_scale, noise_scale_w,
+                                 noise_seed, C.byref(pcm), C.byref(n)))
+    try:
+        out = np.ctypeslib.as_array(pcm, shape=(n.value,)).copy()
+    finally:
+        l.sbv2_pcm_free(pcm)
+    return out.reshape(1, 1, -1)
+
+
+class _Batch:
+    """Keeps the numpy buffers of one sbv2_batch alive."""
+
+    def __init__(self, utts, sdp_ratio, length_scale, noise_scale, noise_scale_w, noise_seed, forced, with_bert):
+        self.keep = []
+        cat = lambda key, dt: np.ascontiguousarray(np.concatenate([np.asarray(u[key]).reshape(-1) for u in utts]), dtype=dt)
+        self.t_lens = np.array([len(u["phones"]) for u in utts], np.int64)
+        self.x, self.tones, self.langs = cat("phones", np.int64), cat("tones", np.int64), cat("langs", np.int64)
+        self.sids = np.array([int(u.get("sid", 0)) for u in utts], np.int64)
+        self.styles = np.ascontiguousarray(np.stack([np.asarray(u["style"], np.float32) for u in utts]))
+        self.bert = cat("bert", np.float32) if with_bert else None
+        self.forced = cat("forced_durations", np.int64) if forced else None
+        p = lambda a, t: a.ctypes.data_as(t) if a is not None else None
+        self.c = Sbv2Batch(len(utts), p(self.t_lens, i64p), p(self.x, i64p), p(self.tones, i64p), p(self.langs, i64p), p(self.sids, i64p),
+                           p(self.styles, f32p), p(self.bert, f32p), sdp_ratio, length_scale, noise_scale, noise_scale_w, noise_seed,
+                           p(self.forced, i64p))
+
+
+def synthesize_batch(session: Session, utts, sdp_ratio=0.0, length_scale=1.0, noise_scale=0.0, noise_scale_w=0.0, noise_seed=0,
+                     forced=False, fetch=True):
+    """New capability: a list of utterance dicts (bert [1024,T], phones, tones, langs, style, sid[, forced_durations])
+    in one call.  Returns a list of PCM arrays (or the lengths when fetch=False: PCM stays in HBM)."""
+    l = _lib.lib()
+    b = _Batch(utts, sdp_ratio, length_scale, noise_scale, noise_scale_w, noise_seed, forced, True)
+    lens = np.zeros(len(utts), np.int64)
+    check(l.sbv2_vits_synthesize_batch(session.handle, C.byref(b.c), lens.ctypes.data_as(i64p)))
+    if not fetch:
+        return lens
+    pcm = np.empty(int(lens.sum()), np.float32)
+    check(l.sbv2_vits_fetch_pcm(session.handle, pcm.ctypes.data_as(f32p)))
+    return np.split(pcm, np.cumsum(lens)[:-1])
+
+
+def fetch_durations(session: Session, total_t: int):
+    d = np.zeros(total_t, np.int64)
+    lw = np.zeros(total_t, np.float32)
+    check(_lib.lib().sbv2_vits_fetch_durations(session.handle, d.ctypes.data_as(i64p), lw.ctypes.data_as(f32p)))
+    return d, lw
+
+
+def set_trace(session: Session, on: bool):
+    check(_lib.lib().sbv2_vits_set_trace(session.handle, int(on)))
+
+
+def get_trace(session: Session, name: str, utt: int = 0) -> np.ndarray:
+    l = _lib.lib()
+    r, c = C.c_int64(), C.c_int64()
+    check(l.sbv2_vits_get_trace(session.handle, name.encode(), utt, None, 0, C.byref(r), C.byref(c)))
+    out = np.empty((r.value, c.value), np.float32)
+    check(l.sbv2_vits_get_trace(session.handle, name.encode(), utt, out.ctypes.data_as(f32p), out.size, C.byref(r), C.byref(c)))
+    return out
+
+
+class Pipeline:
+    """New capability: bert::predict -> word2ph feature repeat (tts_util.rs:129-154) -> model::synthesize for a batch,
+    device resident between the stages."""
+
+    def __init__(self, bert: Session, vits: Session):
+        self.bert, self.vits = bert, vits
+        self.h = C.c_void_p()
+        check(_lib.lib().sbv2_pipeline_create(bert.handle, vits.handle, C.byref(self.h)))
+
+    def prepare(self, utts, sdp_ratio=0.0, length_scale=1.0, noise_scale=0.0, noise_scale_w=0.0, noise_seed=0, forced=False):
+        """Pack the host-side inputs once (outside any timed region)."""
+        b = _Batch(utts, sdp_ratio, length_scale, noise_scale, noise_scale_w, noise_seed, forced, False)
+        b.ids = np.ascontiguousarray(np.concatenate([np.asarray(u["input_ids"], np.int64) for u in utts]))
+        b.s_lens = np.array([len(u["input_ids"]) for u in utts], np.int64)
+        b.w2p = np.ascontiguousarray(np.concatenate([np.asarray(u["word2ph"], np.int64) for u in utts]))
+        b.lens = np.zeros(len(utts), np.int64)
+        return b
+
+    def run(self, b):
+        check(_lib.lib().sbv2_pipeline_run(self.h, C.byref(b.c), b.ids.ctypes.data_as(i64p), b.s_lens.ctypes.data_as(i64p),
+                                           b.w2p.ctypes.data_as(i64p), b.lens.ctypes.data_as(i64p)))
+        return b.lens
+
+    def fetch(self, b):
+        pcm = np.empty(int(b.lens.sum()), np.float32)
+        check(_lib.lib().sbv2_vits_fetch_pcm(self.vits.handle, pcm.ctypes.data_as(f32p)))
+        return np.split(pcm, np.cumsum(b.lens)[:-1])
+
+    def close(self):
+        if self.h:
+            _lib.lib().sbv2_pipeline_destroy(self.h)
+            self.h = None
