@@ -1,0 +1,165 @@
+"""Benchmark of the sbv2_core hot path on MI355X (contract: see the task statement; one JSON line on rank 0).
+
+Workload (BASELINE.json `metric`, configs[2]): a batch of 32 synthetic utterances of 128 phone symbols per GPU
+(T_text 257, BERT S 64, teacher-forced durations -> 897 frames = 10.414 s of 44.1 kHz audio each),
+full ku-nlp/deberta-v2-large + Style-Bert-VITS2 JP-Extra shapes with procedurally generated weights.
+One step = DeBERTa -> word2ph feature repeat -> text encoder + both duration predictors -> flow -> HiFi-GAN for the
+whole batch, PCM left in HBM; with N > 1 ranks every rank synthesises its own 32 utterances (weak scaling, no
+data-path collective) and the PCM is gathered to rank 0 over RCCL inside the timed step.
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (the implicit-GEMM conv tile configuration with the most time), algorithmic FLOP
+                 over HIP-event durations of one extra instrumented step run right after the timed ones.
+  cpu_baseline — oracle/sbv2_oracle.py (a port, NOT onnxruntime) on the host cores for ONE utterance of the same
+                 workload (rank 0, N = 1 only), torch CPU convolutions, all host threads.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--phones", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="tiny model shapes (plumbing check only; not a valid bench number)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sbv2_api_amd import _lib, model, synth
+    l = _lib.lib()
+    if l.sbv2_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+
+    # model shapes (kept in synth-free dicts here: the oracle is not imported on the product path)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sbv2_oracle as O  # configs + cpu_baseline only
+    bc, vc = (O.DEBERTA_TINY, O.VITS_TINY) if args.tiny else (O.DEBERTA_FULL, O.VITS_FULL)
+    bw = synth.make_deberta_weights(bc)
+    vw = synth.make_vits_weights(vc)
+    bs = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, bw), True, device=local_rank)
+    vs = model.load_model(synth.pack_blob(synth.KIND_VITS, vc, vw), False, device=local_rank)
+    pipe = model.Pipeline(bs, vs)
+    utts = [synth.make_utterance(args.phones, bc, vc, seed=rank * 1000 + i) for i in range(args.batch)]
+    b = pipe.prepare(utts, forced=True)   # benchmark mode: blank 1 frame, phone 6 frames
+
+    hop = l.sbv2_vits_hop(vs.handle)
+    send = recv = None
+
+    def step():
+        pipe.run(b)
+        if world > 1:
+            nonlocal send, recv
+            n = int(b.lens.sum())
+            if send is None:
+                send = torch.empty(n, dtype=torch.float32, device="cuda")
+                recv = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
+            _lib.check(l.sbv2_vits_copy_pcm_device(vs.handle, C.c_void_p(send.data_ptr())))
+            dist.gather(send, recv, dst=0)
+        else:
+            _lib.check(l.sbv2_sync(vs.handle))
+
+    def fence():
+        _lib.check(l.sbv2_sync(vs.handle))
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    audio_s_per_rank = float(b.lens.sum()) / O.SAMPLE_RATE
+    total_audio = audio_s_per_rank * world * args.steps
+    value = total_audio / dt
+
+    # ---- roofline leg: one extra instrumented step, HIP events around every implicit-GEMM launch ----------------
+    _lib.check(l.sbv2_prof_begin())
+    pipe.run(b)
+    _lib.check(l.sbv2_sync(vs.handle))
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(l.sbv2_prof_end(buf, len(buf)))
+    prof = json.loads(buf.value.decode())
+    dom = max(prof, key=lambda r: r["ms"]) if prof else None
+    roofline = None
+    if dom:
+        ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "all_conv_gemm_ms_per_step": round(sum(r["ms"] for r in prof), 3),
+                    "all_conv_gemm_tflops": round(sum(r["flop"] for r in prof) / (sum(r["ms"] for r in prof) * 1e-3) / 1e12, 2)}
+
+    # ---- CPU baseline leg (rank 0, N = 1): the oracle on one utterance of the same workload ----------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import torch as _t
+        O.set_conv_backend("torch")
+        u = utts[0]
+        t1 = time.perf_counter()
+        h = O.deberta_forward(bw, bc, u["input_ids"])
+        ref = O.vits_forward(vw, vc, O.expand_bert_features(h, u["word2ph"]), u["phones"], u["tones"], u["langs"], 0, u["style"],
+                             forced_durations=u["forced_durations"])
+        tc = time.perf_counter() - t1
+        O.set_conv_backend("numpy")
+        got = pipe.fetch(b)[0]
+        err = float(np.abs(got - ref).max()) if got.shape == ref.shape else float("nan")
+        cpu = {"value": round(ref.shape[0] / O.SAMPLE_RATE / tc, 4), "unit": "audio-s/s", "cores": _t.get_num_threads(), "kind": "port",
+               "sample": f"1 utterance of the same workload ({args.phones} phones, {ref.shape[0] / O.SAMPLE_RATE:.3f} s audio) through "
+                         f"oracle/sbv2_oracle.py (numpy + torch CPU conv), {tc:.1f} s wall; not onnxruntime",
+               "gpu_vs_oracle_max_abs": err}
+
+    if rank == 0:
+        out = {
+            "metric": "audio_seconds_per_second", "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "real_time_factor": round(dt / total_audio, 6),
+            "config": {"workload": f"batch={args.batch} x {args.phones}-phoneme utterances per GPU, DeBERTa-v2-large(22L) + "
+                                   f"Style-Bert-VITS2 JP-Extra + HiFi-GAN, forced durations -> {int(b.lens[0]) // hop} frames/utt",
+                       "global_batch": args.batch * world, "audio_seconds_per_step": round(audio_s_per_rank * world, 3),
+                       "parallelism": f"utterance-sharded x{world}" + (", RCCL gather of PCM to rank 0" if world > 1 else ""),
+                       "shapes": "tiny (plumbing check)" if args.tiny else "full"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,10 @@ int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* p
 int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm);
 /* Device pointer to the concatenated PCM of the last batch (valid until the next call on the handle). */
 const float* sbv2_vits_pcm_device(sbv2_vits* h, int64_t* total);
+/* Copies the concatenated PCM of the last batch into caller-owned DEVICE memory (e.g. the send buffer of the RCCL gather). */
+int sbv2_vits_copy_pcm_device(sbv2_vits* h, void* dst_device);
+/* Blocks until every kernel the handle has launched is complete (the batch calls are asynchronous up to the PCM). */
+int sbv2_sync(sbv2_vits* h);
 /* Predicted integer durations w_ceil (before any forcing) and log-durations of the last batch, concatenated [sum T]. */
 int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw);
 /* Debug/parity: keep named intermediates of the next calls (x_emb, x, stats, z_p, z, dec_pre, dec_stage<i>). */
@@ -107,6 +111,10 @@ int sbv2_debug_conv1d(int device, const float* x, const float* w, const float* b
 /* y[Cout][L*stride] = conv_transpose1d(x[Cin][L], w[Cin][Cout][k], bias, stride, padding) via the polyphase path. */
 int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout,
                                 int64_t k, int64_t L, int64_t stride, int64_t padding, float pre_slope, float* y);
+/* Per-launch HIP-event timing of the implicit-GEMM kernel family between begin and end; end writes a JSON array
+ * [{"kernel", "launches", "ms", "flop"}] (one entry per tile configuration) into json[cap]. */
+int sbv2_prof_begin(void);
+int sbv2_prof_end(char* json, int64_t cap);
 /* Times `iters` launches of one dilated conv (device buffers, random data) and returns the mean kernel time in ms. */
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters,
                            float* ms);

@@ -39,6 +39,10 @@ SYMBOLS = {
     "sbv2_vits_synthesize_batch": (C.c_int, [C.c_void_p, C.POINTER(Sbv2Batch), i64p]),
     "sbv2_vits_fetch_pcm": (C.c_int, [C.c_void_p, f32p]),
     "sbv2_vits_pcm_device": (C.c_void_p, [C.c_void_p, i64p]),
+    "sbv2_vits_copy_pcm_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sbv2_sync": (C.c_int, [C.c_void_p]),
+    "sbv2_prof_begin": (C.c_int, []),
+    "sbv2_prof_end": (C.c_int, [C.c_char_p, C.c_int64]),
     "sbv2_vits_fetch_durations": (C.c_int, [C.c_void_p, i64p, f32p]),
     "sbv2_vits_set_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "sbv2_vits_get_trace": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, f32p, C.c_int64, i64p, i64p]),

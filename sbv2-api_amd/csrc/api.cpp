@@ -147,6 +147,34 @@ const float* sbv2_vits_pcm_device(sbv2_vits* h, int64_t* total) {
     if (total) *total = h->m->pcm_total();
     return h->m->pcm_device();
 }
+int sbv2_vits_copy_pcm_device(sbv2_vits* h, void* dst_device) {
+    API_BEGIN
+    SBV2_REQUIRE(h && dst_device, "bad arguments");
+    HIP_CHECK(hipSetDevice(h->m->device()));
+    HIP_CHECK(hipMemcpyAsync(dst_device, h->m->pcm_device(), sizeof(float) * (size_t)h->m->pcm_total(), hipMemcpyDeviceToDevice,
+                             h->m->stream()));
+    HIP_CHECK(hipStreamSynchronize(h->m->stream()));
+    API_END
+}
+int sbv2_sync(sbv2_vits* h) {
+    API_BEGIN
+    SBV2_REQUIRE(h, "bad arguments");
+    HIP_CHECK(hipSetDevice(h->m->device()));
+    HIP_CHECK(hipStreamSynchronize(h->m->stream()));
+    API_END
+}
+int sbv2_prof_begin(void) {
+    API_BEGIN
+    conv_prof_begin();
+    API_END
+}
+int sbv2_prof_end(char* json, int64_t cap) {
+    API_BEGIN
+    const std::string s = conv_prof_end();
+    SBV2_REQUIRE(json && (int64_t)s.size() + 1 <= cap, "profile buffer too small");
+    std::memcpy(json, s.c_str(), s.size() + 1);
+    API_END
+}
 int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw) {
     API_BEGIN
     SBV2_REQUIRE(h, "bad arguments");

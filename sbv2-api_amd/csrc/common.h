@@ -141,8 +141,11 @@ struct ConvParams {
     const GemmGroup* groups = nullptr;  // device pointer; when set, blockIdx.z selects the group
     int ngroups = 1;
     int maxM = 0, maxN = 0;  // grid extents when grouped
+    double flops_hint = 0;   // algorithmic FLOP of a grouped launch (profiling only)
 };
 
 void launch_conv(const ConvParams& p, hipStream_t stream);
+void conv_prof_begin();
+std::string conv_prof_end();
 
 }  // namespace sbv2

@@ -255,6 +255,60 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
     }
 }
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
+namespace {
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int cfg;
+    double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+const char* kCfgNames[] = {"conv_gemm<16,1,4,1,4,16>", "conv_gemm<32,1,2,1,4,16>", "conv_gemm<32,1,1,1,4,16>", "conv_gemm<32,2,4,2,2,16>",
+                           "conv_gemm<32,2,2,2,2,16>", "conv_gemm<32,2,2,1,4,16>", "conv_gemm<32,1,2,2,2,16>", "conv_gemm<32,1,1,2,2,16>"};
+constexpr int kNumCfg = 8;
+constexpr int cfg_id(int MF, int TM, int TN, int WM) {
+    return MF == 16 ? 0 : (WM == 1 ? (TM == 1 ? (TN == 2 ? 1 : 2) : 5) : (TM == 2 ? (TN == 4 ? 3 : 4) : (TN == 2 ? 6 : 7)));
+}
+}  // namespace
+
+void conv_prof_begin() {
+    for (auto& r : g_prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    g_prof_on = true;
+}
+// returns one line per tile configuration: name, launches, total ms, total algorithmic FLOP
+std::string conv_prof_end() {
+    g_prof_on = false;
+    double ms[kNumCfg] = {0}, fl[kNumCfg] = {0};
+    long cnt[kNumCfg] = {0};
+    for (auto& r : g_prof) {
+        (void)hipEventSynchronize(r.e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
+        ms[r.cfg] += t;
+        fl[r.cfg] += r.flops;
+        cnt[r.cfg]++;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    std::string out = "[";
+    bool first = true;
+    for (int c = 0; c < kNumCfg; ++c) {
+        if (!cnt[c]) continue;
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flop\": %.6e}", first ? "" : ", ", kCfgNames[c],
+                 cnt[c], ms[c], fl[c]);
+        out += buf;
+        first = false;
+    }
+    return out + "]";
+}
+
 template <int MF, int TM, int TN, int WM, int WN, int KC>
 static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stream) {
     constexpr int MT = MF * TM * WM;
@@ -283,8 +337,20 @@ static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stre
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.cfg = cfg_id(MF, TM, TN, WM);
+        rec.flops = p.groups ? p.flops_hint : 2.0 * p.M * (double)p.N * p.K * p.ntaps;
+        HIP_CHECK(hipEventCreate(&rec.e0));
+        HIP_CHECK(hipEventCreate(&rec.e1));
+        HIP_CHECK(hipEventRecord(rec.e0, stream));
+    }
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, stream, kp);
     HIP_CHECK(hipGetLastError());
+    if (g_prof_on) {
+        HIP_CHECK(hipEventRecord(rec.e1, stream));
+        g_prof.push_back(rec);
+    }
 }
 
 void launch_conv(const ConvParams& p, hipStream_t stream) {

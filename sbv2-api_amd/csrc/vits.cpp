@@ -25,6 +25,7 @@ struct AttnPlan {
     GemmGroup* d_pv = nullptr;
     float* S = nullptr;
     float* PW = nullptr;
+    double flops = 0;  // algorithmic FLOP of one grouped product over all (utterance, head) problems
 };
 
 AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int window, Arena& ar) {
@@ -51,6 +52,7 @@ AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int wind
             a.head = h;
             st[gi] = GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, dk, T};                        // S^T = K^T Q
             pv[gi] = GemmGroup{(int64_t)lay.start[u] * H + h * dk, s_off, a.qk_off, 0, dk, T, T, T};  // ctx = V P^T
+            pl.flops += 2.0 * (double)T * T * dk;
             s_off += (int64_t)T * pl.lds;
             w_off += (int64_t)(2 * window + 1) * pl.lds;
         }
@@ -66,7 +68,7 @@ AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int wind
 }
 
 void grouped_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc, const GemmGroup* grp, int ng, int maxM, int maxN,
-                  float alpha, hipStream_t s) {
+                  float alpha, double flops, hipStream_t s) {
     ConvParams p;
     p.A = A;
     p.lda = lda;
@@ -79,6 +81,7 @@ void grouped_gemm(const float* A, int lda, const float* B, int ldb, float* C, in
     p.ngroups = ng;
     p.maxM = maxM;
     p.maxN = maxN;
+    p.flops_hint = flops;
     launch_conv(p, s);
 }
 }  // namespace
@@ -260,9 +263,9 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
         conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
         conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
         linear_tokmajor(L.attn.v, x, VT, H, stream_);
-        grouped_gemm(K.p, K.ld, Q.p, Q.ld, pl.S, pl.lds, pl.d_st, pl.ng, pl.maxT, pl.maxT, qscale, stream_);
+        grouped_gemm(K.p, K.ld, Q.p, Q.ld, pl.S, pl.lds, pl.d_st, pl.ng, pl.maxT, pl.maxT, qscale, pl.flops, stream_);
         vits_softmax(pl.d_ag, pl.ng, pl.maxT, pl.S, Q.p, Q.ld, dk, L.attn.erk, cfg_.window, qscale, pl.PW, stream_);
-        grouped_gemm(VT, H, pl.S, pl.lds, ctx.p, ctx.ld, pl.d_pv, pl.ng, dk, pl.maxT, 1.0f, stream_);
+        grouped_gemm(VT, H, pl.S, pl.lds, ctx.p, ctx.ld, pl.d_pv, pl.ng, dk, pl.maxT, 1.0f, pl.flops, stream_);
         vits_relv_add(pl.d_ag, pl.ng, pl.maxT, ctx.p, ctx.ld, dk, L.attn.erv, cfg_.window, pl.PW, stream_);
         conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
         layernorm_ch(Y, x, L.n1g, L.n1b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);

@@ -61,3 +61,18 @@ def test_deberta_full(golden_dir):
     W = synth.make_deberta_weights(cfg, int(z["seed"]))
     out = O.deberta_forward(W, cfg, z["input_ids"])
     np.testing.assert_allclose(out, z["output"], atol=1e-4, rtol=0)
+
+
+def test_torch_conv_backend_matches_numpy():
+    """The cpu_baseline leg of bench.py runs the oracle with torch's CPU convolutions; same results as the numpy path."""
+    cfg = O.VITS_TINY
+    W = synth.make_vits_weights(cfg, 9)
+    z = synth.hash_normal(3, cfg["inter"] * 19).reshape(cfg["inter"], 19)
+    g = synth.hash_normal(4, cfg["gin"])
+    a = O.hifigan(W, cfg, z, g)
+    O.set_conv_backend("torch")
+    try:
+        b = O.hifigan(W, cfg, z, g)
+    finally:
+        O.set_conv_backend("numpy")
+    np.testing.assert_allclose(a, b, atol=2e-6, rtol=0)
