@@ -108,7 +108,6 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
 
     const int ntaps = p.ntaps;
     const int nchunks = (K + KC - 1) / KC;
-    const int nsteps = nchunks * ntaps;
     const int wstart = n0 + kp.wshift0;
     const int xw4 = XW >> 2;
     const int f4x = KC * xw4;
@@ -125,52 +124,72 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
     float4 rw[NW];
     float4 rx[NX];
 
+    // Staging loads are BRANCH-FREE (clamped always-valid addresses; out-of-range elements are zeroed when the registers
+    // are written to LDS) so that they stay in flight across the MFMA block: any control flow around a load makes hipcc
+    // wait vmcnt(0) at the join.  A float4 at column j < n is always inside the row (pitches are multiples of 4).
+    int wk0 = 0, xk0 = 0;
     auto load_w = [&](int tap, int k0) {
+        wk0 = k0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int idx = tid + i * kThreads;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < F4W) {
-                const int kr = idx / (MT / 4);
-                const int m = m0 + (idx % (MT / 4)) * 4;
-                const int k = k0 + kr;
-                if (k < K && m < M) v = load4_guard(Ag + (int64_t)tap * p.a_tap_stride + (int64_t)k * p.lda + m, m, 0, M);
-            }
-            rw[i] = v;
+            const int idx = min(tid + i * kThreads, F4W - 1);
+            const int k = min(k0 + idx / (MT / 4), K - 1);
+            const int m = m0 + (idx % (MT / 4)) * 4;
+            const int mm = m < M ? m : 0;
+            rw[i] = *reinterpret_cast<const float4*>(Ag + (int64_t)tap * p.a_tap_stride + (int64_t)k * p.lda + mm);
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int idx = tid + i * kThreads;
-            if (idx < F4W) *reinterpret_cast<float4*>(ws + buf * (KC * MT) + idx * 4) = rw[i];
+            if (idx < F4W) {
+                const int k = wk0 + idx / (MT / 4);
+                const int m = m0 + (idx % (MT / 4)) * 4;
+                float4 v = rw[i];
+                const bool kin = k < K;
+                v.x = (kin && m < M) ? v.x : 0.f;
+                v.y = (kin && m + 1 < M) ? v.y : 0.f;
+                v.z = (kin && m + 2 < M) ? v.z : 0.f;
+                v.w = (kin && m + 3 < M) ? v.w : 0.f;
+                *reinterpret_cast<float4*>(ws + buf * (KC * MT) + idx * 4) = v;
+            }
         }
     };
     auto load_x = [&](int k0) {
+        xk0 = k0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = min(tid + i * kThreads, f4x - 1);
+            const int kr = idx / xw4;
+            const int j = wstart + (idx - kr * xw4) * 4;
+            const int k = min(k0 + kr, K - 1);
+            const int jj = (j >= 0 && j < nb) ? j : 0;
+            rx[i] = *reinterpret_cast<const float4*>(Bg + (int64_t)k * p.ldb + jj);
+        }
+    };
+    // zero fill + the fused input activation happen here, AFTER the MFMA block
+    auto store_x = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * kThreads;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < f4x) {
                 const int kr = idx / xw4;
                 const int j = wstart + (idx - kr * xw4) * 4;
-                const int k = k0 + kr;
-                if (k < K) v = load4_guard(Bg + (int64_t)k * p.ldb + j, j, 0, nb);
+                const bool kin = (xk0 + kr < K) && j >= 0;
+                float4 v = rx[i];
+                v.x = (kin && j < nb) ? v.x : 0.f;
+                v.y = (kin && j + 1 < nb) ? v.y : 0.f;
+                v.z = (kin && j + 2 < nb) ? v.z : 0.f;
+                v.w = (kin && j + 3 < nb) ? v.w : 0.f;
                 if (slope != 1.0f) {
                     v.x = v.x >= 0.f ? v.x : v.x * slope;
                     v.y = v.y >= 0.f ? v.y : v.y * slope;
                     v.z = v.z >= 0.f ? v.z : v.z * slope;
                     v.w = v.w >= 0.f ? v.w : v.w * slope;
                 }
+                *reinterpret_cast<float4*>(xs + buf * (KC * XW) + idx * 4) = v;
             }
-            rx[i] = v;
-        }
-    };
-    auto store_x = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * kThreads;
-            if (idx < f4x) *reinterpret_cast<float4*>(xs + buf * (KC * XW) + idx * 4) = rx[i];
         }
     };
 
@@ -182,6 +201,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
 
     const int lrow = lane / MF;  // k row inside one MFMA k-step
     const int lcol = lane % MF;
+    const int nsteps = nchunks * ntaps;
     int tap = 0, chunk = 0;
     for (int s = 0; s < nsteps; ++s) {
         int ntap = tap + 1, nchunk = chunk;
@@ -370,14 +390,22 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
     const int64_t z = p.groups ? p.ngroups : 1;
     auto blocks = [&](int mt, int nt) { return z * ((Mx + mt - 1) / mt) * (int64_t)((Nx + nt - 1) / nt); };
     // tile choice: largest tile that still gives >= 2 workgroups per CU; 16-row MFMA for 16-row problems
+    static const int force = getenv("SBV2_CONV_CFG") ? atoi(getenv("SBV2_CONV_CFG")) : -1;   // experiments only
+    if (force >= 0 && Mx > 32) {
+        switch (force) {
+            case 3: return launch_cfg<32, 2, 4, 2, 2, 16>(kp, Mx, Nx, stream);
+            case 4: return launch_cfg<32, 2, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+            case 5: return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
+            case 6: return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+            default: break;
+        }
+    }
     if (Mx <= 16) return launch_cfg<16, 1, 4, 1, 4, 16>(kp, Mx, Nx, stream);
     if (Mx <= 32) {
         if (blocks(32, 256) >= 512) return launch_cfg<32, 1, 2, 1, 4, 16>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 1, 4, 16>(kp, Mx, Nx, stream);
     }
-    const bool fits128 = Mx > 64 && (Mx % 128 == 0 || Mx % 128 > 64);  // a 128-row tile wastes < half of its last tile
-    if (fits128 && blocks(128, 256) >= 512) return launch_cfg<32, 2, 4, 2, 2, 16>(kp, Mx, Nx, stream);
-    if (fits128 && blocks(128, 128) >= 512) return launch_cfg<32, 2, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+    // measured on MI355X: 64-row tiles (81 VGPRs, 48 KB LDS -> 3 workgroups per CU) beat 128x256 (1-2 per CU) by 20-30 %
     if (blocks(64, 256) >= 512) return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
     if (blocks(64, 128) >= 256) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
     return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
