@@ -259,6 +259,7 @@ int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* 
     VitsBatch v = to_batch(batch);
     BertModel& bm = *p->bert->m;
     VitsModel& vm = *p->vits->m;
+    HIP_CHECK(hipStreamSynchronize(vm.stream()));  // the previous batch may still be reading the DeBERTa output plane
     bm.forward(v.n, token_ids, nullptr, s_lens);
     // tts_util.rs:129-154: token i's feature vector is repeated word2ph[i] times along the text axis
     const SegLayout& bl = bm.layout();
@@ -278,7 +279,8 @@ int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* 
     v.bert_dev = &bm.out();
     v.bert_map = map.data();
     // the two models run on their own streams: order them
-    HIP_CHECK(hipStreamSynchronize(bm.stream()));
+    // (an event dependency inside forward(), not a host wait: the VITS host-side packing overlaps the DeBERTa kernels)
+    v.after_stream = bm.stream();
     vm.forward(v);
     for (int i = 0; i < v.n; ++i) pcm_lens[i] = vm.pcm_lens()[i];
     API_END

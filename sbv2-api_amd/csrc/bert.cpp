@@ -113,6 +113,7 @@ BertModel::~BertModel() {
 void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens) {
     HIP_CHECK(hipSetDevice(device_));
     SBV2_REQUIRE(n >= 1, "empty batch");
+    HIP_CHECK(hipStreamSynchronize(stream_));  // pinned staging of the previous call must be drained before reuse
     arena_.reset();
     const int H = cfg_.hidden, nh = cfg_.heads, d = H / nh;
     const int span = cfg_.buckets > 0 ? cfg_.buckets : cfg_.max_rel;
@@ -126,7 +127,7 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     std::vector<unsigned char> am((size_t)total, 1);
     if (mask)
         for (int64_t e = 0; e < total; ++e) am[e] = mask[e] != 0;
-    layout_ = make_layout(L, 0, arena_, am.data());
+    layout_ = make_layout(L, 0, arena_, stream_, am.data());
     const SegLayout& lay = layout_;
     const int N = lay.L;
     const int maxT = lay.max_len();
@@ -142,13 +143,13 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
             }
     }
     int* d_ids = arena_.array<int>(N);
-    HIP_CHECK(hipMemcpyAsync(d_ids, hid.data(), sizeof(int) * N, hipMemcpyHostToDevice, stream_));
+    arena_.upload(d_ids, hid.data(), sizeof(int) * N, stream_);
     // valid-token mask (layout) is all that LayerNorm outputs are multiplied with; the attention mask has its own array
     std::vector<unsigned char> valid(N, 0);
     for (int i = 0; i < n; ++i)
         for (int t = 0; t < L[i]; ++t) valid[lay.start[i] + t] = 1;
     unsigned char* d_valid = arena_.array<unsigned char>(N);
-    HIP_CHECK(hipMemcpyAsync(d_valid, valid.data(), N, hipMemcpyHostToDevice, stream_));
+    arena_.upload(d_valid, valid.data(), N, stream_);
 
     // relative-position window used by this batch
     const std::vector<int> tab = bucket_table(maxT, cfg_.buckets, cfg_.max_rel);
@@ -162,7 +163,7 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     const int wlen = dmax - win_lo + 1;
     const int win_ld = round_up(wlen, 4);
     int* d_tab = arena_.array<int>(tab.size());
-    HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, stream_));
+    arena_.upload(d_tab, tab.data(), sizeof(int) * tab.size(), stream_);
 
     // attention problem descriptors
     const int lds = round_up(maxT, 4);
@@ -200,12 +201,11 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     float* P2C = arena_.array<float>((size_t)p_off);
     AttnGroup* d_ag = arena_.array<AttnGroup>(ng);
     GemmGroup* d_g = arena_.array<GemmGroup>((size_t)4 * ng);
-    HIP_CHECK(hipMemcpyAsync(d_ag, ag.data(), sizeof(AttnGroup) * ng, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_g, g_st.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_g + ng, g_c2p.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_g + 2 * ng, g_p2c.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_g + 3 * ng, g_pv.data(), sizeof(GemmGroup) * ng, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));  // host staging vectors go out of scope below
+    arena_.upload(d_ag, ag.data(), sizeof(AttnGroup) * ng, stream_);
+    arena_.upload(d_g, g_st.data(), sizeof(GemmGroup) * ng, stream_);
+    arena_.upload(d_g + ng, g_c2p.data(), sizeof(GemmGroup) * ng, stream_);
+    arena_.upload(d_g + 2 * ng, g_p2c.data(), sizeof(GemmGroup) * ng, stream_);
+    arena_.upload(d_g + 3 * ng, g_pv.data(), sizeof(GemmGroup) * ng, stream_);
 
     const float inv_scale = 1.0f / std::sqrt((float)d * 3.0f);  // c2p + p2c => scale_factor 3 (:226-232)
 
@@ -219,7 +219,7 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
             for (int t = 0; t < L[i]; ++t, ++e)
                 if (mask[e]) map[lay.start[i] + t] = lay.start[i] + t;
         int* d_map = arena_.array<int>(N);
-        HIP_CHECK(hipMemcpy(d_map, map.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+        arena_.upload(d_map, map.data(), sizeof(int) * N, stream_);
         gather_cols(X, d_map, A, stream_);
         std::swap(X, A);
     }

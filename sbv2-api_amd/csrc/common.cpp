@@ -18,18 +18,39 @@ void Arena::release() {
     for (auto& c : chunks_) (void)hipFree(c.base);
     chunks_.clear();
     cur_ = 0;
+    for (auto& c : pinned_) (void)hipHostFree(c.base);
+    pinned_.clear();
+    pcur_ = 0;
+}
+void Arena::upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (!bytes) return;
+    const size_t need = (bytes + 63) / 64 * 64;
+    for (; pcur_ < pinned_.size(); ++pcur_)
+        if (pinned_[pcur_].off + need <= pinned_[pcur_].cap) break;
+    if (pcur_ == pinned_.size()) {
+        Chunk c{nullptr, std::max(need, (size_t)8 << 20), 0};
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.base), c.cap, hipHostMallocDefault));
+        pinned_.push_back(c);
+    }
+    Chunk& c = pinned_[pcur_];
+    std::memcpy(c.base + c.off, src, bytes);
+    HIP_CHECK(hipMemcpyAsync(dst, c.base + c.off, bytes, hipMemcpyHostToDevice, stream));
+    c.off += need;
 }
 void Arena::reset() {
     if (chunks_.size() > 1) {  // grew during the last pass: one allocation of the total size from now on
         const size_t total = capacity();
         HIP_CHECK(hipDeviceSynchronize());
-        release();
+        for (auto& c : chunks_) (void)hipFree(c.base);
+        chunks_.clear();
         Chunk c{nullptr, total + total / 8, 0};
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.base), c.cap));
         chunks_.push_back(c);
     }
     for (auto& c : chunks_) c.off = 0;
     cur_ = 0;
+    for (auto& c : pinned_) c.off = 0;  // callers guarantee the previous pass's copies are complete
+    pcur_ = 0;
 }
 void Arena::rewind(const Mark& m) {
     if (chunks_.empty()) return;

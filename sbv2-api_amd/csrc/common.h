@@ -59,6 +59,9 @@ class Arena {
     T* array(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
     Mark mark() const { return Mark{cur_, chunks_.empty() ? 0 : chunks_[cur_].off}; }
     void rewind(const Mark& m);  // stack discipline: everything allocated after `m` is dead
+    // Host -> device copy that never blocks the host: the bytes are staged in pinned memory owned by the arena (valid until
+    // the next reset()) and copied asynchronously on `stream`.
+    void upload(void* dst, const void* src, size_t bytes, hipStream_t stream);
     void release();
     size_t capacity() const;
 
@@ -69,6 +72,8 @@ class Arena {
     };
     std::vector<Chunk> chunks_;
     size_t cur_ = 0;
+    std::vector<Chunk> pinned_;
+    size_t pcur_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -109,7 +109,7 @@ PackedUpsample WeightStore::upsample(const std::string& prefix, int stride, int 
     return u;
 }
 
-SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, const unsigned char* extra_mask) {
+SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask) {
     SegLayout l;
     l.n = (int)lens.size();
     int pos = 0;
@@ -132,10 +132,10 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, const
     l.d_mask = arena.array<unsigned char>(l.L);
     l.d_start = arena.array<int>(l.n);
     l.d_len = arena.array<int>(l.n);
-    HIP_CHECK(hipMemcpy(l.d_seg_of, seg.data(), sizeof(int) * l.L, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(l.d_mask, mask.data(), l.L, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(l.d_start, l.start.data(), sizeof(int) * l.n, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(l.d_len, l.len.data(), sizeof(int) * l.n, hipMemcpyHostToDevice));
+    arena.upload(l.d_seg_of, seg.data(), sizeof(int) * l.L, stream);
+    arena.upload(l.d_mask, mask.data(), l.L, stream);
+    arena.upload(l.d_start, l.start.data(), sizeof(int) * l.n, stream);
+    arena.upload(l.d_len, l.len.data(), sizeof(int) * l.n, stream);
     return l;
 }
 

@@ -43,7 +43,7 @@ struct SegLayout {
         return m;
     }
 };
-SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, const unsigned char* extra_mask = nullptr);
+SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask = nullptr);
 
 class WeightStore {
   public:
@@ -135,6 +135,7 @@ struct VitsBatch {
     float sdp_ratio = 0.f, length_scale = 1.f, noise_scale = 0.f, noise_scale_w = 0.f;
     uint64_t seed = 0;
     const int64_t* forced_durations = nullptr;  // concatenated, optional
+    hipStream_t after_stream = nullptr;         // when set, the forward's kernels wait for the work queued on this stream
 };
 
 class VitsModel {

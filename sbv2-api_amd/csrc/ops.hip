@@ -167,47 +167,96 @@ void deberta_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, c
 // and saves the +-w band of the probabilities for the relative-value term.
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxWin = 4;
-__global__ __launch_bounds__(64) void k_vits_softmax(const AttnGroup* groups, float* S, const float* Q, int ldq, int dk,
-                                                      const float* erk, int w, float qscale, float* pwin) {
+// 64 query columns x 4 row slices per workgroup: slice `ty` owns key rows j = ty, ty+4, ...; maxima and sums are combined in LDS.
+__global__ __launch_bounds__(256) void k_vits_softmax(const AttnGroup* groups, float* S, const float* Q, int ldq, int dk,
+                                                       const float* erk, int w, float qscale, float* pwin) {
+    __shared__ float rks[2 * kMaxWin + 1][64];
+    __shared__ float rkp[4][2 * kMaxWin + 1][64];
+    __shared__ float red[4][64];
     const AttnGroup g = groups[blockIdx.y];
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= g.T) return;
-    float* Sg = S + g.s_off;
-    const float* q = Q + g.qk_off + i;
-    float rk[2 * kMaxWin + 1];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    if (blockIdx.x * 64 >= g.T) return;  // whole workgroup out of range (uniform)
+    const bool ok = i < g.T;
+    const int ic = ok ? i : g.T - 1;
+    float* Sg = S + g.s_off + ic;
+    const size_t lds = g.lds;
+    const int T = g.T;
+    // relative-key logits q_i . emb_rel_k[r] (each slice sums a quarter of the head dimension)
+    {
+        float rk[2 * kMaxWin + 1];
 #pragma unroll
-    for (int r = 0; r < 2 * kMaxWin + 1; ++r) rk[r] = 0.f;
-    for (int d = 0; d < dk; ++d) {
-        const float qv = q[(size_t)d * ldq];
+        for (int r = 0; r < 2 * kMaxWin + 1; ++r) rk[r] = 0.f;
+        const float* q = Q + g.qk_off + ic;
+        for (int d = ty; d < dk; d += 4) {
+            const float qv = q[(size_t)d * ldq];
 #pragma unroll
-        for (int r = 0; r < 2 * kMaxWin + 1; ++r)
-            if (r < 2 * w + 1) rk[r] += qv * erk[r * dk + d];
+            for (int r = 0; r < 2 * kMaxWin + 1; ++r)
+                if (r < 2 * w + 1) rk[r] += qv * erk[r * dk + d];
+        }
+#pragma unroll
+        for (int r = 0; r < 2 * kMaxWin + 1; ++r) rkp[ty][r][tx] = rk[r];
+        __syncthreads();
+        if (ty == 0) {
+#pragma unroll
+            for (int r = 0; r < 2 * kMaxWin + 1; ++r)  // fixed summation order: results must not depend on scheduling
+                rks[r][tx] = (((rkp[0][r][tx] + rkp[1][r][tx]) + rkp[2][r][tx]) + rkp[3][r][tx]) * qscale;
+        }
+        __syncthreads();
     }
-#pragma unroll
-    for (int r = 0; r < 2 * kMaxWin + 1; ++r) {
-        const int j = i + r - w;
-        if (r < 2 * w + 1 && j >= 0 && j < g.T) Sg[(size_t)j * g.lds + i] += rk[r] * qscale;
-    }
+    auto score = [&](int j) -> float {
+        float v = Sg[(size_t)j * lds];
+        const int r = j - ic + w;
+        if (r >= 0 && r <= 2 * w) v += rks[r][tx];
+        return v;
+    };
     float mx = -FLT_MAX;
-    for (int j = 0; j < g.T; ++j) mx = fmaxf(mx, Sg[(size_t)j * g.lds + i]);
-    float sum = 0.f;
-    for (int j = 0; j < g.T; ++j) {
-        const float e = expf(Sg[(size_t)j * g.lds + i] - mx);
-        Sg[(size_t)j * g.lds + i] = e;
-        sum += e;
+    int j = ty;
+    for (; j + 12 < T; j += 16) {
+        const float a = score(j), b = score(j + 4), c = score(j + 8), d = score(j + 12);
+        mx = fmaxf(fmaxf(mx, fmaxf(a, b)), fmaxf(c, d));
     }
-    for (int j = 0; j < g.T; ++j) Sg[(size_t)j * g.lds + i] /= sum;
-    float* pw = pwin + g.aux_off;
+    for (; j < T; j += 4) mx = fmaxf(mx, score(j));
+    red[ty][tx] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][tx], red[1][tx]), fmaxf(red[2][tx], red[3][tx]));
+    __syncthreads();
+    float sum = 0.f;
+    j = ty;
+    for (; j + 12 < T; j += 16) {
+        const float a = expf(score(j) - mx), b = expf(score(j + 4) - mx), c = expf(score(j + 8) - mx), d = expf(score(j + 12) - mx);
+        if (ok) {
+            Sg[(size_t)j * lds] = a;
+            Sg[(size_t)(j + 4) * lds] = b;
+            Sg[(size_t)(j + 8) * lds] = c;
+            Sg[(size_t)(j + 12) * lds] = d;
+        }
+        sum += (a + b) + (c + d);
+    }
+    for (; j < T; j += 4) {
+        const float a = expf(score(j) - mx);
+        if (ok) Sg[(size_t)j * lds] = a;
+        sum += a;
+    }
+    red[ty][tx] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+    if (!ok) return;
+    for (j = ty; j < T; j += 4) Sg[(size_t)j * lds] *= inv;
+    __syncthreads();
+    if (ty == 0) {
+        float* pw = pwin + g.aux_off;
 #pragma unroll
-    for (int r = 0; r < 2 * kMaxWin + 1; ++r) {
-        const int j = i + r - w;
-        if (r < 2 * w + 1) pw[(size_t)r * g.lds + i] = (j >= 0 && j < g.T) ? Sg[(size_t)j * g.lds + i] : 0.f;
+        for (int r = 0; r < 2 * kMaxWin + 1; ++r) {
+            const int jj = i + r - w;
+            if (r < 2 * w + 1) pw[(size_t)r * lds + i] = (jj >= 0 && jj < T) ? Sg[(size_t)jj * lds] : 0.f;
+        }
     }
 }
 void vits_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, const float* Q, int ldq, int dk, const float* erk,
                   int window, float qscale, float* pwin, hipStream_t s) {
     SBV2_REQUIRE(window <= kMaxWin, "relative attention window larger than the compiled maximum");
-    hipLaunchKernelGGL(k_vits_softmax, dim3((maxT + 63) / 64, ngroups), dim3(64), 0, s, groups, S, Q, ldq, dk, erk, window, qscale,
+    hipLaunchKernelGGL(k_vits_softmax, dim3((maxT + 63) / 64, ngroups), dim3(256), 0, s, groups, S, Q, ldq, dk, erk, window, qscale,
                        pwin);
 }
 

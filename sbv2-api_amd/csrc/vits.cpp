@@ -28,7 +28,7 @@ struct AttnPlan {
     double flops = 0;  // algorithmic FLOP of one grouped product over all (utterance, head) problems
 };
 
-AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int window, Arena& ar) {
+AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int window, Arena& ar, hipStream_t stream) {
     AttnPlan pl;
     const int dk = H / heads;
     pl.ng = lay.n * heads;
@@ -61,9 +61,9 @@ AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int wind
     pl.d_ag = ar.array<AttnGroup>(pl.ng);
     pl.d_st = ar.array<GemmGroup>(pl.ng);
     pl.d_pv = ar.array<GemmGroup>(pl.ng);
-    HIP_CHECK(hipMemcpy(pl.d_ag, ag.data(), sizeof(AttnGroup) * pl.ng, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(pl.d_st, st.data(), sizeof(GemmGroup) * pl.ng, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(pl.d_pv, pv.data(), sizeof(GemmGroup) * pl.ng, hipMemcpyHostToDevice));
+    ar.upload(pl.d_ag, ag.data(), sizeof(AttnGroup) * pl.ng, stream);
+    ar.upload(pl.d_st, st.data(), sizeof(GemmGroup) * pl.ng, stream);
+    ar.upload(pl.d_pv, pv.data(), sizeof(GemmGroup) * pl.ng, stream);
     return pl;
 }
 
@@ -250,7 +250,7 @@ bool VitsModel::get_trace(const std::string& name, int utt, std::vector<float>& 
 void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, const float* spk_vec, Arena& ar) {
     const int H = x.C, heads = cfg_.heads, dk = H / heads, N = lay.L;
     const Arena::Mark mk = ar.mark();
-    const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar);
+    const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar, stream_);
     Plane Q = ar.plane(H, N), K = ar.plane(H, N), ctx = ar.plane(H, N), Y = ar.plane(H, N);
     SBV2_REQUIRE(Q.ld == x.ld, "plane pitch mismatch");
     Plane F = ar.plane(e.layers[0].ffn1.cout, N);
@@ -367,16 +367,24 @@ void VitsModel::run_decoder(Plane z, const SegLayout& fl) {
     pcm_total_ = tot;
     pcm_ = ar.array<float>((size_t)tot);
     int64_t* d_off = ar.array<int64_t>(n);
-    HIP_CHECK(hipMemcpyAsync(d_off, pcm_offs_.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, stream_));
+    ar.upload(d_off, pcm_offs_.data(), sizeof(int64_t) * n, stream_);
     conv_post_tanh(cur, dec_post_w_, dec_post_k_, 0.01f, fl.d_start, fl.d_len, d_off, n, U, maxlen, pcm_, stream_);
 }
 
 void VitsModel::forward(const VitsBatch& b) {
     HIP_CHECK(hipSetDevice(device_));
     SBV2_REQUIRE(b.n >= 1, "empty batch");
+    HIP_CHECK(hipStreamSynchronize(stream_));  // pinned staging of the previous call must be drained before reuse
     arena_.reset();
     keep_.reset();
     traces_.clear();
+    if (b.after_stream) {
+        hipEvent_t ev;
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev, b.after_stream));
+        HIP_CHECK(hipStreamWaitEvent(stream_, ev, 0));
+        HIP_CHECK(hipEventDestroy(ev));
+    }
     Arena& ar = arena_;
     const int n = b.n, H = cfg_.hidden, I = cfg_.inter;
     std::vector<int> T(n);
@@ -386,7 +394,7 @@ void VitsModel::forward(const VitsBatch& b) {
         T[u] = (int)b.t_lens[u];
         total_t += T[u];
     }
-    tl_ = make_layout(T, kTextGap, ar);
+    tl_ = make_layout(T, kTextGap, ar, stream_);
     const SegLayout& tl = tl_;
     const int Lt = tl.L;
 
@@ -412,11 +420,11 @@ void VitsModel::forward(const VitsBatch& b) {
     int* d_lg = ar.array<int>(Lt);
     int* d_sid = ar.array<int>(n);
     float* d_style = ar.array<float>((size_t)n * cfg_.style_dim);
-    HIP_CHECK(hipMemcpy(d_ph, ph.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_tn, tn.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_lg, lg.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_sid, sid.data(), sizeof(int) * n, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_style, b.styles, sizeof(float) * (size_t)n * cfg_.style_dim, hipMemcpyHostToDevice));
+    ar.upload(d_ph, ph.data(), sizeof(int) * Lt, stream_);
+    ar.upload(d_tn, tn.data(), sizeof(int) * Lt, stream_);
+    ar.upload(d_lg, lg.data(), sizeof(int) * Lt, stream_);
+    ar.upload(d_sid, sid.data(), sizeof(int) * n, stream_);
+    ar.upload(d_style, b.styles, sizeof(float) * (size_t)n * cfg_.style_dim, stream_);
 
     Plane bert = ar.plane(cfg_.bert_dim, Lt);
     if (b.bert_host) {
@@ -435,7 +443,7 @@ void VitsModel::forward(const VitsBatch& b) {
         for (int u = 0; u < n; ++u)
             for (int t = 0; t < T[u]; ++t, ++e) map[tl.start[u] + t] = b.bert_map[e];
         int* d_map = ar.array<int>(Lt);
-        HIP_CHECK(hipMemcpy(d_map, map.data(), sizeof(int) * Lt, hipMemcpyHostToDevice));
+        ar.upload(d_map, map.data(), sizeof(int) * Lt, stream_);
         gather_cols(*b.bert_dev, d_map, bert, stream_);
     }
 
@@ -532,7 +540,7 @@ void VitsModel::forward(const VitsBatch& b) {
             Tf[u] = (int)std::max<int64_t>(sum, 1);  // torch.clamp_min(sum, 1)
         }
     }
-    fl_ = make_layout(Tf, kFrameGap, ar);
+    fl_ = make_layout(Tf, kFrameGap, ar, stream_);
     const SegLayout& fl = fl_;
     const int Lf = fl.L;
     std::vector<int> tok(Lf, -1);
@@ -542,7 +550,7 @@ void VitsModel::forward(const VitsBatch& b) {
             for (int q = 0; q < used[u][t]; ++q) tok[y++] = tl.start[u] + t;
     }
     int* d_tok = ar.array<int>(Lf);
-    HIP_CHECK(hipMemcpy(d_tok, tok.data(), sizeof(int) * Lf, hipMemcpyHostToDevice));
+    ar.upload(d_tok, tok.data(), sizeof(int) * Lf, stream_);
 
     // ---- alignment expansion + prior sample ---------------------------------------------------------------
     Plane ZA = ar.plane(I, Lf), ZB = ar.plane(I, Lf);
