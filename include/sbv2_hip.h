@@ -50,6 +50,9 @@ void sbv2_vits_destroy(sbv2_vits* h);
 int64_t sbv2_vits_hop(const sbv2_vits* h);       /* samples per frame (512) */
 int64_t sbv2_vits_bert_dim(const sbv2_vits* h);  /* 1024 */
 int64_t sbv2_vits_style_dim(const sbv2_vits* h); /* 256 */
+/* Decoder arithmetic chosen at create time (env SBV2_DECODER = f32 | bf16x3 | bf16): 0 = exact f32 MFMA, 1 = split-bf16 MFMA
+ * (hi/lo operands, f32-grade, default), 2 = plain bf16 MFMA. */
+int sbv2_vits_decoder_mode(const sbv2_vits* h);
 
 /* ---- model::synthesize(session, bert_ori, x_tst, sid, tones, lang_ids, style_vector, sdp_ratio, length_scale,
  *                        noise_scale, noise_scale_w) -> Array3<f32>[1, 1, L]      crates/sbv2_core/src/model.rs:53-111
@@ -111,6 +114,10 @@ int sbv2_debug_conv1d(int device, const float* x, const float* w, const float* b
 /* y[Cout][L*stride] = conv_transpose1d(x[Cin][L], w[Cin][Cout][k], bias, stride, padding) via the polyphase path. */
 int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout,
                                 int64_t k, int64_t L, int64_t stride, int64_t padding, float pre_slope, float* y);
+/* Same contract as sbv2_debug_conv1d but through the channels-last bf16 MFMA kernel (mode 1 = split-bf16, 2 = plain bf16);
+ * when iters > 0 also returns the mean time of `iters` further launches in *ms. */
+int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k,
+                         int64_t L, int64_t dilation, float pre_slope, int mode, int64_t iters, float* y, float* ms);
 /* Per-launch HIP-event timing of the implicit-GEMM kernel family between begin and end; end writes a JSON array
  * [{"kernel", "launches", "ms", "flop"}] (one entry per tile configuration) into json[cap]. */
 int sbv2_prof_begin(void);

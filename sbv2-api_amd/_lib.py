@@ -33,6 +33,7 @@ SYMBOLS = {
     "sbv2_vits_hop": (C.c_int64, [C.c_void_p]),
     "sbv2_vits_bert_dim": (C.c_int64, [C.c_void_p]),
     "sbv2_vits_style_dim": (C.c_int64, [C.c_void_p]),
+    "sbv2_vits_decoder_mode": (C.c_int, [C.c_void_p]),
     "sbv2_vits_synthesize": (C.c_int, [C.c_void_p, f32p, i64p, i64p, i64p, C.c_int64, C.c_int64, f32p, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_uint64, C.POINTER(f32p), i64p]),
     "sbv2_pcm_free": (None, [f32p]),
@@ -53,6 +54,8 @@ SYMBOLS = {
     "sbv2_debug_conv1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
     "sbv2_debug_conv_transpose1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                               C.c_int64, C.c_float, f32p]),
+    "sbv2_debug_conv1d_cl": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int,
+                                       C.c_int64, f32p, f32p]),
     "sbv2_debug_time_conv1d": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, f32p]),
 }
 

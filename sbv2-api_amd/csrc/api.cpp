@@ -126,6 +126,7 @@ void sbv2_vits_destroy(sbv2_vits* h) { delete h; }
 int64_t sbv2_vits_hop(const sbv2_vits* h) { return h ? h->m->cfg().hop() : 0; }
 int64_t sbv2_vits_bert_dim(const sbv2_vits* h) { return h ? h->m->cfg().bert_dim : 0; }
 int64_t sbv2_vits_style_dim(const sbv2_vits* h) { return h ? h->m->cfg().style_dim : 0; }
+int sbv2_vits_decoder_mode(const sbv2_vits* h) { return h ? h->m->decoder_mode() : -1; }
 
 int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* pcm_lens) {
     API_BEGIN
@@ -352,6 +353,58 @@ int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, cons
     }
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy2D(y, sizeof(float) * Lo, Y.p, sizeof(float) * Y.ld, sizeof(float) * Lo, cout, hipMemcpyDeviceToHost));
+    API_END
+}
+
+int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k, int64_t L,
+                         int64_t dilation, float pre_slope, int mode, int64_t iters, float* y, float* ms) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(mode == 1 || mode == 2, "mode: 1 = split-bf16, 2 = bf16");
+    Blob b = one_conv_blob(w, bias, {cout, cin, k}, cout);
+    WeightStore ws(b);
+    ClConv c = pack_cl(ws, w, (int)cout, (int)cin, (int)k, mode == 1 ? 2 : 1, bias);
+    std::vector<float> xt((size_t)L * cin), yt((size_t)L * cout);
+    for (int64_t ci = 0; ci < cin; ++ci)
+        for (int64_t n = 0; n < L; ++n) xt[(size_t)n * cin + ci] = x[(size_t)ci * L + n];
+    DevBuf dx(xt.size()), dy(yt.size());
+    HIP_CHECK(hipMemcpy(dx.p, xt.data(), sizeof(float) * xt.size(), hipMemcpyHostToDevice));
+    ConvClParams p;
+    p.X = dx.p;
+    p.ldx = (int)cin;
+    p.NB = (int)L;
+    p.W = c.w;
+    p.nmt = c.nmt;
+    p.tm = c.tm;
+    p.split = mode == 1;
+    p.M = (int)cout;
+    p.N = (int)L;
+    p.K = (int)cin;
+    p.ntaps = (int)k;
+    for (int j = 0; j < k; ++j) p.shift[j] = (int)(j * dilation - dilation * (k - 1) / 2);
+    p.Y = dy.p;
+    p.ldy = (int)cout;
+    p.bias = c.bias;
+    p.pre_slope = pre_slope;
+    launch_conv_cl(p, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (iters > 0 && ms) {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) launch_conv_cl(p, nullptr);
+        HIP_CHECK(hipEventRecord(e1, nullptr));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        *ms = t / (float)iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    HIP_CHECK(hipMemcpy(yt.data(), dy.p, sizeof(float) * yt.size(), hipMemcpyDeviceToHost));
+    for (int64_t co = 0; co < cout; ++co)
+        for (int64_t n = 0; n < L; ++n) y[(size_t)co * L + n] = yt[(size_t)n * cout + co];
     API_END
 }
 

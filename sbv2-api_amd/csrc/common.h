@@ -152,5 +152,31 @@ struct ConvParams {
 void launch_conv(const ConvParams& p, hipStream_t stream);
 void conv_prof_begin();
 std::string conv_prof_end();
+bool conv_prof_active();
+void conv_prof_add(int cfg, double flops, hipEvent_t e0, hipEvent_t e1);
+
+// ---------------------------------------------------------------------------------------------
+// Channels-last bf16 / split-bf16 convolution (conv_cl.hip): X[pos][C] f32 in HBM, weights pre-packed as MFMA fragments
+// ---------------------------------------------------------------------------------------------
+struct ConvClParams {
+    const float* X = nullptr;  // [NB][ldx]
+    int ldx = 0, NB = 0;
+    const void* W = nullptr;   // bf16 fragment blocks [chunk][mtile][tap][part][64 lanes][8]
+    int nmt = 0, tm = 2, split = 1;
+    int M = 0, N = 0, K = 0, ntaps = 1;
+    int shift[kMaxTaps] = {0};
+    float* Y = nullptr;
+    int ldy = 0;
+    const float* bias = nullptr;
+    const float* R = nullptr;
+    int ldr = 0;
+    float pre_slope = 1.0f, beta = 1.0f;
+    int accumulate = 0;
+    const unsigned char* mask = nullptr;
+    int mask_div = 1;
+    int out_stride = 1, phase_rows = 1 << 30;
+    int phase_off[kMaxPhases] = {0};
+};
+void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
 
 }  // namespace sbv2

@@ -1,0 +1,295 @@
+// Channels-last implicit-GEMM convolution on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16), f32 storage.
+//
+//   Y[pos][m] (+)= epi( sum_tap sum_k W_tap[m][k] * pre(X[n + shift_tap][k]) ),   pos = n * out_stride + phase_off[m / phase_rows]
+//
+// Why a second conv kernel: the f32 MFMA of gemm_conv.hip tops out at 157 TFLOP/s; the bf16 MFMA is 16x faster per clock but
+// wants 8 CONSECUTIVE k per lane for both operands (A[row][k = 8h + j], B[k = 8h + j][col]), i.e. k-contiguous ("channels-last")
+// tiles.  The HiFi-GAN decoder (82 % of the path's FLOPs: SURVEY.md §8a a8) therefore runs on planes X[position][channel].
+//
+// Precision modes (template SPLIT):
+//   SPLIT = true : every f32 operand is split into bf16 hi + bf16 lo (x = hi + lo + O(2^-17 x)) and the product is taken as
+//                  hi*hi + hi*lo + lo*hi with f32 accumulation: 3 MFMAs per tile step, relative error ~1e-5 per product,
+//                  i.e. f32-grade results (the path stays inside the 1e-3 waveform tolerance) at 3/16 the cost of the f32 MFMA.
+//   SPLIT = false: plain bf16 operands (BASELINE.json configs[2] "bf16 MFMA for the decoder GEMMs"), error reported by bench.py.
+// Storage stays f32 in HBM in both modes, so rounding does not compound through the residual chain.
+//
+// Structure: one workgroup = 4 waves = (TM*32 rows) x 256 positions, wave tile (TM*32) x 64.  Per 16-channel chunk the
+// activation window [256 + tap span][16] is converted (leaky-ReLU, hi/lo split) ONCE into LDS and ALL taps' weight fragments of
+// that chunk are copied into LDS in fragment order (1 KB blocks, lane-linear -> conflict-free ds_read_b128), so the tap loop
+// contains no global memory operation and no barrier: B fragments are plain shifted rows of the window.  Global loads for chunk
+// c+1 are issued before the MFMA loop of chunk c and written to LDS after it (two barriers per chunk).
+#include <type_traits>
+
+#include "common.h"
+
+namespace sbv2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// compile-time loop: indices are constants before SROA runs, so per-thread staging arrays stay in registers (a late-unrolled
+// `for` over a 12-entry float4 array was left in scratch by hipcc)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int kClThreads = 256;
+constexpr int kClNT = 256;
+constexpr int kClMaxSpan = 64;
+
+struct ClKernelParams {
+    ConvClParams p;
+    int xrows;    // window rows staged per chunk (NT + tap span)
+    int wshift0;  // min shift
+    int wbytes;   // LDS bytes of the weight region
+    int nmt;      // 32-row tiles in the packed weights (padded to a multiple of TM)
+    int mask_shift;
+};
+
+template <int TM, bool SPLIT>
+__global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParams kp) {
+    constexpr int PARTS = SPLIT ? 2 : 1;
+    constexpr int TN = 2;
+    constexpr int MAXW = (kMaxTaps * TM * PARTS * 64 + kClThreads - 1) / kClThreads;  // float4 per thread for one chunk's weights
+    constexpr int NX = ((kClNT + kClMaxSpan) * 4 + kClThreads - 1) / kClThreads;
+    const ConvClParams& p = kp.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wsm = smem;
+    char* xs_hi = smem + kp.wbytes;
+    char* xs_lo = xs_hi + kp.xrows * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn0 = wave * 64;
+    const int m0 = blockIdx.y * (TM * 32);
+    const int n0 = blockIdx.x * kClNT;
+    const int M = p.M, N = p.N, NB = p.NB, ntaps = p.ntaps;
+    const int nchunks = p.K >> 4;
+    const int wstart = n0 + kp.wshift0;
+    const int nwf4 = ntaps * TM * PARTS * 64;   // float4 of one chunk's weight region
+    const int nxf4 = kp.xrows * 4;
+    const float slope = p.pre_slope;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4v rw[MAXW];
+    float4 rx[NX];
+    // branch-free loads (clamped, always-valid addresses); see gemm_conv.hip for why
+    auto load_w = [&](int chunk) {
+        const f32x4v* src = reinterpret_cast<const f32x4v*>(p.W) + ((int64_t)chunk * kp.nmt + blockIdx.y * TM) * ntaps * PARTS * 64;
+        static_for<0, MAXW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            rw[i] = src[min(tid + i * kClThreads, nwf4 - 1)];
+        });
+    };
+    auto store_w = [&]() {
+        static_for<0, MAXW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * kClThreads;
+            if (idx < nwf4) reinterpret_cast<f32x4v*>(wsm)[idx] = rw[i];
+        });
+    };
+    auto load_x = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = min(tid + i * kClThreads, nxf4 - 1);
+            const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
+            rx[i] = *reinterpret_cast<const float4*>(p.X + (int64_t)pos * p.ldx + chunk * 16 + (idx & 3) * 4);
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * kClThreads;
+            if (idx < nxf4) {
+                const int row = idx >> 2, q = idx & 3;
+                const int pos = wstart + row;
+                float4 v = rx[i];
+                if (pos < 0 || pos >= NB) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (slope != 1.0f) {
+                    v.x = v.x >= 0.f ? v.x : v.x * slope;
+                    v.y = v.y >= 0.f ? v.y : v.y * slope;
+                    v.z = v.z >= 0.f ? v.z : v.z * slope;
+                    v.w = v.w >= 0.f ? v.w : v.w * slope;
+                }
+                // row = 32 bytes = two 16-byte halves (k 0-7 | k 8-15); the half index is XOR-swizzled with bit 3 of the row so
+                // that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots
+                const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
+                bf16x4 h;
+                h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+                *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
+                if (SPLIT) {
+                    bf16x4 l;
+                    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+                    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+                    *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
+                }
+            }
+        }
+    };
+
+    load_w(0);
+    load_x(0);
+    store_w();
+    store_x();
+    __syncthreads();
+
+    const int lcol = lane & 31, lh = lane >> 5;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) {
+            load_w(chunk + 1);
+            load_x(chunk + 1);
+        }
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int sh = p.shift[tap] - kp.wshift0;
+            bf16x8 bh[TN], bl[TN], ah[TM], al[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 32 + lcol + sh;
+                const int off = row * 32 + (((lh ^ (row >> 3)) & 1) << 4);
+                bh[j] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
+                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char* blk = wsm + ((i * ntaps + tap) * PARTS) * 1024 + lane * 16;
+                ah[i] = *reinterpret_cast<const bf16x8*>(blk);
+                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(blk + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();   // every wave is done reading this chunk's tiles
+        if (more) {
+            store_w();
+            store_x();
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: each lane owns one position (column) and, per accumulator quad, 4 consecutive output channels ------------
+    const bool phased = p.phase_rows < (1 << 30);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + i * 32 + 8 * q + 4 * lh;
+            if (m >= M) continue;
+            int co = m, po = 0, ostride = 1;
+            if (phased) {
+                const int ph = m / p.phase_rows;
+                co = m - ph * p.phase_rows;
+                ostride = p.out_stride;
+#pragma unroll
+                for (int t = 0; t < kMaxPhases; ++t) po = (ph == t) ? p.phase_off[t] : po;
+            }
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 32 + lcol;
+                if (n >= N) continue;
+                const int64_t pos = (int64_t)n * ostride + po;
+                float4 v = make_float4(acc[i][j][4 * q] + b4.x, acc[i][j][4 * q + 1] + b4.y, acc[i][j][4 * q + 2] + b4.z,
+                                       acc[i][j][4 * q + 3] + b4.w);
+                if (p.R) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.R + pos * p.ldr + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                v.x *= p.beta; v.y *= p.beta; v.z *= p.beta; v.w *= p.beta;
+                float4* dst = reinterpret_cast<float4*>(p.Y + pos * p.ldy + co);
+                if (p.accumulate) {
+                    const float4 o = *dst;
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (p.mask) {
+                    const int64_t mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
+                    if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *dst = v;
+            }
+        }
+    }
+}
+
+template <int TM, bool SPLIT>
+static void launch_cl(ClKernelParams kp, hipStream_t stream) {
+    constexpr int PARTS = SPLIT ? 2 : 1;
+    const ConvClParams& p = kp.p;
+    kp.wbytes = p.ntaps * TM * PARTS * 1024;
+    const size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
+    SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
+    auto kern = conv_cl_kernel<TM, SPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((p.N + kClNT - 1) / kClNT, kp.nmt / TM);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = conv_prof_active();
+    if (prof) {
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kClThreads), lds, stream, kp);
+    HIP_CHECK(hipGetLastError());
+    if (prof) {
+        HIP_CHECK(hipEventRecord(e1, stream));
+        conv_prof_add(SPLIT ? (TM == 2 ? 8 : 9) : (TM == 2 ? 10 : 11), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+    }
+}
+
+void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
+    SBV2_REQUIRE(p.ntaps >= 1 && p.ntaps <= kMaxTaps, "bad tap count");
+    SBV2_REQUIRE((p.K & 15) == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 && (p.M & 3) == 0, "conv_cl: channel counts must be multiples of 16 / 4");
+    SBV2_REQUIRE(p.tm == 1 || p.tm == 2, "conv_cl: bad row tiling");
+    if (p.N <= 0) return;
+    ClKernelParams kp;
+    kp.p = p;
+    int smin = p.shift[0], smax = p.shift[0];
+    for (int t = 1; t < p.ntaps; ++t) {
+        smin = std::min(smin, p.shift[t]);
+        smax = std::max(smax, p.shift[t]);
+    }
+    SBV2_REQUIRE(smax - smin <= kClMaxSpan, "conv_cl: tap span too large");
+    kp.wshift0 = smin;
+    kp.xrows = kClNT + (smax - smin);
+    kp.nmt = p.nmt;
+    kp.mask_shift = -1;
+    if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
+        int s = 0;
+        while ((1 << s) < p.mask_div) ++s;
+        kp.mask_shift = s;
+    }
+    if (p.split) {
+        if (p.tm == 2) launch_cl<2, true>(kp, stream);
+        else launch_cl<1, true>(kp, stream);
+    } else {
+        if (p.tm == 2) launch_cl<2, false>(kp, stream);
+        else launch_cl<1, false>(kp, stream);
+    }
+}
+
+}  // namespace sbv2

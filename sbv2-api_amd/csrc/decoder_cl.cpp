@@ -1,0 +1,242 @@
+// HiFi-GAN generator (models_jp_extra.Generator) on channels-last planes with the bf16 / split-bf16 MFMA kernel of conv_cl.hip.
+// Same arithmetic graph as VitsModel::run_decoder (vits.cpp), different layout and matrix-core data type:
+//   dec_mode_ 1 = split-bf16 (hi/lo operands, 3 MFMAs per product, f32-grade), 2 = plain bf16 operands.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "models.h"
+
+namespace sbv2 {
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// Packs W (either [M][K][k] = Conv1d layout, or already [M][K][k] rows built by the caller) into MFMA fragment blocks
+// [chunk][mtile][tap][part][lane][8]: lane l of a block holds W[m = mtile*32 + (l & 31)][k = chunk*16 + 8*(l >> 5) + j][tap].
+ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias) {
+    SBV2_REQUIRE(K % 16 == 0 && M % 4 == 0, "channels-last conv: Cin must be a multiple of 16 and Cout of 4");
+    ClConv c;
+    c.M = M;
+    c.K = K;
+    c.k = k;
+    c.tm = M >= 64 ? 2 : 1;
+    c.nmt = round_up((M + 31) / 32, c.tm);
+    const int nchunks = K / 16;
+    std::vector<uint16_t> h((size_t)nchunks * c.nmt * k * parts * 512, 0);
+    for (int ch = 0; ch < nchunks; ++ch)
+        for (int mt = 0; mt < c.nmt; ++mt)
+            for (int t = 0; t < k; ++t) {
+                uint16_t* blk = h.data() + ((((size_t)ch * c.nmt + mt) * k + t) * parts) * 512;
+                for (int l = 0; l < 64; ++l) {
+                    const int m = mt * 32 + (l & 31);
+                    if (m >= M) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = ch * 16 + 8 * (l >> 5) + j;
+                        const float v = w[((size_t)m * K + kk) * k + t];
+                        const uint16_t hi = f32_to_bf16_rne(v);
+                        blk[l * 8 + j] = hi;
+                        if (parts == 2) blk[512 + l * 8 + j] = f32_to_bf16_rne(v - bf16_to_f32(hi));
+                    }
+                }
+            }
+    c.w = ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
+    if (bias) c.bias = ws.upload(bias, (size_t)M);
+    return c;
+}
+
+void VitsModel::load_decoder_cl(const Blob& blob) {
+    auto conv = [&](const std::string& prefix) {
+        const HostTensor& t = blob.get(prefix + ".weight");
+        const float* b = blob.has(prefix + ".bias") ? blob.get(prefix + ".bias").data : nullptr;
+        return pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], dec_mode_ == 1 ? 2 : 1, b);
+    };
+    cl_pre_ = conv("dec.conv_pre");
+    int C = cfg_.up_initial;
+    const int nk = (int)cfg_.res_kernels.size();
+    for (size_t i = 0; i < cfg_.up_rates.size(); ++i) {
+        ClStage st;
+        st.rate = cfg_.up_rates[i];
+        st.cin = C;
+        C /= 2;
+        st.ch = C;
+        // polyphase groups: rows (phase, cout), taps = input offsets shared by the group's phases (see WeightStore::upsample)
+        const HostTensor& t = blob.get("dec.ups." + std::to_string(i) + ".weight");
+        const float* ub = blob.get("dec.ups." + std::to_string(i) + ".bias").data;
+        const int k = (int)t.dims[2], s = st.rate, pad = (k - s) / 2, cin = (int)t.dims[0], cout = (int)t.dims[1];
+        SBV2_REQUIRE(k - 2 * pad == s, "transposed conv must upsample exactly by its stride");
+        std::vector<std::vector<int>> tsets(s);
+        for (int r = 0; r < s; ++r)
+            for (int tt = -k; tt <= k; ++tt) {
+                const int j = s * tt + r + pad;
+                if (j >= 0 && j < k) tsets[r].push_back(tt);
+            }
+        std::vector<bool> done(s, false);
+        for (int r = 0; r < s; ++r) {
+            if (done[r]) continue;
+            std::vector<int> phases;
+            for (int r2 = r; r2 < s && (int)phases.size() < kMaxPhases; ++r2)
+                if (!done[r2] && tsets[r2] == tsets[r]) {
+                    phases.push_back(r2);
+                    done[r2] = true;
+                }
+            ClUpGroup g;
+            g.ntaps = (int)tsets[r].size();
+            g.nph = (int)phases.size();
+            const int M = g.nph * cout;
+            std::vector<float> w((size_t)M * cin * g.ntaps), bias((size_t)M);
+            for (int pi = 0; pi < g.nph; ++pi)
+                for (int co = 0; co < cout; ++co) {
+                    bias[pi * cout + co] = ub[co];
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int ti = 0; ti < g.ntaps; ++ti)
+                            w[((size_t)(pi * cout + co) * cin + ci) * g.ntaps + ti] =
+                                t.data[((size_t)ci * cout + co) * k + (s * tsets[r][ti] + phases[pi] + pad)];
+                }
+            for (int ti = 0; ti < g.ntaps; ++ti) g.shift[ti] = -tsets[r][ti];
+            for (int pi = 0; pi < kMaxPhases; ++pi) g.phase_off[pi] = pi < g.nph ? phases[pi] : 0;
+            g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, dec_mode_ == 1 ? 2 : 1, bias.data());
+            st.up.push_back(g);
+        }
+        for (int j = 0; j < nk; ++j) {
+            ClBranch rb;
+            rb.k = cfg_.res_kernels[j];
+            rb.dil = cfg_.res_dilations[j];
+            const std::string p = "dec.resblocks." + std::to_string(i * nk + j) + ".";
+            for (size_t n = 0; n < rb.dil.size(); ++n) {
+                rb.c1.push_back(conv(p + "convs1." + std::to_string(n)));
+                rb.c2.push_back(conv(p + "convs2." + std::to_string(n)));
+            }
+            st.branches.push_back(rb);
+        }
+        cl_stages_.push_back(st);
+    }
+}
+
+void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l,
+                        const unsigned char* mask, int mask_div, float pre_slope, const float* R, int ldr, float beta, int accumulate) {
+    ConvClParams p;
+    p.X = X;
+    p.ldx = ldx;
+    p.NB = NB;
+    p.W = c.w;
+    p.nmt = c.nmt;
+    p.tm = c.tm;
+    p.split = dec_mode_ == 1;
+    p.M = c.M;
+    p.N = N;
+    p.K = c.K;
+    p.ntaps = c.k;
+    for (int j = 0; j < c.k; ++j) p.shift[j] = j * dil - pad_l;
+    p.Y = Y;
+    p.ldy = ldy;
+    p.bias = c.bias;
+    p.R = R;
+    p.ldr = ldr;
+    p.pre_slope = pre_slope;
+    p.beta = beta;
+    p.accumulate = accumulate;
+    p.mask = mask;
+    p.mask_div = mask_div;
+    launch_conv_cl(p, stream_);
+}
+
+void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
+    const int n = fl.n, Lf = fl.L, I = cfg_.inter;
+    Arena& ar = arena_;
+    SBV2_REQUIRE(I % 16 == 0, "flow channels must be a multiple of 16 for the channels-last decoder");
+    // z [inter][Lf] -> channels-last [Lf][inter]
+    float* zc = ar.array<float>((size_t)Lf * I);
+    transpose_out(z, 0, Lf, zc, stream_);
+    int C = cfg_.up_initial;
+    float* cur = ar.array<float>((size_t)Lf * C);
+    conv_cl(cl_pre_, zc, I, Lf, cur, C, Lf, 1, cl_pre_.k / 2, fl.d_mask, 1, 1.0f, nullptr, 0, 1.0f, 0);
+    add_segvec_cl(cur, Lf, C, dec_cond_vec_, C, fl.d_seg_of, fl.d_mask, stream_);
+    int U = 1;
+    int64_t Lcur = Lf;
+    const int nk = (int)cfg_.res_kernels.size();
+    for (size_t si = 0; si < cl_stages_.size(); ++si) {
+        const ClStage& st = cl_stages_[si];
+        U *= st.rate;
+        const int64_t Lo = (int64_t)Lf * U;
+        SBV2_REQUIRE(Lo < (1ll << 31), "batch too long for 32-bit positions");
+        C = st.ch;
+        float* XS = ar.array<float>((size_t)Lo * C);
+        const Arena::Mark mk = ar.mark();
+        float* XU = ar.array<float>((size_t)Lo * C);
+        float* T1 = ar.array<float>((size_t)Lo * C);
+        float* YA = ar.array<float>((size_t)Lo * C);
+        float* YB = ar.array<float>((size_t)Lo * C);
+        for (const auto& g : st.up) {
+            ConvClParams p;
+            p.X = cur;
+            p.ldx = st.cin;
+            p.NB = (int)Lcur;
+            p.W = g.c.w;
+            p.nmt = g.c.nmt;
+            p.tm = g.c.tm;
+            p.split = dec_mode_ == 1;
+            p.M = g.c.M;
+            p.N = (int)Lcur;
+            p.K = st.cin;
+            p.ntaps = g.ntaps;
+            for (int t = 0; t < g.ntaps; ++t) p.shift[t] = g.shift[t];
+            p.Y = XU;
+            p.ldy = C;
+            p.bias = g.c.bias;
+            p.pre_slope = 0.1f;
+            p.mask = fl.d_mask;
+            p.mask_div = U;
+            p.out_stride = st.rate;
+            p.phase_rows = C;
+            for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
+            launch_conv_cl(p, stream_);
+        }
+        for (int j = 0; j < nk; ++j) {
+            const ClBranch& rb = st.branches[j];
+            const float* y = XU;
+            const int nd = (int)rb.dil.size();
+            for (int q = 0; q < nd; ++q) {
+                const int d = rb.dil[q];
+                conv_cl(rb.c1[q], y, C, (int)Lo, T1, C, (int)Lo, d, d * (rb.k - 1) / 2, fl.d_mask, U, 0.1f, nullptr, 0, 1.0f, 0);
+                if (q + 1 < nd) {
+                    float* yn = (y == YA) ? YB : YA;
+                    conv_cl(rb.c2[q], T1, C, (int)Lo, yn, C, (int)Lo, 1, (rb.k - 1) / 2, fl.d_mask, U, 0.1f, y, C, 1.0f, 0);
+                    y = yn;
+                } else {
+                    conv_cl(rb.c2[q], T1, C, (int)Lo, XS, C, (int)Lo, 1, (rb.k - 1) / 2, fl.d_mask, U, 0.1f, y, C, 1.0f / nk, j > 0);
+                }
+            }
+        }
+        ar.rewind(mk);
+        cur = XS;
+        Lcur = Lo;
+    }
+    pcm_lens_.assign(n, 0);
+    pcm_offs_.assign(n, 0);
+    int64_t tot = 0, maxlen = 0;
+    for (int u = 0; u < n; ++u) {
+        pcm_offs_[u] = tot;
+        pcm_lens_[u] = (int64_t)fl.len[u] * U;
+        tot += pcm_lens_[u];
+        maxlen = std::max(maxlen, pcm_lens_[u]);
+    }
+    pcm_total_ = tot;
+    pcm_ = ar.array<float>((size_t)tot);
+    int64_t* d_off = ar.array<int64_t>(n);
+    ar.upload(d_off, pcm_offs_.data(), sizeof(int64_t) * n, stream_);
+    conv_post_tanh_cl(cur, C, Lcur, dec_post_w_, dec_post_k_, 0.01f, fl.d_start, fl.d_len, d_off, n, U, maxlen, pcm_, stream_);
+}
+
+}  // namespace sbv2

@@ -70,6 +70,15 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 // y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s);
 
+// A convolution packed for conv_cl.hip (bf16 MFMA fragment blocks); parts = 2 keeps a bf16 hi and a bf16 lo copy.
+struct ClConv {
+    void* w = nullptr;
+    float* bias = nullptr;
+    int M = 0, K = 0, k = 1, nmt = 0, tm = 1;
+};
+// w is [M][K][k] (Conv1d layout)
+ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
+
 struct BertConfig {
     int vocab, hidden, layers, heads, inter, buckets, max_rel;
     float eps;
@@ -155,6 +164,7 @@ class VitsModel {
     const std::vector<float>& logw() const { return logw_host_; }
     hipStream_t stream() const { return stream_; }
     void set_trace(bool on) { trace_ = on; }
+    int decoder_mode() const { return dec_mode_; }
     // copies a traced plane of the last forward for utterance `utt`: returns rows/cols
     bool get_trace(const std::string& name, int utt, std::vector<float>& out, int& rows, int& cols);
 
@@ -206,6 +216,27 @@ class VitsModel {
     void run_encoder(const Encoder& e, Plane x, const SegLayout& lay, const float* spk_vec, Arena& ar);
     void run_dds(const DDS& d, Plane x, const SegLayout& lay, Arena& ar);
     void run_decoder(Plane z, const SegLayout& fl);
+    // channels-last bf16 / split-bf16 MFMA decoder (decoder_cl.cpp)
+    struct ClUpGroup {
+        ClConv c;
+        int ntaps = 0, nph = 0;
+        int shift[kMaxTaps];
+        int phase_off[kMaxPhases];
+    };
+    struct ClBranch {
+        std::vector<ClConv> c1, c2;
+        std::vector<int> dil;
+        int k;
+    };
+    struct ClStage {
+        std::vector<ClUpGroup> up;
+        std::vector<ClBranch> branches;
+        int cin, ch, rate;
+    };
+    void load_decoder_cl(const Blob& blob);
+    void run_decoder_cl(Plane z, const SegLayout& fl);
+    void conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l, const unsigned char* mask,
+                 int mask_div, float pre_slope, const float* R, int ldr, float beta, int accumulate);
     void trace(const std::string& name, Plane p, const SegLayout& lay, int div = 1);
 
     int device_;
@@ -229,6 +260,9 @@ class VitsModel {
     float* dec_cond_vec_ = nullptr;  // cond(g) per utterance of the running forward
     int dec_post_k_ = 7;
     std::vector<Stage> stages_;
+    int dec_mode_ = 0;  // 0 = exact f32 MFMA (k-major), 1 = split-bf16 (f32-grade), 2 = plain bf16
+    ClConv cl_pre_;
+    std::vector<ClStage> cl_stages_;
     // last-forward results
     float* pcm_ = nullptr;
     int64_t pcm_total_ = 0;

@@ -61,5 +61,9 @@ void conv_post_tanh(Plane x, const float* w, int k, float slope, const int* seg_
 void transpose_out(Plane in, int col0, int T, float* out, hipStream_t s);  // out[t][c] = in[c][col0+t]
 void gather_cols(Plane in, const int* map, Plane out, hipStream_t s);       // out[c][n] = map[n]>=0 ? in[c][map[n]] : 0
 void fill_zero(void* p, size_t bytes, hipStream_t s);
+// channels-last helpers: x[L][C]
+void add_segvec_cl(float* x, int L, int C, const float* vec, int vec_ld, const int* seg_of, const unsigned char* mask, hipStream_t s);
+void conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope, const int* seg_start, const int* seg_len,
+                       const int64_t* pcm_off, int nseg, int up, int64_t max_samples, float* pcm, hipStream_t s);
 
 }  // namespace sbv2

@@ -612,6 +612,59 @@ void gather_cols(Plane in, const int* map, Plane out, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_cols, dim3((out.L + 255) / 256, out.C), dim3(256), 0, s, in, map, out);
 }
 
+__global__ void k_add_segvec_cl(float* x, int L, int C, const float* vec, int vec_ld, const int* seg_of, const unsigned char* mask) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+    const int c4 = C >> 2;
+    if (e >= (int64_t)L * c4) return;
+    const int n = (int)(e / c4), c = (int)(e % c4) * 4;
+    const int sg = seg_of[n];
+    float4* p = reinterpret_cast<float4*>(x + (int64_t)n * C + c);
+    float4 v = *p;
+    if (sg >= 0 && mask[n]) {
+        const float4 g = *reinterpret_cast<const float4*>(vec + (int64_t)sg * vec_ld + c);
+        v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+    } else {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *p = v;
+}
+void add_segvec_cl(float* x, int L, int C, const float* vec, int vec_ld, const int* seg_of, const unsigned char* mask, hipStream_t s) {
+    const int64_t n4 = (int64_t)L * (C >> 2);
+    hipLaunchKernelGGL(k_add_segvec_cl, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, L, C, vec, vec_ld, seg_of, mask);
+}
+
+// Generator tail on a channels-last plane: one thread per output sample, C*k MACs from k consecutive rows
+__global__ __launch_bounds__(256) void k_conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope,
+                                                            const int* seg_start, const int* seg_len, const int64_t* pcm_off, int up,
+                                                            float* pcm) {
+    const int sg = blockIdx.y;
+    const int64_t len = (int64_t)seg_len[sg] * up;
+    const int64_t sidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= len) return;
+    const int64_t col = (int64_t)seg_start[sg] * up + sidx;
+    const int half = k / 2;
+    float a = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int64_t q = col + j - half;
+        if (q < 0 || q >= L) continue;
+        const float4* r = reinterpret_cast<const float4*>(x + q * C);
+        for (int c = 0; c < C; c += 4) {
+            float4 v = r[c >> 2];
+            v.x = v.x >= 0.f ? v.x : v.x * slope;
+            v.y = v.y >= 0.f ? v.y : v.y * slope;
+            v.z = v.z >= 0.f ? v.z : v.z * slope;
+            v.w = v.w >= 0.f ? v.w : v.w * slope;
+            a += w[c * k + j] * v.x + w[(c + 1) * k + j] * v.y + w[(c + 2) * k + j] * v.z + w[(c + 3) * k + j] * v.w;
+        }
+    }
+    pcm[pcm_off[sg] + sidx] = tanhf(a);
+}
+void conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope, const int* seg_start, const int* seg_len,
+                       const int64_t* pcm_off, int nseg, int up, int64_t max_samples, float* pcm, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv_post_tanh_cl, dim3((unsigned)((max_samples + 255) / 256), nseg), dim3(256), 0, s, x, C, L, w, k, slope,
+                       seg_start, seg_len, pcm_off, up, pcm);
+}
+
 void fill_zero(void* p, size_t bytes, hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
 
 }  // namespace sbv2

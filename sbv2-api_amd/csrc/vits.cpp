@@ -217,6 +217,21 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         }
         stages_.push_back(st);
     }
+    // decoder arithmetic: exact f32 MFMA (default) | split-bf16 MFMA, f32-grade | plain bf16 MFMA
+    //   bf16x3 (default when every decoder channel count is a multiple of 16): split-bf16 MFMA, waveform within ~2e-6 of the f32 path
+    //   f32: exact f32 MFMA on k-major planes;  bf16: plain bf16 operands (~1e-3 waveform error)
+    bool cl_ok = cfg_.inter % 16 == 0;
+    for (const Stage& st : stages_) cl_ok = cl_ok && st.ch % 16 == 0;
+    dec_mode_ = cl_ok ? 1 : 0;
+    if (const char* m = getenv("SBV2_DECODER")) {
+        const std::string v(m);
+        if (v == "bf16x3") dec_mode_ = 1;
+        else if (v == "bf16") dec_mode_ = 2;
+        else if (v == "f32") dec_mode_ = 0;
+        else SBV2_REQUIRE(v.empty(), "SBV2_DECODER must be f32, bf16x3 or bf16");
+        SBV2_REQUIRE(dec_mode_ == 0 || cl_ok, "SBV2_DECODER: the bf16 MFMA decoder needs channel counts that are multiples of 16");
+    }
+    if (dec_mode_) load_decoder_cl(blob);
 }
 
 VitsModel::~VitsModel() {
@@ -571,7 +586,8 @@ void VitsModel::forward(const VitsBatch& b) {
     }
     trace("z", ZA, fl);
 
-    run_decoder(ZA, fl);
+    if (dec_mode_) run_decoder_cl(ZA, fl);
+    else run_decoder(ZA, fl);
 }
 
 void VitsModel::copy_pcm(float* host) {

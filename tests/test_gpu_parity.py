@@ -57,6 +57,31 @@ def test_conv_transpose_kernel(cin, cout, k, s, p, L):
     np.testing.assert_allclose(y, ref, atol=2e-5, rtol=1e-5)
 
 
+def _conv_cl_dev(x, w, b, dil, slope, mode):
+    cout, cin, k = w.shape
+    y = np.empty((cout, x.shape[1]), np.float32)
+    P = lambda a: a.ctypes.data_as(f32p)
+    xs, ws, bs = (np.ascontiguousarray(a, np.float32) for a in (x, w, b))
+    ms = np.zeros(1, np.float32)
+    _lib.check(_lib.lib().sbv2_debug_conv1d_cl(0, P(xs), P(ws), P(bs), cin, cout, k, x.shape[1], dil, slope, mode, 0, P(y), P(ms)))
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,L", [(16, 16, 11, 5, 3000), (32, 32, 7, 3, 1500), (64, 64, 3, 1, 777), (128, 128, 11, 1, 1030),
+                                              (256, 256, 7, 5, 515), (192, 512, 7, 1, 130), (16, 16, 3, 3, 70000), (48, 20, 5, 1, 9)])
+def test_conv1d_cl_kernel(cin, cout, k, dil, L):
+    """Channels-last bf16 MFMA kernel: split-bf16 must be f32-grade, plain bf16 within bf16 rounding of the operands."""
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    x = rng.standard_normal((cin, L)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv1d_same(O.leaky_relu(x, 0.1), w, b, dil)
+    got = _conv_cl_dev(x, w, b, dil, 0.1, 1)
+    np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
+    got = _conv_cl_dev(x, w, b, dil, 0.1, 2)
+    np.testing.assert_allclose(got, ref, atol=3e-2, rtol=0)
+
+
 def _golden(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name))
     return z, ast.literal_eval(str(z["cfg"]))
@@ -198,6 +223,35 @@ def test_vits_full_small_utterance():
     print("full-config waveform max-abs error:", err)
     assert err < 2e-4
     s.close()
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-4), ("bf16", 5e-2)])
+def test_vits_decoder_cl_modes(mode, tol):
+    """The channels-last bf16-MFMA decoder (SBV2_DECODER=bf16x3 | bf16) against the oracle: tiny batch + full-shape utterance."""
+    os.environ["SBV2_DECODER"] = mode
+    try:
+        cfg = dict(O.VITS_TINY, up_initial=128)     # decoder channels 64/32/16: the bf16 MFMA needs multiples of 16
+        W = synth.make_vits_weights(cfg, 5)
+        s = model.load_model(synth.pack_blob(synth.KIND_VITS, cfg, W), False)
+        utts = make_utts([6, 13, 8], O.DEBERTA_TINY, cfg, seed0=31)
+        pcms = model.synthesize_batch(s, utts, forced=True)
+        for i, (u, got) in enumerate(zip(utts, pcms)):
+            r = _oracle_utt(W, cfg, u, i, 0.0, 1.0, 0.0, 0.0, 0, True)
+            np.testing.assert_allclose(got, r["pcm"], atol=tol, rtol=0)
+            alone = model.synthesize_batch(s, [u], forced=True)[0]
+            np.testing.assert_array_equal(alone, got)
+        s.close()
+        cfg, W = weights("vits", "full")
+        s = model.load_model(blob("vits", "full"), False)
+        u = make_utts([12], O.DEBERTA_FULL, cfg, seed0=41)[0]
+        pcm = model.synthesize(s, u["bert"], u["phones"], [0], u["tones"], u["langs"], u["style"], 0.0, 1.0, 0.0, 0.0)
+        r = _oracle_utt(W, cfg, u, 0, 0.0, 1.0, 0.0, 0.0, 0, False)
+        err = float(np.abs(pcm[0, 0] - r["pcm"]).max())
+        print(f"decoder {mode}: full-shape waveform max-abs error {err:.3e} (peak |pcm| {np.abs(r['pcm']).max():.3f})")
+        assert err < tol
+        s.close()
+    finally:
+        os.environ.pop("SBV2_DECODER", None)
 
 
 def test_pipeline_tiny():
