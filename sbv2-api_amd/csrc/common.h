@@ -176,6 +176,9 @@ struct ConvClParams {
     int mask_div = 1;
     int out_stride = 1, phase_rows = 1 << 30;
     int phase_off[kMaxPhases] = {0};
+    int in_km = 0, out_km = 0;  // operand / result layout: 0 = channels-last [pos][C], 1 = k-major plane [C][ld]
+    int act = ACT_NONE;         // k-major output only
+    float alpha = 1.0f;         // k-major output only
 };
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
 

@@ -52,7 +52,7 @@ struct ClKernelParams {
     int mask_shift;
 };
 
-template <int TM, bool SPLIT>
+template <int TM, bool SPLIT, bool IN_KM, bool OUT_KM>
 __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParams kp) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     constexpr int TN = 2;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     const int m0 = blockIdx.y * (TM * 32);
     const int n0 = blockIdx.x * kClNT;
     const int M = p.M, N = p.N, NB = p.NB, ntaps = p.ntaps;
-    const int nchunks = p.K >> 4;
+    const int nchunks = (p.K + 15) >> 4;
     const int wstart = n0 + kp.wshift0;
     const int nwf4 = ntaps * TM * PARTS * 64;   // float4 of one chunk's weight region
     const int nxf4 = kp.xrows * 4;
@@ -100,40 +100,75 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             if (idx < nwf4) reinterpret_cast<f32x4v*>(wsm)[idx] = rw[i];
         });
     };
+    // IN_KM = false: X is channels-last [pos][ldx]; a float4 is 4 channels of one position.
+    // IN_KM = true : X is a k-major plane [k][ldx]; a float4 is 4 positions of one channel and is transposed while staging.
+    const int xr4 = kp.xrows >> 2;
     auto load_x = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = min(tid + i * kClThreads, nxf4 - 1);
-            const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
-            rx[i] = *reinterpret_cast<const float4*>(p.X + (int64_t)pos * p.ldx + chunk * 16 + (idx & 3) * 4);
+            if (IN_KM) {
+                const int kr = idx / xr4;
+                const int j = wstart + (idx - kr * xr4) * 4;
+                const int k = min(chunk * 16 + kr, p.K - 1);
+                rx[i] = *reinterpret_cast<const float4*>(p.X + (int64_t)k * p.ldx + ((j >= 0 && j < NB) ? j : 0));
+            } else {
+                const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
+                rx[i] = *reinterpret_cast<const float4*>(p.X + (int64_t)pos * p.ldx + chunk * 16 + (idx & 3) * 4);
+            }
         }
     };
+    auto lrelu4 = [&](float4& v) {
+        if (slope != 1.0f) {
+            v.x = v.x >= 0.f ? v.x : v.x * slope;
+            v.y = v.y >= 0.f ? v.y : v.y * slope;
+            v.z = v.z >= 0.f ? v.z : v.z * slope;
+            v.w = v.w >= 0.f ? v.w : v.w * slope;
+        }
+    };
+    // LDS window: row = position, 32 bytes = two 16-byte halves (k 0-7 | k 8-15); the half index is XOR-swizzled with bit 3 of
+    // the row so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots
+    int xchunk = 0;
     auto store_x = [&]() {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * kClThreads;
             if (idx < nxf4) {
-                const int row = idx >> 2, q = idx & 3;
-                const int pos = wstart + row;
                 float4 v = rx[i];
-                if (pos < 0 || pos >= NB) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (slope != 1.0f) {
-                    v.x = v.x >= 0.f ? v.x : v.x * slope;
-                    v.y = v.y >= 0.f ? v.y : v.y * slope;
-                    v.z = v.z >= 0.f ? v.z : v.z * slope;
-                    v.w = v.w >= 0.f ? v.w : v.w * slope;
-                }
-                // row = 32 bytes = two 16-byte halves (k 0-7 | k 8-15); the half index is XOR-swizzled with bit 3 of the row so
-                // that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots
-                const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
-                bf16x4 h;
-                h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-                *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
-                if (SPLIT) {
-                    bf16x4 l;
-                    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-                    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-                    *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
+                if (IN_KM) {
+                    const int kr = idx / xr4;
+                    const int r0 = (idx - kr * xr4) * 4;
+                    const int j = wstart + r0;
+                    const bool kin = (xchunk * 16 + kr < p.K) && j >= 0;
+                    v.x = (kin && j < NB) ? v.x : 0.f;
+                    v.y = (kin && j + 1 < NB) ? v.y : 0.f;
+                    v.z = (kin && j + 2 < NB) ? v.z : 0.f;
+                    v.w = (kin && j + 3 < NB) ? v.w : 0.f;
+                    lrelu4(v);
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = r0 + t;
+                        const int off = row * 32 + ((((kr >> 3) ^ (row >> 3)) & 1) << 4) + ((kr & 7) << 1);
+                        const __bf16 h = (__bf16)e[t];
+                        *reinterpret_cast<__bf16*>(xs_hi + off) = h;
+                        if (SPLIT) *reinterpret_cast<__bf16*>(xs_lo + off) = (__bf16)(e[t] - (float)h);
+                    }
+                } else {
+                    const int row = idx >> 2, q = idx & 3;
+                    const int pos = wstart + row;
+                    if (pos < 0 || pos >= NB) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    lrelu4(v);
+                    const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
+                    bf16x4 h;
+                    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+                    *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
+                    if (SPLIT) {
+                        bf16x4 l;
+                        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+                        l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+                        *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
+                    }
                 }
             }
         }
@@ -181,14 +216,47 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         }
         __syncthreads();   // every wave is done reading this chunk's tiles
         if (more) {
+            xchunk = chunk + 1;
             store_w();
             store_x();
         }
         __syncthreads();
     }
 
-    // ---- epilogue: each lane owns one position (column) and, per accumulator quad, 4 consecutive output channels ------------
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------
     const bool phased = p.phase_rows < (1 << 30);
+    if (OUT_KM) {
+        // k-major output plane Y[m][ldy]: for one accumulator register the 32 lanes of a half-wave hold 32 consecutive columns
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= M) continue;
+                const float brow = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn0 + j * 32 + lcol;
+                    if (n >= N) continue;
+                    float v = acc[i][j][r] + brow;
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    v *= p.alpha;
+                    if (p.R) v += p.R[(int64_t)m * p.ldr + n];
+                    v *= p.beta;
+                    float* dst = p.Y + (int64_t)m * p.ldy + n;
+                    if (p.accumulate) v += *dst;
+                    if (p.mask) {
+                        const int mi = kp.mask_shift >= 0 ? (n >> kp.mask_shift) : (n / p.mask_div);
+                        if (!p.mask[mi]) v = 0.f;
+                    }
+                    *dst = v;
+                }
+            }
+        }
+        return;
+    }
+    // channels-last output: each lane owns one position (column) and, per accumulator quad, 4 consecutive output channels
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -232,14 +300,14 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     }
 }
 
-template <int TM, bool SPLIT>
+template <int TM, bool SPLIT, bool IN_KM, bool OUT_KM>
 static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     const ConvClParams& p = kp.p;
     kp.wbytes = p.ntaps * TM * PARTS * 1024;
     const size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
-    auto kern = conv_cl_kernel<TM, SPLIT>;
+    auto kern = conv_cl_kernel<TM, SPLIT, IN_KM, OUT_KM>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -257,13 +325,27 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(SPLIT ? (TM == 2 ? 8 : 9) : (TM == 2 ? 10 : 11), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+        conv_prof_add((SPLIT ? 8 : 10) + (TM == 2 ? 0 : 1) + (IN_KM ? 4 : 0), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+    }
+}
+
+template <int TM, bool SPLIT>
+static void launch_cl_layout(const ClKernelParams& kp, hipStream_t stream) {
+    const ConvClParams& p = kp.p;
+    if (p.in_km) {
+        if (p.out_km) launch_cl<TM, SPLIT, true, true>(kp, stream);
+        else launch_cl<TM, SPLIT, true, false>(kp, stream);
+    } else {
+        SBV2_REQUIRE(!p.out_km, "conv_cl: channels-last input with k-major output is not instantiated");
+        launch_cl<TM, SPLIT, false, false>(kp, stream);
     }
 }
 
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
     SBV2_REQUIRE(p.ntaps >= 1 && p.ntaps <= kMaxTaps, "bad tap count");
-    SBV2_REQUIRE((p.K & 15) == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 && (p.M & 3) == 0, "conv_cl: channel counts must be multiples of 16 / 4");
+    SBV2_REQUIRE((p.ldx & 3) == 0, "conv_cl: input pitch must be a multiple of 4 floats");
+    SBV2_REQUIRE(p.in_km || (p.K & 15) == 0, "conv_cl: channels-last input needs Cin % 16 == 0");
+    SBV2_REQUIRE(p.out_km || ((p.ldy & 3) == 0 && (p.M & 3) == 0), "conv_cl: channels-last output needs Cout % 4 == 0");
     SBV2_REQUIRE(p.tm == 1 || p.tm == 2, "conv_cl: bad row tiling");
     if (p.N <= 0) return;
     ClKernelParams kp;
@@ -273,9 +355,14 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         smin = std::min(smin, p.shift[t]);
         smax = std::max(smax, p.shift[t]);
     }
-    SBV2_REQUIRE(smax - smin <= kClMaxSpan, "conv_cl: tap span too large");
-    kp.wshift0 = smin;
-    kp.xrows = kClNT + (smax - smin);
+    if (p.in_km) {  // float4 loads along the position axis: 16-byte aligned window
+        kp.wshift0 = (smin >= 0) ? (smin / 4) * 4 : -(((-smin) + 3) / 4) * 4;
+        kp.xrows = kClNT + round_up(smax - kp.wshift0, 4);
+    } else {
+        kp.wshift0 = smin;
+        kp.xrows = kClNT + (smax - smin);
+    }
+    SBV2_REQUIRE(kp.xrows - kClNT <= kClMaxSpan, "conv_cl: tap span too large");
     kp.nmt = p.nmt;
     kp.mask_shift = -1;
     if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
@@ -284,11 +371,11 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         kp.mask_shift = s;
     }
     if (p.split) {
-        if (p.tm == 2) launch_cl<2, true>(kp, stream);
-        else launch_cl<1, true>(kp, stream);
+        if (p.tm == 2) launch_cl_layout<2, true>(kp, stream);
+        else launch_cl_layout<1, true>(kp, stream);
     } else {
-        if (p.tm == 2) launch_cl<2, false>(kp, stream);
-        else launch_cl<1, false>(kp, stream);
+        if (p.tm == 2) launch_cl_layout<2, false>(kp, stream);
+        else launch_cl_layout<1, false>(kp, stream);
     }
 }
 

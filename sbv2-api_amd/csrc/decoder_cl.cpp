@@ -26,14 +26,14 @@ static inline float bf16_to_f32(uint16_t h) {
 // Packs W (either [M][K][k] = Conv1d layout, or already [M][K][k] rows built by the caller) into MFMA fragment blocks
 // [chunk][mtile][tap][part][lane][8]: lane l of a block holds W[m = mtile*32 + (l & 31)][k = chunk*16 + 8*(l >> 5) + j][tap].
 ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias) {
-    SBV2_REQUIRE(K % 16 == 0 && M % 4 == 0, "channels-last conv: Cin must be a multiple of 16 and Cout of 4");
     ClConv c;
     c.M = M;
     c.K = K;
     c.k = k;
     c.tm = M >= 64 ? 2 : 1;
     c.nmt = round_up((M + 31) / 32, c.tm);
-    const int nchunks = K / 16;
+    c.parts = parts;
+    const int nchunks = (K + 15) / 16;
     std::vector<uint16_t> h((size_t)nchunks * c.nmt * k * parts * 512, 0);
     for (int ch = 0; ch < nchunks; ++ch)
         for (int mt = 0; mt < c.nmt; ++mt)
@@ -44,6 +44,7 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
                     if (m >= M) continue;
                     for (int j = 0; j < 8; ++j) {
                         const int kk = ch * 16 + 8 * (l >> 5) + j;
+                        if (kk >= K) continue;
                         const float v = w[((size_t)m * K + kk) * k + t];
                         const uint16_t hi = f32_to_bf16_rne(v);
                         blk[l * 8 + j] = hi;

@@ -39,6 +39,10 @@ PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
             for (int j = 0; j < pc.k; ++j) h[((size_t)j * pc.cin + ci) * pc.lda + co] = t.data[((size_t)co * pc.cin + ci) * pc.k + j];
     pc.w = upload(h.data(), h.size());
     if (bias && blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias");
+    if (cl_parts_) {
+        pc.cl = pack_cl(*this, t.data, pc.cout, pc.cin, pc.k, cl_parts_, nullptr);
+        pc.cl.bias = pc.bias;
+    }
     return pc;
 }
 
@@ -55,6 +59,10 @@ PackedConv WeightStore::linear(const std::string& prefix) {
         for (int ci = 0; ci < pc.cin; ++ci) h[(size_t)ci * pc.lda + co] = t.data[(size_t)co * pc.cin + ci];
     pc.w = upload(h.data(), h.size());
     if (blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias");
+    if (cl_parts_) {
+        pc.cl = pack_cl(*this, t.data, pc.cout, pc.cin, 1, cl_parts_, nullptr);
+        pc.cl.bias = pc.bias;
+    }
     return pc;
 }
 
@@ -142,6 +150,39 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
 void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div, hipStream_t s,
                 int act, float pre_slope, const Plane* res, float alpha, float beta, int accumulate) {
     SBV2_REQUIRE(x.C == w.cin && y.C == w.cout, "conv channel mismatch");
+    if (w.cl.parts) {  // bf16 / split-bf16 matrix cores, k-major planes in and out
+        ConvClParams q;
+        q.X = x.p;
+        q.ldx = x.ld;
+        q.NB = x.L;
+        q.W = w.cl.w;
+        q.nmt = w.cl.nmt;
+        q.tm = w.cl.tm;
+        q.split = w.cl.parts == 2;
+        q.M = w.cout;
+        q.N = y.L;
+        q.K = w.cin;
+        q.ntaps = w.k;
+        for (int j = 0; j < w.k; ++j) q.shift[j] = j * dil - pad_l;
+        q.Y = y.p;
+        q.ldy = y.ld;
+        q.bias = w.bias;
+        if (res) {
+            q.R = res->p;
+            q.ldr = res->ld;
+        }
+        q.pre_slope = pre_slope;
+        q.act = act;
+        q.alpha = alpha;
+        q.beta = beta;
+        q.accumulate = accumulate;
+        q.mask = mask;
+        q.mask_div = mask_div;
+        q.in_km = 1;
+        q.out_km = 1;
+        launch_conv_cl(q, s);
+        return;
+    }
     ConvParams p;
     p.A = w.w;
     p.lda = w.lda;
@@ -174,6 +215,26 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s) {
     SBV2_REQUIRE(w.k == 1 && x.C == w.cin, "token-major linear: shape mismatch");
+    if (w.cl.parts && (w.cout & 3) == 0 && (ldy & 3) == 0) {  // k-major plane in, token-major (channels-last) out
+        ConvClParams q;
+        q.X = x.p;
+        q.ldx = x.ld;
+        q.NB = x.L;
+        q.W = w.cl.w;
+        q.nmt = w.cl.nmt;
+        q.tm = w.cl.tm;
+        q.split = w.cl.parts == 2;
+        q.M = w.cout;
+        q.N = x.L;
+        q.K = w.cin;
+        q.Y = y;
+        q.ldy = ldy;
+        q.bias = w.bias;
+        q.in_km = 1;
+        q.out_km = 0;
+        launch_conv_cl(q, s);
+        return;
+    }
     ConvParams p;
     p.A = x.p;  // A[k = cin][m = token]
     p.lda = x.ld;

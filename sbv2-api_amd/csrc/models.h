@@ -8,11 +8,20 @@
 
 namespace sbv2 {
 
-// Weights in the layout gemm_conv expects: [tap][Cin][lda] (k-major, Cout contiguous).
+// A convolution packed for conv_cl.hip (bf16 MFMA fragment blocks); parts = 2 keeps a bf16 hi and a bf16 lo copy.
+struct ClConv {
+    void* w = nullptr;
+    float* bias = nullptr;
+    int M = 0, K = 0, k = 1, nmt = 0, tm = 1, parts = 0;
+};
+
+// Weights in the layout gemm_conv expects: [tap][Cin][lda] (k-major, Cout contiguous), plus (optionally) the bf16 fragment
+// packing of the same weights: when `cl.parts != 0` conv_plain / linear_tokmajor run on the bf16 matrix cores.
 struct PackedConv {
     float* w = nullptr;
     float* bias = nullptr;
     int cout = 0, cin = 0, k = 1, lda = 0;
+    ClConv cl;
     int64_t tap_stride() const { return (int64_t)cin * lda; }
 };
 // One ConvTranspose1d split into groups of output phases that share the same input taps.
@@ -45,9 +54,16 @@ struct SegLayout {
 };
 SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask = nullptr);
 
+class WeightStore;
+// w is [M][K][k] (Conv1d layout); K is zero-padded to a multiple of 16
+ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
+
 class WeightStore {
   public:
-    explicit WeightStore(const Blob& b) : blob_(b) {}
+    // cl_parts: 0 = f32 MFMA only, 1 = also pack plain-bf16 fragments, 2 = also pack split-bf16 (hi/lo) fragments
+    explicit WeightStore(const Blob& b, int cl_parts = 0) : blob_(b), cl_parts_(cl_parts) {}
+    int cl_parts() const { return cl_parts_; }
+    void set_cl_parts(int parts) { cl_parts_ = parts; }
     ~WeightStore();
     float* upload(const float* host, size_t n);
     float* tensor(const std::string& name);                      // raw copy
@@ -59,6 +75,7 @@ class WeightStore {
 
   private:
     const Blob& blob_;
+    int cl_parts_ = 0;
     std::vector<void*> allocs_;
     size_t bytes_ = 0;
 };
@@ -69,15 +86,6 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
                 int accumulate = 0);
 // y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s);
-
-// A convolution packed for conv_cl.hip (bf16 MFMA fragment blocks); parts = 2 keeps a bf16 hi and a bf16 lo copy.
-struct ClConv {
-    void* w = nullptr;
-    float* bias = nullptr;
-    int M = 0, K = 0, k = 1, nmt = 0, tm = 1;
-};
-// w is [M][K][k] (Conv1d layout)
-ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
 
 struct BertConfig {
     int vocab, hidden, layers, heads, inter, buckets, max_rel;

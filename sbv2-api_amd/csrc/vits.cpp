@@ -151,7 +151,17 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(cfg_.inter % 8 == 0, "flow channels must be a multiple of 8");
     SBV2_REQUIRE(cfg_.res_dilations.size() == cfg_.res_kernels.size(), "resblock config mismatch");
 
-    ws_.reset(new WeightStore(blob));
+    // GEMM / conv arithmetic outside the decoder: exact f32 MFMA (default) | split-bf16 | plain bf16 through the k-major variant of
+    // conv_cl.hip.  Measured on MI355X (round 1): the k-major variant transposes while staging (32 ds_write_b16 per thread and
+    // chunk) and reaches only ~48 TFLOP/s on these 1x1 shapes, slower than the f32 MFMA kernel, so it is opt-in only.
+    int gemm_parts = 0;
+    if (const char* m = getenv("SBV2_GEMM")) {
+        const std::string v(m);
+        if (v == "bf16x3") gemm_parts = 2;
+        else if (v == "bf16") gemm_parts = 1;
+        else SBV2_REQUIRE(v == "f32" || v.empty(), "SBV2_GEMM must be f32, bf16x3 or bf16");
+    }
+    ws_.reset(new WeightStore(blob, gemm_parts));
     WeightStore& w = *ws_;
     emb_g_ = w.tensor("emb_g.weight");
     emb_ = w.tensor("enc_p.emb.weight");
@@ -191,6 +201,8 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         c.enc = load_encoder(p + "enc.", cfg_.flow_layers);
         flows_.push_back(c);
     }
+    // the k-major decoder weights stay exact f32 (SBV2_DECODER=f32 is the exact reference path); the bf16 decoder has its own packing
+    w.set_cl_parts(0);
     dec_pre_ = w.conv("dec.conv_pre");
     dec_cond_w_ = w.tensor("dec.cond.weight");
     dec_cond_b_ = w.tensor("dec.cond.bias");
