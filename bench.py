@@ -45,10 +45,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SBV2_FORCE_DIST") == "1"   # the latter exercises the RCCL path on one GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sbv2_api_amd import _lib, model, synth
@@ -75,7 +78,7 @@ def main():
 
     def step():
         pipe.run(b)
-        if world > 1:
+        if use_dist:
             nonlocal send, recv
             n = int(b.lens.sum())
             if send is None:
@@ -88,11 +91,16 @@ def main():
 
     def fence():
         _lib.check(l.sbv2_sync(vs.handle))
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
+    if use_dist:   # create the RCCL communicators outside the measured steps, whatever --warmup is
+        dist.barrier()
+        dummy = torch.zeros(1, device="cuda")
+        dist.gather(dummy, [torch.zeros(1, device="cuda") for _ in range(world)] if rank == 0 else None, dst=0)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -101,7 +109,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -164,7 +172,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
