@@ -84,7 +84,8 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4v rw[MAXW];
-    float4 rx[NX];
+    f32x4v rx[NX];    // channels-last input: both 16-channel halves of a 128-byte line are fetched together (rx = even chunk,
+    f32x4v rx1[NX];   // rx1 = the following odd chunk)
     // branch-free loads (clamped, always-valid addresses); see gemm_conv.hip for why
     auto load_w = [&](int chunk) {
         const f32x4v* src = reinterpret_cast<const f32x4v*>(p.W) + ((int64_t)chunk * kp.nmt + blockIdx.y * TM) * ntaps * PARTS * 64;
@@ -111,10 +112,14 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                 const int kr = idx / xr4;
                 const int j = wstart + (idx - kr * xr4) * 4;
                 const int k = min(chunk * 16 + kr, p.K - 1);
-                rx[i] = *reinterpret_cast<const float4*>(p.X + (int64_t)k * p.ldx + ((j >= 0 && j < NB) ? j : 0));
+                rx[i] = *reinterpret_cast<const f32x4v*>(p.X + (int64_t)k * p.ldx + ((j >= 0 && j < NB) ? j : 0));
             } else {
+                // called for even chunks only: channels [16c, 16c+16) now, [16c+16, 16c+32) kept in registers for chunk c+1, so every
+                // 128-byte line of X is fetched once (PMC: fetching the halves one chunk apart doubled FETCH_SIZE)
                 const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
-                rx[i] = *reinterpret_cast<const float4*>(p.X + (int64_t)pos * p.ldx + chunk * 16 + (idx & 3) * 4);
+                const float* src = p.X + (int64_t)pos * p.ldx + chunk * 16 + (idx & 3) * 4;
+                rx[i] = *reinterpret_cast<const f32x4v*>(src);
+                rx1[i] = *reinterpret_cast<const f32x4v*>(chunk + 1 < nchunks ? src + 16 : src);
             }
         }
     };
@@ -134,7 +139,9 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * kClThreads;
             if (idx < nxf4) {
-                float4 v = rx[i];
+                f32x4v rv = rx[i];
+                if (!IN_KM && (xchunk & 1)) rv = rx1[i];
+                float4 v = make_float4(rv[0], rv[1], rv[2], rv[3]);
                 if (IN_KM) {
                     const int kr = idx / xr4;
                     const int r0 = (idx - kr * xr4) * 4;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         const bool more = chunk + 1 < nchunks;
         if (more) {
             load_w(chunk + 1);
-            load_x(chunk + 1);
+            if (IN_KM || ((chunk + 1) & 1) == 0) load_x(chunk + 1);
         }
         for (int tap = 0; tap < ntaps; ++tap) {
             const int sh = p.shift[tap] - kp.wshift0;
@@ -256,46 +263,55 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         }
         return;
     }
-    // channels-last output: each lane owns one position (column) and, per accumulator quad, 4 consecutive output channels
+    // channels-last output.  In the accumulators a lane owns one position and, per register quad, 4 consecutive channels: stored
+    // directly that is 16 bytes per lane scattered over 32 rows.  Instead each wave transposes its 32 x 64 sub-tile through a private
+    // LDS tile [64 positions][32 channels (+4 pad)] so that 8 consecutive lanes write (and read the residual as) one full 128-byte
+    // line of a row.
+    float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + i * 32 + 8 * q + 4 * lh;
-            if (m >= M) continue;
-            int co = m, po = 0, ostride = 1;
-            if (phased) {
-                const int ph = m / p.phase_rows;
-                co = m - ph * p.phase_rows;
-                ostride = p.out_stride;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int t = 0; t < kMaxPhases; ++t) po = (ph == t) ? p.phase_off[t] : po;
+            for (int q = 0; q < 4; ++q) {
+                f32x4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *reinterpret_cast<f32x4v*>(tile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
             }
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+        const int c4 = (lane & 7) * 4;
+        const int m = m0 + i * 32 + c4;
+        int co = m, po = 0, ostride = 1;
+        if (phased) {
+            const int ph = m / p.phase_rows;
+            co = m - ph * p.phase_rows;
+            ostride = p.out_stride;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn0 + j * 32 + lcol;
-                if (n >= N) continue;
-                const int64_t pos = (int64_t)n * ostride + po;
-                float4 v = make_float4(acc[i][j][4 * q] + b4.x, acc[i][j][4 * q + 1] + b4.y, acc[i][j][4 * q + 2] + b4.z,
-                                       acc[i][j][4 * q + 3] + b4.w);
-                if (p.R) {
-                    const float4 r = *reinterpret_cast<const float4*>(p.R + pos * p.ldr + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                v.x *= p.beta; v.y *= p.beta; v.z *= p.beta; v.w *= p.beta;
-                float4* dst = reinterpret_cast<float4*>(p.Y + pos * p.ldy + co);
-                if (p.accumulate) {
-                    const float4 o = *dst;
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                if (p.mask) {
-                    const int64_t mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
-                    if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                *dst = v;
+            for (int t = 0; t < kMaxPhases; ++t) po = (ph == t) ? p.phase_off[t] : po;
+        }
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && m < M) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int n = n0 + wn0 + row;
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(tile + row * 36 + c4);
+            if (n >= N || m >= M) continue;
+            const int64_t pos = (int64_t)n * ostride + po;
+            float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+            if (p.R) {
+                const float4 r = *reinterpret_cast<const float4*>(p.R + pos * p.ldr + co);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
+            v.x *= p.beta; v.y *= p.beta; v.z *= p.beta; v.w *= p.beta;
+            float4* dst = reinterpret_cast<float4*>(p.Y + pos * p.ldy + co);
+            if (p.accumulate) {
+                const float4 o = *dst;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (p.mask) {
+                const int64_t mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
+                if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *dst = v;
         }
     }
 }
@@ -305,7 +321,8 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     const ConvClParams& p = kp.p;
     kp.wbytes = p.ntaps * TM * PARTS * 1024;
-    const size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
+    size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
+    if (!OUT_KM) lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));  // the epilogue's per-wave transpose tiles
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
     auto kern = conv_cl_kernel<TM, SPLIT, IN_KM, OUT_KM>;
     static bool attr_set = false;
