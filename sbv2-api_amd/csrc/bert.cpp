@@ -53,12 +53,12 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     // GEMM / conv arithmetic outside the decoder: exact f32 MFMA (default) | split-bf16 | plain bf16 through the k-major variant of
     // conv_cl.hip.  Measured on MI355X (round 1): the k-major variant transposes while staging (32 ds_write_b16 per thread and
     // chunk) and reaches only ~48 TFLOP/s on these 1x1 shapes, slower than the f32 MFMA kernel, so it is opt-in only.
-    int gemm_parts = 0;
+    int gemm_parts = 0;   // DeBERTa has 1x1 products only: nothing would use the bf16 fragments by default
     if (const char* m = getenv("SBV2_GEMM")) {
         const std::string v(m);
-        if (v == "bf16x3") gemm_parts = 2;
+        if (v == "f32") gemm_parts = 0;
         else if (v == "bf16") gemm_parts = 1;
-        else SBV2_REQUIRE(v == "f32" || v.empty(), "SBV2_GEMM must be f32, bf16x3 or bf16");
+        else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3 or bf16");
     }
     ws_.reset(new WeightStore(blob, gemm_parts));
     emb_ = ws_->tensor("deberta.embeddings.word_embeddings.weight");

@@ -109,10 +109,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         for (int i = 0; i < NX; ++i) {
             const int idx = min(tid + i * kClThreads, nxf4 - 1);
             if (IN_KM) {
-                const int kr = idx / xr4;
-                const int j = wstart + (idx - kr * xr4) * 4;
-                const int k = min(chunk * 16 + kr, p.K - 1);
-                rx[i] = *reinterpret_cast<const f32x4v*>(p.X + (int64_t)k * p.ldx + ((j >= 0 && j < NB) ? j : 0));
+                // handled by load_xk below (4 x 4 blocks)
             } else {
                 // called for even chunks only: channels [16c, 16c+16) now, [16c+16, 16c+32) kept in registers for chunk c+1, so every
                 // 128-byte line of X is fetched once (PMC: fetching the halves one chunk apart doubled FETCH_SIZE)
@@ -120,6 +117,25 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                 const float* src = p.X + (int64_t)pos * p.ldx + chunk * 16 + (idx & 3) * 4;
                 rx[i] = *reinterpret_cast<const f32x4v*>(src);
                 rx1[i] = *reinterpret_cast<const f32x4v*>(chunk + 1 < nchunks ? src + 16 : src);
+            }
+        }
+    };
+    // k-major input: one thread owns a 4-channel x 4-position block (4 float4 loads along the position axis), transposes it in
+    // registers and writes 4 channels per position with one 8-byte LDS store (instead of sixteen 2-byte stores)
+    constexpr int NBK = ((kClNT + kClMaxSpan) + kClThreads - 1) / kClThreads;   // blocks per thread: 4 * xrows / 4 / 256
+    f32x4v rk[NBK][4];
+    const int nblk = 4 * xr4;
+    auto load_xk = [&](int chunk) {
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int b = min(tid + bi * kClThreads, nblk - 1);
+            const int kq = b / xr4;
+            const int j = wstart + (b - kq * xr4) * 4;
+            const int jj = (j >= 0 && j < NB) ? j : 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = min(chunk * 16 + kq * 4 + t, p.K - 1);
+                rk[bi][t] = *reinterpret_cast<const f32x4v*>(p.X + (int64_t)k * p.ldx + jj);
             }
         }
     };
@@ -143,24 +159,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                 if (!IN_KM && (xchunk & 1)) rv = rx1[i];
                 float4 v = make_float4(rv[0], rv[1], rv[2], rv[3]);
                 if (IN_KM) {
-                    const int kr = idx / xr4;
-                    const int r0 = (idx - kr * xr4) * 4;
-                    const int j = wstart + r0;
-                    const bool kin = (xchunk * 16 + kr < p.K) && j >= 0;
-                    v.x = (kin && j < NB) ? v.x : 0.f;
-                    v.y = (kin && j + 1 < NB) ? v.y : 0.f;
-                    v.z = (kin && j + 2 < NB) ? v.z : 0.f;
-                    v.w = (kin && j + 3 < NB) ? v.w : 0.f;
-                    lrelu4(v);
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int row = r0 + t;
-                        const int off = row * 32 + ((((kr >> 3) ^ (row >> 3)) & 1) << 4) + ((kr & 7) << 1);
-                        const __bf16 h = (__bf16)e[t];
-                        *reinterpret_cast<__bf16*>(xs_hi + off) = h;
-                        if (SPLIT) *reinterpret_cast<__bf16*>(xs_lo + off) = (__bf16)(e[t] - (float)h);
-                    }
+                    // handled by store_xk below
                 } else {
                     const int row = idx >> 2, q = idx & 3;
                     const int pos = wstart + row;
@@ -181,10 +180,41 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         }
     };
 
+    auto store_xk = [&]() {
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int b = tid + bi * kClThreads;
+            if (b < nblk) {
+                const int kq = b / xr4;
+                const int r0 = (b - kq * xr4) * 4;
+                const int j = wstart + r0;
+                const int kbase = xchunk * 16 + kq * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pin = (j + e >= 0) && (j + e < NB);
+                    float4 v = make_float4((pin && kbase < p.K) ? rk[bi][0][e] : 0.f, (pin && kbase + 1 < p.K) ? rk[bi][1][e] : 0.f,
+                                           (pin && kbase + 2 < p.K) ? rk[bi][2][e] : 0.f, (pin && kbase + 3 < p.K) ? rk[bi][3][e] : 0.f);
+                    lrelu4(v);
+                    const int row = r0 + e;
+                    const int off = row * 32 + ((((kq >> 1) ^ (row >> 3)) & 1) << 4) + ((kq & 1) << 3);
+                    bf16x4 h;
+                    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+                    *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
+                    if (SPLIT) {
+                        bf16x4 l;
+                        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+                        l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+                        *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
+                    }
+                }
+            }
+        }
+    };
+
     load_w(0);
-    load_x(0);
+    if (IN_KM) load_xk(0); else load_x(0);
     store_w();
-    store_x();
+    if (IN_KM) store_xk(); else store_x();
     __syncthreads();
 
     const int lcol = lane & 31, lh = lane >> 5;
@@ -192,7 +222,8 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         const bool more = chunk + 1 < nchunks;
         if (more) {
             load_w(chunk + 1);
-            if (IN_KM || ((chunk + 1) & 1) == 0) load_x(chunk + 1);
+            if (IN_KM) load_xk(chunk + 1);
+            else if (((chunk + 1) & 1) == 0) load_x(chunk + 1);
         }
         for (int tap = 0; tap < ntaps; ++tap) {
             const int sh = p.shift[tap] - kp.wshift0;
@@ -225,7 +256,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         if (more) {
             xchunk = chunk + 1;
             store_w();
-            store_x();
+            if (IN_KM) store_xk(); else store_x();
         }
         __syncthreads();
     }

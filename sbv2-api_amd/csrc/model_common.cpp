@@ -150,7 +150,9 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
 void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div, hipStream_t s,
                 int act, float pre_slope, const Plane* res, float alpha, float beta, int accumulate) {
     SBV2_REQUIRE(x.C == w.cin && y.C == w.cout, "conv channel mismatch");
-    if (w.cl.parts) {  // bf16 / split-bf16 matrix cores, k-major planes in and out
+    // bf16 / split-bf16 matrix cores on k-major planes; only for k >= 3: a 1x1 conv has 384 MFMA cycles per 16-channel chunk and the
+    // two barriers + the transposing stage around it cost more than the f32 MFMA kernel (measured, round 1)
+    if (w.cl.parts && w.k >= 3) {
         ConvClParams q;
         q.X = x.p;
         q.ldx = x.ld;
@@ -215,7 +217,7 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s) {
     SBV2_REQUIRE(w.k == 1 && x.C == w.cin, "token-major linear: shape mismatch");
-    if (w.cl.parts && (w.cout & 3) == 0 && (ldy & 3) == 0) {  // k-major plane in, token-major (channels-last) out
+    if (false && w.cl.parts && (w.cout & 3) == 0 && (ldy & 3) == 0) {  // k-major plane in, token-major out: 1x1, see conv_plain
         ConvClParams q;
         q.X = x.p;
         q.ldx = x.ld;
