@@ -139,6 +139,23 @@ def main():
                     "all_conv_gemm_ms_per_step": round(sum(r["ms"] for r in prof), 3),
                     "all_conv_gemm_tflops": round(sum(r["flop"] for r in prof) / (sum(r["ms"] for r in prof) * 1e-3) / 1e12, 2)}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the per-launch FETCH_SIZE (x2, the
+    # gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE of the SAME command line under `rocprofv3 --pmc` is kept in profiles/.
+    if roofline:
+        try:
+            import csv, glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))[-1]
+            want = {"conv_cl<2,split-bf16>": "conv_cl_kernel<2, true, false, false>", "conv_cl<1,split-bf16>": "conv_cl_kernel<1, true, false, false>",
+                    "conv_cl<2,bf16>": "conv_cl_kernel<2, false, false, false>", "conv_gemm<32,2,2,1,4,16>": "conv_gemm_kernel<32, 2, 2, 1, 4, 16>",
+                    "conv_gemm<32,2,4,2,2,16>": "conv_gemm_kernel<32, 2, 4, 2, 2, 16>"}.get(dom["kernel"], "\0")
+            for r in csv.DictReader(open(pm)):
+                if want in r["kernel"]:
+                    roofline["traffic"] = round(float(r["fetch_bytes_per_launch(x2 gfx950 correction)"]) + float(r["write_bytes_per_launch"]))
+                    roofline["traffic_unit"] = "bytes per launch (HBM, PMC)"
+                    roofline["traffic_source"] = os.path.relpath(pm, ROOT)
+        except Exception:
+            pass
+
     # ---- CPU baseline leg (rank 0, N = 1): the oracle on one utterance of the same workload ----------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

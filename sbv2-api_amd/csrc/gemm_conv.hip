@@ -402,6 +402,7 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
             case 4: return launch_cfg<32, 2, 2, 2, 2, 16>(kp, Mx, Nx, stream);
             case 5: return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
             case 6: return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+            case 7: return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
             default: break;
         }
     }
