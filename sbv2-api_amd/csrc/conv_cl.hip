@@ -354,6 +354,8 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     kp.wbytes = p.ntaps * TM * PARTS * 1024;
     size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
     if (!OUT_KM) lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));  // the epilogue's per-wave transpose tiles
+    static const int pad_lds = getenv("SBV2_CL_PADLDS") ? atoi(getenv("SBV2_CL_PADLDS")) : 0;   // occupancy experiments only
+    lds += pad_lds;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
     auto kern = conv_cl_kernel<TM, SPLIT, IN_KM, OUT_KM>;
     static bool attr_set = false;

@@ -30,7 +30,8 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
     c.M = M;
     c.K = K;
     c.k = k;
-    c.tm = M >= 64 ? 2 : 1;
+    static const int tm_min = getenv("SBV2_CL_TM2_MIN") ? atoi(getenv("SBV2_CL_TM2_MIN")) : 64;   // experiments
+    c.tm = M >= tm_min ? 2 : 1;
     c.nmt = round_up((M + 31) / 32, c.tm);
     c.parts = parts;
     const int nchunks = (K + 15) / 16;

@@ -254,6 +254,43 @@ def test_vits_decoder_cl_modes(mode, tol):
         os.environ.pop("SBV2_DECODER", None)
 
 
+def test_full_shapes_mixed_batch_and_long_utterance():
+    """BASELINE configs 4/5 as parity cases: a mixed-length full-shape batch (32..512 phone symbols) and one long utterance
+    (600 symbols -> 4201 frames, 48.8 s of audio) through the whole pipeline; a subset is checked against the oracle (torch CPU
+    convolutions), every waveform for length, finiteness and |x| < 1."""
+    bc, bw = weights("bert", "full")
+    vc, vw = weights("vits", "full")
+    bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
+    pipe = model.Pipeline(bs, vs)
+    ns = [32, 512, 77, 128, 300, 45, 256, 33]
+    utts = [synth.make_utterance(n, bc, vc, seed=900 + i, chars=min(98, max(1, n // 2 - 2))) for i, n in enumerate(ns)]
+    b = pipe.prepare(utts, forced=True)
+    pipe.run(b)
+    pcms = pipe.fetch(b)
+    O.set_conv_backend("torch")
+    try:
+        for i, (u, got) in enumerate(zip(utts, pcms)):
+            assert got.shape[0] == 512 * (7 * ns[i] + 1) and np.isfinite(got).all() and np.abs(got).max() < 1.0
+            if i in (0, 2):
+                h = O.deberta_forward(bw, bc, u["input_ids"])
+                ref = O.vits_forward(vw, vc, O.expand_bert_features(h, u["word2ph"]), u["phones"], u["tones"], u["langs"], 0, u["style"],
+                                     forced_durations=u["forced_durations"])
+                np.testing.assert_allclose(got, ref, atol=1e-3, rtol=0)
+                assert np.abs(got - ref).max() < 5e-5
+        u = synth.make_utterance(600, bc, vc, seed=990, chars=98)
+        b = pipe.prepare([u], forced=True)
+        pipe.run(b)
+        got = pipe.fetch(b)[0]
+        h = O.deberta_forward(bw, bc, u["input_ids"])
+        ref = O.vits_forward(vw, vc, O.expand_bert_features(h, u["word2ph"]), u["phones"], u["tones"], u["langs"], 0, u["style"],
+                             forced_durations=u["forced_durations"])
+        assert got.shape == ref.shape == (512 * 4201,)
+        np.testing.assert_allclose(got, ref, atol=1e-3, rtol=0)
+    finally:
+        O.set_conv_backend("numpy")
+    pipe.close(); bs.close(); vs.close()
+
+
 def test_pipeline_tiny():
     """DeBERTa -> word2ph repeat -> VITS on the device equals predict + expand + synthesize through the host."""
     bc, bw = weights("bert", "tiny", 3)
