@@ -121,43 +121,41 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
 #pragma unroll
             for (int r = 0; r < MM::NACC; ++r) acc[i][j][r] = 0.f;
 
-    float4 rw[NW];
-    float4 rx[NX];
+    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    f32x4r rw[NW], rx[NX];     // staging registers of the next step / chunk
+    f32x4r rw2[NW], rx2[NX];   // second set: 1x1 products prefetch two chunks ahead (see the GEMM loop below)
 
     // Staging loads are BRANCH-FREE (clamped always-valid addresses; out-of-range elements are zeroed when the registers
     // are written to LDS) so that they stay in flight across the MFMA block: any control flow around a load makes hipcc
     // wait vmcnt(0) at the join.  A float4 at column j < n is always inside the row (pitches are multiples of 4).
-    int wk0 = 0, xk0 = 0;
-    auto load_w = [&](int tap, int k0) {
-        wk0 = k0;
+    auto load_w = [&](auto& regs, int tap, int k0) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int idx = min(tid + i * kThreads, F4W - 1);
             const int k = min(k0 + idx / (MT / 4), K - 1);
             const int m = m0 + (idx % (MT / 4)) * 4;
             const int mm = m < M ? m : 0;
-            rw[i] = *reinterpret_cast<const float4*>(Ag + (int64_t)tap * p.a_tap_stride + (int64_t)k * p.lda + mm);
+            regs[i] = *reinterpret_cast<const f32x4r*>(Ag + (int64_t)tap * p.a_tap_stride + (int64_t)k * p.lda + mm);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](auto& regs, int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int idx = tid + i * kThreads;
             if (idx < F4W) {
-                const int k = wk0 + idx / (MT / 4);
+                const int k = k0 + idx / (MT / 4);
                 const int m = m0 + (idx % (MT / 4)) * 4;
-                float4 v = rw[i];
+                f32x4r v = regs[i];
                 const bool kin = k < K;
-                v.x = (kin && m < M) ? v.x : 0.f;
-                v.y = (kin && m + 1 < M) ? v.y : 0.f;
-                v.z = (kin && m + 2 < M) ? v.z : 0.f;
-                v.w = (kin && m + 3 < M) ? v.w : 0.f;
-                *reinterpret_cast<float4*>(ws + buf * (KC * MT) + idx * 4) = v;
+                v[0] = (kin && m < M) ? v[0] : 0.f;
+                v[1] = (kin && m + 1 < M) ? v[1] : 0.f;
+                v[2] = (kin && m + 2 < M) ? v[2] : 0.f;
+                v[3] = (kin && m + 3 < M) ? v[3] : 0.f;
+                *reinterpret_cast<f32x4r*>(ws + buf * (KC * MT) + idx * 4) = v;
             }
         }
     };
-    auto load_x = [&](int k0) {
-        xk0 = k0;
+    auto load_x = [&](auto& regs, int k0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = min(tid + i * kThreads, f4x - 1);
@@ -165,54 +163,37 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
             const int j = wstart + (idx - kr * xw4) * 4;
             const int k = min(k0 + kr, K - 1);
             const int jj = (j >= 0 && j < nb) ? j : 0;
-            rx[i] = *reinterpret_cast<const float4*>(Bg + (int64_t)k * p.ldb + jj);
+            regs[i] = *reinterpret_cast<const f32x4r*>(Bg + (int64_t)k * p.ldb + jj);
         }
     };
     // zero fill + the fused input activation happen here, AFTER the MFMA block
-    auto store_x = [&](int buf) {
+    auto store_x = [&](auto& regs, int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * kThreads;
             if (idx < f4x) {
                 const int kr = idx / xw4;
                 const int j = wstart + (idx - kr * xw4) * 4;
-                const bool kin = (xk0 + kr < K) && j >= 0;
-                float4 v = rx[i];
-                v.x = (kin && j < nb) ? v.x : 0.f;
-                v.y = (kin && j + 1 < nb) ? v.y : 0.f;
-                v.z = (kin && j + 2 < nb) ? v.z : 0.f;
-                v.w = (kin && j + 3 < nb) ? v.w : 0.f;
+                const bool kin = (k0 + kr < K) && j >= 0;
+                f32x4r v = regs[i];
+                v[0] = (kin && j < nb) ? v[0] : 0.f;
+                v[1] = (kin && j + 1 < nb) ? v[1] : 0.f;
+                v[2] = (kin && j + 2 < nb) ? v[2] : 0.f;
+                v[3] = (kin && j + 3 < nb) ? v[3] : 0.f;
                 if (slope != 1.0f) {
-                    v.x = v.x >= 0.f ? v.x : v.x * slope;
-                    v.y = v.y >= 0.f ? v.y : v.y * slope;
-                    v.z = v.z >= 0.f ? v.z : v.z * slope;
-                    v.w = v.w >= 0.f ? v.w : v.w * slope;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope;
                 }
-                *reinterpret_cast<float4*>(xs + buf * (KC * XW) + idx * 4) = v;
+                *reinterpret_cast<f32x4r*>(xs + buf * (KC * XW) + idx * 4) = v;
             }
         }
     };
 
-    load_x(0);
-    load_w(0, 0);
-    store_x(0);
-    store_w(0);
-    __syncthreads();
-
     const int lrow = lane / MF;  // k row inside one MFMA k-step
     const int lcol = lane % MF;
-    const int nsteps = nchunks * ntaps;
-    int tap = 0, chunk = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == ntaps) { ntap = 0; nchunk = chunk + 1; }
-        const bool has_next = s + 1 < nsteps;
-        const bool new_chunk = has_next && ntap == 0;
-        if (has_next) load_w(ntap, nchunk * KC);
-        if (new_chunk) load_x(nchunk * KC);
-
-        const float* wsb = ws + (s & 1) * (KC * MT) + wm0 + lcol;
-        const float* xsb = xs + (chunk & 1) * (KC * XW) + wn0 + lcol + (p.shift[tap] - kp.wshift0);
+    auto compute = [&](int wbuf, int xbuf, int shift) {
+        const float* wsb = ws + wbuf * (KC * MT) + wm0 + lcol;
+        const float* xsb = xs + xbuf * (KC * XW) + wn0 + lcol + (shift - kp.wshift0);
 #pragma unroll
         for (int kk = 0; kk < KC / MM::KS; ++kk) {
             const int kr = kk * MM::KS + lrow;
@@ -226,12 +207,57 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = MM::run(a[i], b[j], acc[i][j]);
         }
+    };
 
-        if (has_next) store_w((s + 1) & 1);
-        if (new_chunk) store_x(nchunk & 1);
+    load_x(rx, 0);
+    load_w(rw, 0, 0);
+    store_x(rx, 0, 0);
+    store_w(rw, 0, 0);
+
+    if (ntaps == 1 && nchunks >= 3) {
+        // 1x1 products (Linear layers, attention): every step is a new chunk, so a one-step prefetch only hides one MFMA block
+        // (~1024 cycles) of the ~2 us global latency.  Two register sets keep the loads of chunks c+1 and c+2 in flight.
+        const int sh0 = p.shift[0];
+        load_x(rx, KC);
+        load_w(rw, 0, KC);
         __syncthreads();
-        tap = ntap;
-        chunk = nchunk;
+        for (int c = 0; c < nchunks; c += 2) {
+            load_x(rx2, min(c + 2, nchunks - 1) * KC);
+            load_w(rw2, 0, min(c + 2, nchunks - 1) * KC);
+            compute(0, 0, sh0);
+            if (c + 1 < nchunks) {
+                store_x(rx, 1, (c + 1) * KC);
+                store_w(rw, 1, (c + 1) * KC);
+            }
+            __syncthreads();
+            if (c + 1 >= nchunks) break;
+            load_x(rx, min(c + 3, nchunks - 1) * KC);
+            load_w(rw, 0, min(c + 3, nchunks - 1) * KC);
+            compute(1, 1, sh0);
+            if (c + 2 < nchunks) {
+                store_x(rx2, 0, (c + 2) * KC);
+                store_w(rw2, 0, (c + 2) * KC);
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        const int nsteps = nchunks * ntaps;
+        int tap = 0, chunk = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == ntaps) { ntap = 0; nchunk = chunk + 1; }
+            const bool has_next = s + 1 < nsteps;
+            const bool new_chunk = has_next && ntap == 0;
+            if (has_next) load_w(rw, ntap, nchunk * KC);
+            if (new_chunk) load_x(rx, nchunk * KC);
+            compute(s & 1, chunk & 1, p.shift[tap]);
+            if (has_next) store_w(rw, (s + 1) & 1, nchunk * KC);
+            if (new_chunk) store_x(rx, nchunk & 1, nchunk * KC);
+            __syncthreads();
+            tap = ntap;
+            chunk = nchunk;
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
