@@ -84,13 +84,13 @@ def main():
             if send is None:
                 send = torch.empty(n, dtype=torch.float32, device="cuda")
                 recv = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
-            _lib.check(l.sbv2_vits_copy_pcm_device(vs.handle, C.c_void_p(send.data_ptr())))
+            pipe.fetch_to_device(send.data_ptr())
             dist.gather(send, recv, dst=0)
         else:
-            _lib.check(l.sbv2_sync(vs.handle))
+            pipe.sync()
 
     def fence():
-        _lib.check(l.sbv2_sync(vs.handle))
+        pipe.sync()
         if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
@@ -121,7 +121,7 @@ def main():
     # ---- roofline leg: one extra instrumented step, HIP events around every implicit-GEMM launch ----------------
     _lib.check(l.sbv2_prof_begin())
     pipe.run(b)
-    _lib.check(l.sbv2_sync(vs.handle))
+    pipe.sync()
     buf = C.create_string_buffer(1 << 16)
     _lib.check(l.sbv2_prof_end(buf, len(buf)))
     prof = json.loads(buf.value.decode())

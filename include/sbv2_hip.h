@@ -104,6 +104,12 @@ void sbv2_pipeline_destroy(sbv2_pipeline* p);
 int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens,
                       const int64_t* word2ph, int64_t* pcm_lens);
 
+/* The batch is cut into up to SBV2_MICROBATCHES (default 4) contiguous ranges that run on their own HIP streams, so the DeBERTa /
+ * text-side kernels of one range overlap the decoder kernels of the previous one; results are identical to one big batch. */
+int sbv2_pipeline_sync(sbv2_pipeline* p);
+/* Concatenated PCM of the last sbv2_pipeline_run in utterance order; dst_is_device != 0: dst is device memory. */
+int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int dst_is_device);
+
 /* ---- test hooks (no reference counterpart) ------------------------------------------------------------------------ */
 /* bucket(rel) for rel in [-(max_s-1), max_s-1] (transformers modeling_deberta_v2.py:57-69); host only, no GPU needed. */
 int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out);

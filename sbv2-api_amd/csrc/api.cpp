@@ -20,6 +20,13 @@ struct sbv2_vits {
 struct sbv2_pipeline {
     sbv2_bert* bert;
     sbv2_vits* vits;
+    // micro-batch contexts: context 0 is the caller's pair of handles, the others are clones (shared weights, own stream + arena)
+    std::vector<std::unique_ptr<BertModel>> bclones;
+    std::vector<std::unique_ptr<VitsModel>> vclones;
+    std::vector<int> mb_first, mb_count;   // utterance ranges of the last run
+    BertModel& bm(int i) { return i == 0 ? *bert->m : *bclones[i - 1]; }
+    VitsModel& vm(int i) { return i == 0 ? *vits->m : *vclones[i - 1]; }
+    int contexts() const { return 1 + (int)vclones.size(); }
 };
 
 #define API_BEGIN try {
@@ -248,21 +255,27 @@ int sbv2_pipeline_create(sbv2_bert* bert, sbv2_vits* vits, sbv2_pipeline** out) 
     SBV2_REQUIRE(bert && vits && out, "bad arguments");
     SBV2_REQUIRE(bert->m->device() == vits->m->device(), "bert and vits handles live on different devices");
     SBV2_REQUIRE(bert->m->cfg().hidden == vits->m->cfg().bert_dim, "DeBERTa hidden size does not match the VITS bert_proj input");
-    *out = new sbv2_pipeline{bert, vits};
+    std::unique_ptr<sbv2_pipeline> p(new sbv2_pipeline);
+    p->bert = bert;
+    p->vits = vits;
+    // micro-batch contexts.  Default 1: measured on MI355X (round 1) the DeBERTa / text / flow chains are latency bound (small grids),
+    // so cutting the batch multiplies their cost (4 contexts: 220 ms/step vs 186) instead of hiding it behind the decoder.
+    int k = 1;
+    if (const char* e = getenv("SBV2_MICROBATCHES")) k = std::max(1, std::min(16, atoi(e)));
+    for (int i = 1; i < k; ++i) {
+        p->bclones.emplace_back(bert->m->clone());
+        p->vclones.emplace_back(vits->m->clone());
+    }
+    *out = p.release();
     API_END
 }
 void sbv2_pipeline_destroy(sbv2_pipeline* p) { delete p; }
 
-int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens, const int64_t* word2ph,
-                      int64_t* pcm_lens) {
-    API_BEGIN
-    SBV2_REQUIRE(p && token_ids && s_lens && word2ph && pcm_lens, "bad arguments");
-    VitsBatch v = to_batch(batch);
-    BertModel& bm = *p->bert->m;
-    VitsModel& vm = *p->vits->m;
-    HIP_CHECK(hipStreamSynchronize(vm.stream()));  // the previous batch may still be reading the DeBERTa output plane
+// One micro-batch on one context: bert::predict -> word2ph repeat (tts_util.rs:129-154) -> model::synthesize
+static void pipeline_run_one(BertModel& bm, VitsModel& vm, VitsBatch v, const int64_t* token_ids, const int64_t* s_lens,
+                             const int64_t* word2ph) {
+    HIP_CHECK(hipStreamSynchronize(vm.stream()));  // this context's previous batch may still be reading the DeBERTa output plane
     bm.forward(v.n, token_ids, nullptr, s_lens);
-    // tts_util.rs:129-154: token i's feature vector is repeated word2ph[i] times along the text axis
     const SegLayout& bl = bm.layout();
     std::vector<int> map;
     int64_t e = 0;
@@ -279,11 +292,86 @@ int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* 
     v.bert_host = nullptr;
     v.bert_dev = &bm.out();
     v.bert_map = map.data();
-    // the two models run on their own streams: order them
-    // (an event dependency inside forward(), not a host wait: the VITS host-side packing overlaps the DeBERTa kernels)
+    // the two models run on their own streams: an event dependency inside forward(), not a host wait
     v.after_stream = bm.stream();
     vm.forward(v);
-    for (int i = 0; i < v.n; ++i) pcm_lens[i] = vm.pcm_lens()[i];
+}
+
+int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens, const int64_t* word2ph,
+                      int64_t* pcm_lens) {
+    API_BEGIN
+    SBV2_REQUIRE(p && token_ids && s_lens && word2ph && pcm_lens, "bad arguments");
+    const VitsBatch all = to_batch(batch);
+    // Micro-batch pipelining: the batch is cut into contiguous, cost-balanced ranges, each on its own context (stream + workspace).
+    // The host issues them one after the other; the DeBERTa / text-side kernels of range i+1 (small grids, latency bound) then run
+    // beside the decoder kernels of range i.  Every utterance's result is independent of the batch it is in (tests assert
+    // bit equality), so the cut does not change the output.
+    const int k = std::min(p->contexts(), all.n);
+    std::vector<int64_t> cost(all.n);
+    int64_t total = 0;
+    for (int u = 0; u < all.n; ++u) total += (cost[u] = all.t_lens[u]);
+    p->mb_first.assign(k, 0);
+    p->mb_count.assign(k, 0);
+    {
+        int u = 0;
+        int64_t acc = 0;
+        for (int j = 0; j < k; ++j) {
+            p->mb_first[j] = u;
+            const int64_t target = total * (j + 1) / k;
+            while (u < all.n && (acc < target || p->mb_count[j] == 0) && all.n - u > k - 1 - j) {
+                acc += cost[u];
+                ++u;
+                ++p->mb_count[j];
+            }
+        }
+        p->mb_count[k - 1] += all.n - u;   // remainder
+    }
+    std::vector<int64_t> t_off(all.n + 1, 0), s_off(all.n + 1, 0);
+    for (int u = 0; u < all.n; ++u) {
+        t_off[u + 1] = t_off[u] + all.t_lens[u];
+        s_off[u + 1] = s_off[u] + s_lens[u];
+    }
+    for (int j = 0; j < k; ++j) {
+        const int f = p->mb_first[j], c = p->mb_count[j];
+        if (c == 0) continue;
+        VitsBatch v = all;
+        v.n = c;
+        v.t_lens = all.t_lens + f;
+        v.phones = all.phones + t_off[f];
+        v.tones = all.tones + t_off[f];
+        v.langs = all.langs + t_off[f];
+        v.sids = all.sids + f;
+        v.styles = all.styles + (int64_t)f * p->vits->m->cfg().style_dim;
+        v.forced_durations = all.forced_durations ? all.forced_durations + t_off[f] : nullptr;
+        v.utt0 = f;   // noise streams are keyed by the utterance's index in the whole batch
+        pipeline_run_one(p->bm(j), p->vm(j), v, token_ids + s_off[f], s_lens + f, word2ph + s_off[f]);
+        for (int i = 0; i < c; ++i) pcm_lens[f + i] = p->vm(j).pcm_lens()[i];
+    }
+    API_END
+}
+
+int sbv2_pipeline_sync(sbv2_pipeline* p) {
+    API_BEGIN
+    SBV2_REQUIRE(p, "bad arguments");
+    for (size_t j = 0; j < p->mb_count.size(); ++j)
+        if (p->mb_count[j]) HIP_CHECK(hipStreamSynchronize(p->vm((int)j).stream()));
+    API_END
+}
+
+// Concatenated PCM of the last run in utterance order; `device` != 0: dst is device memory (e.g. the RCCL send buffer)
+int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int device) {
+    API_BEGIN
+    SBV2_REQUIRE(p && dst, "bad arguments");
+    int64_t off = 0;
+    for (size_t j = 0; j < p->mb_count.size(); ++j) {
+        if (!p->mb_count[j]) continue;
+        VitsModel& vm = p->vm((int)j);
+        HIP_CHECK(hipMemcpyAsync(dst + off, vm.pcm_device(), sizeof(float) * (size_t)vm.pcm_total(),
+                                 device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, vm.stream()));
+        off += vm.pcm_total();
+    }
+    for (size_t j = 0; j < p->mb_count.size(); ++j)
+        if (p->mb_count[j]) HIP_CHECK(hipStreamSynchronize(p->vm((int)j).stream()));
     API_END
 }
 

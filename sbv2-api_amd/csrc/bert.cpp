@@ -115,6 +115,16 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+BertModel* BertModel::clone() const {
+    HIP_CHECK(hipSetDevice(device_));
+    BertModel* c = new BertModel(*this);   // shares ws_ (device weights); Arena copies are empty
+    c->stream_ = nullptr;
+    HIP_CHECK(hipStreamCreate(&c->stream_));
+    c->out_ = Plane{};
+    c->layout_ = SegLayout{};
+    return c;
+}
+
 BertModel::~BertModel() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamDestroy(stream_);

@@ -50,6 +50,9 @@ class Arena {
     struct Mark {
         size_t chunk, off;
     };
+    Arena() = default;
+    Arena(const Arena&) {}   // a copied model context starts with an empty workspace of its own
+    Arena& operator=(const Arena&) = delete;
     ~Arena() { release(); }
     // Start a new forward pass: keeps the memory, consolidates into one chunk if the last pass had to grow.
     void reset();

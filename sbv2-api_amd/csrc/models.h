@@ -96,6 +96,8 @@ class BertModel {
   public:
     BertModel(const Blob& blob, int device);
     ~BertModel();
+    // A second execution context on the same weights: own stream and workspace (micro-batch pipelining)
+    BertModel* clone() const;
     int device() const { return device_; }
     const BertConfig& cfg() const { return cfg_; }
     // ids/mask concatenated over utterances; result stays on the device (out_, layout_)
@@ -114,7 +116,7 @@ class BertModel {
     };
     int device_;
     BertConfig cfg_;
-    std::unique_ptr<WeightStore> ws_;
+    std::shared_ptr<WeightStore> ws_;
     float *emb_, *emb_g_, *emb_b_;
     std::vector<Layer> layers_;
     Arena arena_;
@@ -152,6 +154,7 @@ struct VitsBatch {
     float sdp_ratio = 0.f, length_scale = 1.f, noise_scale = 0.f, noise_scale_w = 0.f;
     uint64_t seed = 0;
     const int64_t* forced_durations = nullptr;  // concatenated, optional
+    int utt0 = 0;                               // index of the first utterance in the caller's batch (noise stream keys)
     hipStream_t after_stream = nullptr;         // when set, the forward's kernels wait for the work queued on this stream
 };
 
@@ -159,6 +162,8 @@ class VitsModel {
   public:
     VitsModel(const Blob& blob, int device);
     ~VitsModel();
+    // A second execution context on the same weights: own stream and workspace (micro-batch pipelining)
+    VitsModel* clone() const;
     int device() const { return device_; }
     const VitsConfig& cfg() const { return cfg_; }
     void forward(const VitsBatch& b);
@@ -249,7 +254,7 @@ class VitsModel {
 
     int device_;
     VitsConfig cfg_;
-    std::unique_ptr<WeightStore> ws_;
+    std::shared_ptr<WeightStore> ws_;
     hipStream_t stream_ = nullptr;
     Arena arena_, keep_;
     // weights

@@ -246,6 +246,20 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     if (dec_mode_) load_decoder_cl(blob);
 }
 
+VitsModel* VitsModel::clone() const {
+    HIP_CHECK(hipSetDevice(device_));
+    VitsModel* c = new VitsModel(*this);   // shares ws_ (device weights); Arena copies are empty
+    c->stream_ = nullptr;
+    HIP_CHECK(hipStreamCreate(&c->stream_));
+    c->pcm_ = nullptr;
+    c->pcm_total_ = 0;
+    c->pcm_lens_.clear();
+    c->pcm_offs_.clear();
+    c->traces_.clear();
+    c->trace_ = false;
+    return c;
+}
+
 VitsModel::~VitsModel() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -414,6 +428,7 @@ void VitsModel::forward(const VitsBatch& b) {
     }
     Arena& ar = arena_;
     const int n = b.n, H = cfg_.hidden, I = cfg_.inter;
+    const uint64_t seed = b.seed + (uint64_t)(2 * b.utt0) * 0x9E3779B97F4A7C15ull;   // noise_key(seed, utt0 + u, stream)
     std::vector<int> T(n);
     int64_t total_t = 0;
     for (int u = 0; u < n; ++u) {
@@ -524,7 +539,7 @@ void VitsModel::forward(const VitsBatch& b) {
     conv_plain(sdp_proj_, XSd, COND, 1, 0, tl.d_mask, 1, stream_);
     float* z0 = Z.p;
     float* z1 = Z.p + Z.ld;
-    noise_fill(Z.p, Z.ld, 2, tl.d_seg_of, tl.d_start, tl.d_len, Lt, b.seed, 0, b.noise_scale_w, stream_);
+    noise_fill(Z.p, Z.ld, 2, tl.d_seg_of, tl.d_start, tl.d_len, Lt, seed, 0, b.noise_scale_w, stream_);
     const float inv_sqrt_f = 1.0f / std::sqrt((float)H);
     for (int i = (int)sdp_cf_.size() - 1; i >= 0; --i) {
         const ConvFlow& cf = sdp_cf_[i];
@@ -581,7 +596,7 @@ void VitsModel::forward(const VitsBatch& b) {
 
     // ---- alignment expansion + prior sample ---------------------------------------------------------------
     Plane ZA = ar.plane(I, Lf), ZB = ar.plane(I, Lf);
-    expand_frames(m_p, logs_p, d_tok, fl.d_seg_of, fl.d_start, fl.d_len, b.seed, b.noise_scale, nullptr, 0, ZA, stream_);
+    expand_frames(m_p, logs_p, d_tok, fl.d_seg_of, fl.d_start, fl.d_len, seed, b.noise_scale, nullptr, 0, ZA, stream_);
     trace("z_p", ZA, fl);
 
     // ---- TransformerCouplingBlock, reverse ----------------------------------------------------------------

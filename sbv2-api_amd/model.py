@@ -176,10 +176,17 @@ class Pipeline:
                                            b.w2p.ctypes.data_as(i64p), b.lens.ctypes.data_as(i64p)))
         return b.lens
 
+    def sync(self):
+        check(_lib.lib().sbv2_pipeline_sync(self.h))
+
     def fetch(self, b):
         pcm = np.empty(int(b.lens.sum()), np.float32)
-        check(_lib.lib().sbv2_vits_fetch_pcm(self.vits.handle, pcm.ctypes.data_as(f32p)))
+        check(_lib.lib().sbv2_pipeline_fetch_pcm(self.h, pcm.ctypes.data_as(C.c_void_p), 0))
         return np.split(pcm, np.cumsum(b.lens)[:-1])
+
+    def fetch_to_device(self, device_ptr: int):
+        """Concatenated PCM of the last run -> caller-owned device memory (e.g. the RCCL gather's send buffer)."""
+        check(_lib.lib().sbv2_pipeline_fetch_pcm(self.h, C.c_void_p(device_ptr), 1))
 
     def close(self):
         if self.h:
