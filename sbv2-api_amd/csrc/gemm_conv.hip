@@ -438,6 +438,12 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         return launch_cfg<32, 1, 1, 1, 4, 16>(kp, Mx, Nx, stream);
     }
     // measured on MI355X: 64-row tiles (81 VGPRs, 48 KB LDS -> 3 workgroups per CU) beat 128x256 (1-2 per CU) by 20-30 %
+    if (p.ntaps == 1) {
+        // 1x1 products (measured on the DeBERTa / flow shapes with the two-deep prefetch): 64x128 beats 64x256, and 64x64 wins when
+        // the grid would otherwise be under two workgroups per CU
+        if (blocks(64, 128) >= 512) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+        return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
+    }
     if (blocks(64, 256) >= 512) return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
     if (blocks(64, 128) >= 256) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
     return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
