@@ -185,4 +185,20 @@ struct ConvClParams {
 };
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
 
+// One fused ResBlock1 step y' = beta * (conv2(lrelu(conv1(lrelu(y), dil) + b1)) + b2 + y) on a channels-last plane (respair_cl.hip)
+struct ResPairParams {
+    const float* X = nullptr;   // y  [N][C]
+    float* Y = nullptr;         // y' [N][C] (may be a different buffer; += when accumulate)
+    const void* W1 = nullptr;   // conv_cl fragment blocks (tm = 1)
+    const void* W2 = nullptr;
+    const float* b1 = nullptr;
+    const float* b2 = nullptr;
+    int C = 0, N = 0, k = 1, dil = 1, split = 1;
+    float slope = 0.1f, beta = 1.0f;
+    int accumulate = 0;
+    const unsigned char* mask = nullptr;
+    int mask_div = 1;
+};
+void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
+
 }  // namespace sbv2

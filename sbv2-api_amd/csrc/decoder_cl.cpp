@@ -211,14 +211,34 @@ void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
             const int nd = (int)rb.dil.size();
             for (int q = 0; q < nd; ++q) {
                 const int d = rb.dil[q];
-                conv_cl(rb.c1[q], y, C, (int)Lo, T1, C, (int)Lo, d, d * (rb.k - 1) / 2, fl.d_mask, U, 0.1f, nullptr, 0, 1.0f, 0);
-                if (q + 1 < nd) {
-                    float* yn = (y == YA) ? YB : YA;
-                    conv_cl(rb.c2[q], T1, C, (int)Lo, yn, C, (int)Lo, 1, (rb.k - 1) / 2, fl.d_mask, U, 0.1f, y, C, 1.0f, 0);
-                    y = yn;
+                const bool last = q + 1 == nd;
+                float* yn = last ? XS : ((y == YA) ? YB : YA);
+                if (fuse_pairs_ && C <= 32) {
+                    // narrow stages are HBM bound: conv1 -> conv2 fused, the intermediate stays in LDS (respair_cl.hip)
+                    ResPairParams rp;
+                    rp.X = y;
+                    rp.Y = yn;
+                    rp.W1 = rb.c1[q].w;
+                    rp.W2 = rb.c2[q].w;
+                    rp.b1 = rb.c1[q].bias;
+                    rp.b2 = rb.c2[q].bias;
+                    rp.C = C;
+                    rp.N = (int)Lo;
+                    rp.k = rb.k;
+                    rp.dil = d;
+                    rp.split = dec_mode_ == 1;
+                    rp.slope = 0.1f;
+                    rp.beta = last ? 1.0f / nk : 1.0f;
+                    rp.accumulate = last && j > 0;
+                    rp.mask = fl.d_mask;
+                    rp.mask_div = U;
+                    launch_respair_cl(rp, stream_);
                 } else {
-                    conv_cl(rb.c2[q], T1, C, (int)Lo, XS, C, (int)Lo, 1, (rb.k - 1) / 2, fl.d_mask, U, 0.1f, y, C, 1.0f / nk, j > 0);
+                    conv_cl(rb.c1[q], y, C, (int)Lo, T1, C, (int)Lo, d, d * (rb.k - 1) / 2, fl.d_mask, U, 0.1f, nullptr, 0, 1.0f, 0);
+                    conv_cl(rb.c2[q], T1, C, (int)Lo, yn, C, (int)Lo, 1, (rb.k - 1) / 2, fl.d_mask, U, 0.1f, y, C, last ? 1.0f / nk : 1.0f,
+                            last && j > 0);
                 }
+                y = yn;
             }
         }
         ar.rewind(mk);

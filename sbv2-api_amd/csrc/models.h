@@ -273,6 +273,7 @@ class VitsModel {
     float* dec_cond_vec_ = nullptr;  // cond(g) per utterance of the running forward
     int dec_post_k_ = 7;
     std::vector<Stage> stages_;
+    bool fuse_pairs_ = true;  // SBV2_FUSE_PAIRS=0 disables the fused ResBlock step of the 16/32-channel stages
     int dec_mode_ = 0;  // 0 = exact f32 MFMA (k-major), 1 = split-bf16 (f32-grade), 2 = plain bf16
     ClConv cl_pre_;
     std::vector<ClStage> cl_stages_;

@@ -1,0 +1,287 @@
+// One HiFi-GAN ResBlock1 step fused into one launch for the narrow decoder stages (C <= 32 channels, channels-last planes):
+//
+//     y' = beta * ( conv2( lrelu( conv1( lrelu(y), dilation d ) + b1 ) ) + b2 + y )  [+ previous contents]  (then column mask)
+//
+// (HifiGanResidualBlock.forward, transformers modeling_vits.py:455-463 = modules.ResBlock1 upstream.)
+// Unfused, this is two launches that move 5 planes through HBM (read y, write t, read t, read y again, write y'); the PMC pass
+// showed the 16/32-channel launches at 3.2 TB/s, i.e. bandwidth bound.  Fused, the intermediate t never leaves the CU: a
+// workgroup computes t for 256 positions into LDS (already leaky-ReLU'ed, masked and split into bf16 hi/lo: exactly the B-operand
+// window conv2 needs), then conv2 for the 256 - (k-1) positions whose taps it covers.  Arithmetic, operand split and summation
+// order are those of conv_cl.hip, so results are bit-identical to the two-launch path.
+#include <type_traits>
+
+#include "common.h"
+
+namespace sbv2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kRpThreads = 256;
+constexpr int kRpNT = 256;        // positions of the intermediate per workgroup
+constexpr int kRpWin2Rows = 272;  // 256 + tap overrun of the last wave (read for discarded columns only)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void rp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rp_static_for<I + 1, N>(f);
+    }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairParams p) {
+    constexpr int PARTS = SPLIT ? 2 : 1;
+    constexpr int TN = 2;
+    constexpr int MAXW = (kMaxTaps * PARTS * 64 + kRpThreads - 1) / kRpThreads;
+    constexpr int NX = ((kRpNT + 64) * 4 + kRpThreads - 1) / kRpThreads;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntaps = p.k, C = p.C, nchunks = C >> 4;
+    const int h2 = (p.k - 1) / 2, h1 = p.dil * (p.k - 1) / 2;
+    const int rows1 = kRpNT + 2 * h1;
+    const int wbytes = ntaps * PARTS * 1024;
+    char* wsm = smem;
+    char* x1_hi = smem + wbytes;
+    char* x1_lo = x1_hi + rows1 * 32;
+    char* x2_hi = x1_hi + rows1 * 32 * PARTS;                 // [chunk][kRpWin2Rows][32 B]
+    char* x2_lo = x2_hi + nchunks * kRpWin2Rows * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lh = lane >> 5;
+    const int wn0 = wave * 64;
+    const int nto = kRpNT - 2 * h2;                 // outputs per workgroup
+    const int n0 = blockIdx.x * nto;                // first output position
+    const int t0 = n0 - h2;                         // first position of the intermediate
+    const int wstart = t0 - h1;                     // first row of the conv1 window
+    const int NB = p.N;
+    const int nwf4 = ntaps * PARTS * 64;
+    const int nxf4 = rows1 * 4;
+
+    f32x16 acc[TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    };
+    zero_acc();
+
+    f32x4v rw[MAXW];
+    f32x4v rx[NX], rx1[NX];
+    auto load_w = [&](const void* W, int chunk) {
+        const f32x4v* src = reinterpret_cast<const f32x4v*>(W) + (int64_t)chunk * ntaps * PARTS * 64;   // nmt == 1
+        rp_static_for<0, MAXW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            rw[i] = src[min(tid + i * kRpThreads, nwf4 - 1)];
+        });
+    };
+    auto store_w = [&]() {
+        rp_static_for<0, MAXW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * kRpThreads;
+            if (idx < nwf4) reinterpret_cast<f32x4v*>(wsm)[idx] = rw[i];
+        });
+    };
+    // both 16-channel chunks of the conv1 window are requested at once (one 128-byte line per position when C == 32)
+    auto load_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = min(tid + i * kRpThreads, nxf4 - 1);
+            const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
+            const float* src = p.X + (int64_t)pos * C + (idx & 3) * 4;
+            rx[i] = *reinterpret_cast<const f32x4v*>(src);
+            rx1[i] = *reinterpret_cast<const f32x4v*>(nchunks > 1 ? src + 16 : src);
+        }
+    };
+    auto store_x = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * kRpThreads;
+            if (idx < nxf4) {
+                const int row = idx >> 2, q = idx & 3;
+                const int pos = wstart + row;
+                f32x4v v = chunk ? rx1[i] : rx[i];
+                if (pos < 0 || pos >= NB) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
+                const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4*>(x1_hi + off) = h;
+                if (SPLIT) {
+                    bf16x4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
+                    *reinterpret_cast<bf16x4*>(x1_lo + off) = l;
+                }
+            }
+        }
+    };
+    auto mfma_chunk = [&](const char* bhi, const char* blo, int tap_stride) {
+        for (int tap = 0; tap < ntaps; ++tap) {
+            bf16x8 bh[TN], bl[TN], ah, al;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 32 + lcol + tap * tap_stride;
+                const int off = row * 32 + (((lh ^ (row >> 3)) & 1) << 4);
+                bh[j] = *reinterpret_cast<const bf16x8*>(bhi + off);
+                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(blo + off);
+            }
+            const char* blk = wsm + (tap * PARTS) * 1024 + lane * 16;
+            ah = *reinterpret_cast<const bf16x8*>(blk);
+            if (SPLIT) al = *reinterpret_cast<const bf16x8*>(blk + 1024);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (SPLIT) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- phase 1: t = lrelu(conv1(lrelu(y)) + b1) on positions [t0, t0 + 256) -> LDS ----------------------------------------
+    load_w(p.W1, 0);
+    load_x();
+    store_w();
+    store_x(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        load_w(more ? p.W1 : p.W2, more ? chunk + 1 : 0);   // the next weights: conv1's next chunk, then conv2's first
+        mfma_chunk(x1_hi, x1_lo, p.dil);
+        __syncthreads();
+        if (more) {
+            store_w();
+            store_x(chunk + 1);
+            __syncthreads();
+        }
+    }
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = 8 * q + 4 * lh;
+            if (co >= C) continue;
+            const f32x4v b4 = *reinterpret_cast<const f32x4v*>(p.b1 + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 32 + lcol;
+                const int pos = t0 + row;
+                bool keep = pos >= 0 && pos < NB;
+                if (keep && p.mask) keep = p.mask[pos / p.mask_div] != 0;
+                f32x4v v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[j][4 * q + e] + b4[e];
+                    t = t >= 0.f ? t : t * p.slope;
+                    v[e] = keep ? t : 0.f;
+                }
+                const int off = (co >> 4) * (kRpWin2Rows * 32) + row * 32 + (((((co >> 3) & 1) ^ (row >> 3)) & 1) << 4) + ((co & 7) << 1);
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4*>(x2_hi + off) = h;
+                if (SPLIT) {
+                    bf16x4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
+                    *reinterpret_cast<bf16x4*>(x2_lo + off) = l;
+                }
+            }
+        }
+    }
+    store_w();   // conv2 chunk 0 (requested before the last conv1 MFMA block)
+    zero_acc();
+    __syncthreads();
+
+    // ---- phase 2: conv2 over the LDS-resident intermediate --------------------------------------------------------------------
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) load_w(p.W2, chunk + 1);
+        mfma_chunk(x2_hi + chunk * (kRpWin2Rows * 32), x2_lo + chunk * (kRpWin2Rows * 32), 1);
+        __syncthreads();
+        if (more) {
+            store_w();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: + b2 + y, beta, accumulate, mask; full 128-byte lines through a per-wave LDS transpose ---------------------
+    float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4v v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+            *reinterpret_cast<f32x4v*>(tile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
+        }
+    const int c4 = (lane & 7) * 4;
+    f32x4v b4 = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C) b4 = *reinterpret_cast<const f32x4v*>(p.b2 + c4);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int o = wn0 + row;          // output index inside the workgroup's range
+        const int64_t pos = (int64_t)n0 + o;
+        const f32x4v a = *reinterpret_cast<const f32x4v*>(tile + row * 36 + c4);
+        if (o >= nto || pos >= NB || c4 >= C) continue;
+        const f32x4v r = *reinterpret_cast<const f32x4v*>(p.X + pos * C + c4);
+        f32x4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (a[e] + b4[e] + r[e]) * p.beta;
+        f32x4v* dst = reinterpret_cast<f32x4v*>(p.Y + pos * C + c4);
+        if (p.accumulate) {
+            const f32x4v old = *dst;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += old[e];
+        }
+        if (p.mask && !p.mask[pos / p.mask_div]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+        *dst = v;
+    }
+}
+
+template <bool SPLIT>
+static void launch_rp(const ResPairParams& p, hipStream_t stream) {
+    constexpr int PARTS = SPLIT ? 2 : 1;
+    const int h1 = p.dil * (p.k - 1) / 2, h2 = (p.k - 1) / 2;
+    const int rows1 = kRpNT + 2 * h1;
+    size_t lds = (size_t)p.k * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
+    lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));
+    SBV2_REQUIRE(lds <= 160 * 1024, "respair: LDS budget exceeded");
+    auto kern = respair_cl_kernel<SPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int nto = kRpNT - 2 * h2;
+    dim3 grid((p.N + nto - 1) / nto);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = conv_prof_active();
+    if (prof) {
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kRpThreads), lds, stream, p);
+    HIP_CHECK(hipGetLastError());
+    if (prof) {
+        HIP_CHECK(hipEventRecord(e1, stream));
+        conv_prof_add(16, 2.0 * 2.0 * p.C * (double)p.N * p.C * p.k, e0, e1);
+    }
+}
+
+void launch_respair_cl(const ResPairParams& p, hipStream_t stream) {
+    SBV2_REQUIRE(p.C == 16 || p.C == 32, "respair: only the 16- and 32-channel stages are fused");
+    SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
+    SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
+    if (p.N <= 0) return;
+    if (p.split) launch_rp<true>(p, stream);
+    else launch_rp<false>(p, stream);
+}
+
+}  // namespace sbv2

@@ -243,6 +243,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         else SBV2_REQUIRE(v.empty(), "SBV2_DECODER must be f32, bf16x3 or bf16");
         SBV2_REQUIRE(dec_mode_ == 0 || cl_ok, "SBV2_DECODER: the bf16 MFMA decoder needs channel counts that are multiples of 16");
     }
+    if (const char* f = getenv("SBV2_FUSE_PAIRS")) fuse_pairs_ = atoi(f) != 0;
     if (dec_mode_) load_decoder_cl(blob);
 }
 
