@@ -52,9 +52,10 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     const int lcol = lane & 31, lh = lane >> 5;
     const int wn0 = wave * 64;
     const int nto = kRpNT - 2 * h2;                 // outputs per workgroup
-    const int n0 = blockIdx.x * nto;                // first output position
-    const int t0 = n0 - h2;                         // first position of the intermediate
-    const int wstart = t0 - h1;                     // first row of the conv1 window
+    const int ntiles = (p.N + nto - 1) / nto;
+    int n0 = blockIdx.x * nto;                      // first output position (persistent: tile += gridDim.x)
+    int t0 = n0 - h2;                               // first position of the intermediate
+    int wstart = t0 - h1;                           // first row of the conv1 window
     const int NB = p.N;
     const int nwf4 = ntaps * PARTS * 64;
     const int nxf4 = rows1 * 4;
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     // ---- phase 1: t = lrelu(conv1(lrelu(y)) + b1) on positions [t0, t0 + 256) -> LDS ----------------------------------------
     load_w(p.W1, 0);
     load_x();
+  for (int tile = blockIdx.x;; tile += gridDim.x) {
+    const bool next_tile = tile + (int)gridDim.x < ntiles;
     store_w();
     store_x(0);
     __syncthreads();
@@ -196,12 +199,21 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     }
     store_w();   // conv2 chunk 0 (requested before the last conv1 MFMA block)
     zero_acc();
+    const int n0_cur = n0;
+    if (next_tile) {
+        // cross-tile prefetch: the next tile's conv1 window is requested now and lands during conv2 + the epilogue of this tile
+        n0 += gridDim.x * nto;
+        t0 = n0 - h2;
+        wstart = t0 - h1;
+        load_x();
+    }
     __syncthreads();
 
     // ---- phase 2: conv2 over the LDS-resident intermediate --------------------------------------------------------------------
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
         if (more) load_w(p.W2, chunk + 1);
+        else if (next_tile) load_w(p.W1, 0);
         mfma_chunk(x2_hi + chunk * (kRpWin2Rows * 32), x2_lo + chunk * (kRpWin2Rows * 32), 1);
         __syncthreads();
         if (more) {
@@ -211,13 +223,13 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     }
 
     // ---- epilogue: + b2 + y, beta, accumulate, mask; full 128-byte lines through a per-wave LDS transpose ---------------------
-    float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
+    float* ttile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4v v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-            *reinterpret_cast<f32x4v*>(tile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
+            *reinterpret_cast<f32x4v*>(ttile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
         }
     const int c4 = (lane & 7) * 4;
     f32x4v b4 = {0.f, 0.f, 0.f, 0.f};
@@ -226,8 +238,8 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3);
         const int o = wn0 + row;          // output index inside the workgroup's range
-        const int64_t pos = (int64_t)n0 + o;
-        const f32x4v a = *reinterpret_cast<const f32x4v*>(tile + row * 36 + c4);
+        const int64_t pos = (int64_t)n0_cur + o;
+        const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * 36 + c4);
         if (o >= nto || pos >= NB || c4 >= C) continue;
         const f32x4v r = *reinterpret_cast<const f32x4v*>(p.X + pos * C + c4);
         f32x4v v;
@@ -242,6 +254,10 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
         if (p.mask && !p.mask[pos / p.mask_div]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
         *dst = v;
     }
+    if (!next_tile) break;
+    zero_acc();
+    __syncthreads();   // the transpose tiles overlap the staging regions
+  }
 }
 
 template <bool SPLIT>
@@ -259,7 +275,11 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nto = kRpNT - 2 * h2;
-    dim3 grid((p.N + nto - 1) / nto);
+    int per_cu = 1;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kRpThreads, lds));
+    per_cu = std::max(1, std::min(per_cu, 4));
+    const int ntiles = (p.N + nto - 1) / nto;
+    dim3 grid(std::min(ntiles, 256 * per_cu));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = conv_prof_active();
     if (prof) {
