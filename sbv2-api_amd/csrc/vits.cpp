@@ -163,6 +163,9 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     }
     ws_.reset(new WeightStore(blob, gemm_parts));
     WeightStore& w = *ws_;
+    // The text side decides the INTEGER durations (ceil(exp(logw) * length_scale)): text encoder and both duration predictors always
+    // run on the exact-f32 kernels, whatever SBV2_GEMM says; a 1e-5 relative error there flips ~1 duration per 10^4 symbols.
+    w.set_cl_parts(0);
     emb_g_ = w.tensor("emb_g.weight");
     emb_ = w.tensor("enc_p.emb.weight");
     tone_emb_ = w.tensor("enc_p.tone_emb.weight");
@@ -193,6 +196,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         SBV2_REQUIRE(cf.proj.cout == 3 * cfg_.sdp_bins - 1, "ConvFlow projection size");
         sdp_cf_.push_back(cf);
     }
+    w.set_cl_parts(gemm_parts);   // the flow only shapes the (continuous) latent: split-bf16 for its k = 5 FFN convs
     for (int i = 0; i < cfg_.flow_n; ++i) {
         const std::string p = "flow.flows." + std::to_string(2 * i) + ".";
         Coupling c;
