@@ -66,8 +66,17 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn0 = wave * 64;
-    const int m0 = blockIdx.y * (TM * 32);
-    const int n0 = blockIdx.x * kClNT;
+    // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2.  The gy row tiles
+    // of one position tile read the SAME activation window, so they are given ids that differ by 8 (same XCD, back to back) and
+    // consecutive position tiles of an XCD are neighbours (shared halo).  Speed only: any placement is correct.
+    const int gy = kp.nmt / TM;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int by = slot % gy;
+    const int bx = (slot / gy) * 8 + xcd;
+    const int m0 = by * (TM * 32);
+    const int n0 = bx * kClNT;
+    if (n0 >= p.N) return;
     const int M = p.M, N = p.N, NB = p.NB, ntaps = p.ntaps;
     const int nchunks = (p.K + 15) >> 4;
     const int wstart = n0 + kp.wshift0;
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     f32x4v rx1[NX];   // rx1 = the following odd chunk)
     // branch-free loads (clamped, always-valid addresses); see gemm_conv.hip for why
     auto load_w = [&](int chunk) {
-        const f32x4v* src = reinterpret_cast<const f32x4v*>(p.W) + ((int64_t)chunk * kp.nmt + blockIdx.y * TM) * ntaps * PARTS * 64;
+        const f32x4v* src = reinterpret_cast<const f32x4v*>(p.W) + ((int64_t)chunk * kp.nmt + by * TM) * ntaps * PARTS * 64;
         static_for<0, MAXW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             rw[i] = src[min(tid + i * kClThreads, nwf4 - 1)];
@@ -363,7 +372,8 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((p.N + kClNT - 1) / kClNT, kp.nmt / TM);
+    const int ntx = round_up((p.N + kClNT - 1) / kClNT, 8);   // padded so that the (xcd, slot) <-> (tile, row tile) map is a bijection
+    dim3 grid(ntx * (kp.nmt / TM));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = conv_prof_active();
     if (prof) {

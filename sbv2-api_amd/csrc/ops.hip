@@ -260,17 +260,18 @@ void vits_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, cons
                        pwin);
 }
 
-__global__ __launch_bounds__(64) void k_vits_relv_add(const AttnGroup* groups, float* ctx, int ldc, int dk, const float* erv, int w,
-                                                       const float* pwin) {
+__global__ __launch_bounds__(256) void k_vits_relv_add(const AttnGroup* groups, float* ctx, int ldc, int dk, const float* erv, int w,
+                                                        const float* pwin) {
     const AttnGroup g = groups[blockIdx.y];
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;   // 4 channel slices per 64 columns
     if (i >= g.T) return;
     const float* pw = pwin + g.aux_off;
     float p[2 * kMaxWin + 1];
 #pragma unroll
     for (int r = 0; r < 2 * kMaxWin + 1; ++r) p[r] = (r < 2 * w + 1) ? pw[(size_t)r * g.lds + i] : 0.f;
     float* c = ctx + g.qk_off + i;
-    for (int d = 0; d < dk; ++d) {
+    for (int d = ty; d < dk; d += 4) {
         float a = 0.f;
 #pragma unroll
         for (int r = 0; r < 2 * kMaxWin + 1; ++r)
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(64) void k_vits_relv_add(const AttnGroup* groups, f
 }
 void vits_relv_add(const AttnGroup* groups, int ngroups, int maxT, float* ctx, int ldc, int dk, const float* erv, int window,
                    const float* pwin, hipStream_t s) {
-    hipLaunchKernelGGL(k_vits_relv_add, dim3((maxT + 63) / 64, ngroups), dim3(64), 0, s, groups, ctx, ldc, dk, erv, window, pwin);
+    hipLaunchKernelGGL(k_vits_relv_add, dim3((maxT + 63) / 64, ngroups), dim3(256), 0, s, groups, ctx, ldc, dk, erv, window, pwin);
 }
 
 // ------------------------------------------------------------------------------------------------

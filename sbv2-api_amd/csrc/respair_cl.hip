@@ -31,7 +31,7 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool PERSIST>
 __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairParams p) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     constexpr int TN = 2;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     load_w(p.W1, 0);
     load_x();
   for (int tile = blockIdx.x;; tile += gridDim.x) {
-    const bool next_tile = tile + (int)gridDim.x < ntiles;
+    const bool next_tile = PERSIST && tile + (int)gridDim.x < ntiles;
     store_w();
     store_x(0);
     __syncthreads();
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
   }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool PERSIST>
 static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     const int h1 = p.dil * (p.k - 1) / 2, h2 = (p.k - 1) / 2;
@@ -268,7 +268,7 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     size_t lds = (size_t)p.k * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
     lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));
     SBV2_REQUIRE(lds <= 160 * 1024, "respair: LDS budget exceeded");
-    auto kern = respair_cl_kernel<SPLIT>;
+    auto kern = respair_cl_kernel<SPLIT, PERSIST>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -279,7 +279,7 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kRpThreads, lds));
     per_cu = std::max(1, std::min(per_cu, 4));
     const int ntiles = (p.N + nto - 1) / nto;
-    dim3 grid(std::min(ntiles, 256 * per_cu));
+    dim3 grid(PERSIST ? std::min(ntiles, 256 * per_cu) : ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = conv_prof_active();
     if (prof) {
@@ -300,8 +300,13 @@ void launch_respair_cl(const ResPairParams& p, hipStream_t stream) {
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
     if (p.N <= 0) return;
-    if (p.split) launch_rp<true>(p, stream);
-    else launch_rp<false>(p, stream);
+    static const int persist = getenv("SBV2_RESPAIR_PERSIST") ? atoi(getenv("SBV2_RESPAIR_PERSIST")) : 0;
+    if (p.split) {
+        if (persist) launch_rp<true, true>(p, stream);
+        else launch_rp<true, false>(p, stream);
+    } else {
+        launch_rp<false, false>(p, stream);
+    }
 }
 
 }  // namespace sbv2
