@@ -49,6 +49,7 @@ struct ClKernelParams {
     int wshift0;  // min shift
     int wbytes;   // LDS bytes of the weight region
     int nmt;      // 32-row tiles in the packed weights (padded to a multiple of TM)
+    int sh0, sh_step;   // tap t reads window row offset sh0 + t * sh_step (tap shifts are an arithmetic progression)
     int mask_shift;
 };
 
@@ -234,33 +235,50 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             if (IN_KM) load_xk(chunk + 1);
             else if (((chunk + 1) & 1) == 0) load_x(chunk + 1);
         }
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int sh = p.shift[tap] - kp.wshift0;
+        // Software-pipelined tap loop: the LDS fragments of tap t+1 are requested before the MFMAs of tap t are issued (two register
+        // sets, static ping-pong), so a wave's LDS latency hides under its own MFMA block instead of relying on the partner wave.
+        // Tap offsets are an arithmetic progression (shift0 + tap * step): no scalar load shares the lgkm counter with the ds_reads.
+        struct Frags {
             bf16x8 bh[TN], bl[TN], ah[TM], al[TM];
+        };
+        auto load_frags = [&](Frags& f, int tap) {
+            const int sh = kp.sh0 + tap * kp.sh_step;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lcol + sh;
                 const int off = row * 32 + (((lh ^ (row >> 3)) & 1) << 4);
-                bh[j] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
-                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+                f.bh[j] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
+                if (SPLIT) f.bl[j] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const char* blk = wsm + ((i * ntaps + tap) * PARTS) * 1024 + lane * 16;
-                ah[i] = *reinterpret_cast<const bf16x8*>(blk);
-                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(blk + 1024);
+                f.ah[i] = *reinterpret_cast<const bf16x8*>(blk);
+                if (SPLIT) f.al[i] = *reinterpret_cast<const bf16x8*>(blk + 1024);
             }
+        };
+        auto mfma_frags = [&](const Frags& f) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
                 }
+        };
+        Frags fa, fb;
+        load_frags(fa, 0);
+        int tap = 0;
+        for (; tap + 2 <= ntaps; tap += 2) {
+            load_frags(fb, tap + 1);
+            mfma_frags(fa);
+            load_frags(fa, min(tap + 2, ntaps - 1));
+            mfma_frags(fb);
         }
+        if (tap < ntaps) mfma_frags(fa);
         __syncthreads();   // every wave is done reading this chunk's tiles
         if (more) {
             xchunk = chunk + 1;
@@ -423,6 +441,9 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         kp.xrows = kClNT + (smax - smin);
     }
     SBV2_REQUIRE(kp.xrows - kClNT <= kClMaxSpan, "conv_cl: tap span too large");
+    kp.sh0 = p.shift[0] - kp.wshift0;
+    kp.sh_step = p.ntaps > 1 ? p.shift[1] - p.shift[0] : 0;
+    for (int t = 1; t < p.ntaps; ++t) SBV2_REQUIRE(p.shift[t] - p.shift[t - 1] == kp.sh_step, "conv_cl: tap shifts must be an arithmetic progression");
     kp.nmt = p.nmt;
     kp.mask_shift = -1;
     if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
