@@ -76,20 +76,32 @@ def main():
     dtype = {0: "f32", 1: "bf16x3-split (decoder convs: bf16 hi/lo MFMA, f32 accumulate/storage) + f32", 2: "bf16 (decoder convs) + f32"}[dmode]
     send = recv = None
 
-    def step():
-        pipe.run(b)
+    # Steps are pipelined one deep: step n's PCM is collected (and, with N > 1, gathered to rank 0 over RCCL) right after step n+1
+    # has been enqueued, so the latency-bound DeBERTa / text / flow part of a batch overlaps the decoder of the previous one.
+    # fence() drains the pipeline: every step's work, gather included, lies inside the timed region.
+    pending = []
+
+    def collect(ticket):
         if use_dist:
             nonlocal send, recv
             n = int(b.lens.sum())
             if send is None:
                 send = torch.empty(n, dtype=torch.float32, device="cuda")
                 recv = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
-            pipe.fetch_to_device(send.data_ptr())
+            pipe.fetch_ticket_to_device(ticket, send.data_ptr())
             dist.gather(send, recv, dst=0)
         else:
-            pipe.sync()
+            pipe.wait(ticket)
+
+    def step():
+        pipe.run(b)
+        pending.append(b.ticket)
+        if len(pending) > 1:
+            collect(pending.pop(0))
 
     def fence():
+        while pending:
+            collect(pending.pop(0))
         pipe.sync()
         if use_dist:
             torch.cuda.synchronize()

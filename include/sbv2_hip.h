@@ -104,11 +104,16 @@ void sbv2_pipeline_destroy(sbv2_pipeline* p);
 int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens,
                       const int64_t* word2ph, int64_t* pcm_lens);
 
-/* The batch is cut into up to SBV2_MICROBATCHES (default 4) contiguous ranges that run on their own HIP streams, so the DeBERTa /
- * text-side kernels of one range overlap the decoder kernels of the previous one; results are identical to one big batch. */
-int sbv2_pipeline_sync(sbv2_pipeline* p);
-/* Concatenated PCM of the last sbv2_pipeline_run in utterance order; dst_is_device != 0: dst is device memory. */
-int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int dst_is_device);
+/* Calls are pipelined: call n runs on execution context n % SBV2_PIPELINE_DEPTH (default 2; own stream + workspace, shared
+ * weights) and returns once its kernels are enqueued, so the latency-bound DeBERTa / text / flow part of the next batch overlaps
+ * the HiFi-GAN kernels of this one.  The ticket (= context index) of the most recent call identifies its results until that
+ * context is used again (depth calls later). */
+int sbv2_pipeline_last_ticket(sbv2_pipeline* p);
+int sbv2_pipeline_wait(sbv2_pipeline* p, int ticket);   /* blocks until that run is complete */
+int sbv2_pipeline_sync(sbv2_pipeline* p);               /* ... until every run is complete */
+/* Concatenated PCM of a run in utterance order (waits for it); dst_is_device != 0: dst is device memory. */
+int sbv2_pipeline_fetch_pcm_ticket(sbv2_pipeline* p, int ticket, float* dst, int dst_is_device);
+int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int dst_is_device);   /* the most recent run */
 
 /* ---- test hooks (no reference counterpart) ------------------------------------------------------------------------ */
 /* bucket(rel) for rel in [-(max_s-1), max_s-1] (transformers modeling_deberta_v2.py:57-69); host only, no GPU needed. */

@@ -52,6 +52,9 @@ SYMBOLS = {
     "sbv2_pipeline_run": (C.c_int, [C.c_void_p, C.POINTER(Sbv2Batch), i64p, i64p, i64p, i64p]),
     "sbv2_pipeline_sync": (C.c_int, [C.c_void_p]),
     "sbv2_pipeline_fetch_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "sbv2_pipeline_fetch_pcm_ticket": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "sbv2_pipeline_last_ticket": (C.c_int, [C.c_void_p]),
+    "sbv2_pipeline_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "sbv2_debug_bucket_table": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "sbv2_debug_conv1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
     "sbv2_debug_conv_transpose1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

@@ -20,10 +20,11 @@ struct sbv2_vits {
 struct sbv2_pipeline {
     sbv2_bert* bert;
     sbv2_vits* vits;
-    // micro-batch contexts: context 0 is the caller's pair of handles, the others are clones (shared weights, own stream + arena)
+    // execution contexts: context 0 is the caller's pair of handles, the others are clones (shared weights, own stream + arena)
     std::vector<std::unique_ptr<BertModel>> bclones;
     std::vector<std::unique_ptr<VitsModel>> vclones;
-    std::vector<int> mb_first, mb_count;   // utterance ranges of the last run
+    int64_t calls = 0;
+    int last_ctx = 0;
     BertModel& bm(int i) { return i == 0 ? *bert->m : *bclones[i - 1]; }
     VitsModel& vm(int i) { return i == 0 ? *vits->m : *vclones[i - 1]; }
     int contexts() const { return 1 + (int)vclones.size(); }
@@ -258,10 +259,10 @@ int sbv2_pipeline_create(sbv2_bert* bert, sbv2_vits* vits, sbv2_pipeline** out) 
     std::unique_ptr<sbv2_pipeline> p(new sbv2_pipeline);
     p->bert = bert;
     p->vits = vits;
-    // micro-batch contexts.  Default 1: measured on MI355X (round 1) the DeBERTa / text / flow chains are latency bound (small grids),
-    // so cutting the batch multiplies their cost (4 contexts: 220 ms/step vs 186) instead of hiding it behind the decoder.
-    int k = 1;
-    if (const char* e = getenv("SBV2_MICROBATCHES")) k = std::max(1, std::min(16, atoi(e)));
+    // execution contexts = pipeline depth across calls (SBV2_PIPELINE_DEPTH, default 2).  (Cutting ONE batch into micro-batches was
+    // measured too: the latency-bound chains then repeat per micro-batch and the step gets slower, 220 vs 186 ms with 4 cuts.)
+    int k = 2;
+    if (const char* e = getenv("SBV2_PIPELINE_DEPTH")) k = std::max(1, std::min(8, atoi(e)));
     for (int i = 1; i < k; ++i) {
         p->bclones.emplace_back(bert->m->clone());
         p->vclones.emplace_back(vits->m->clone());
@@ -297,82 +298,54 @@ static void pipeline_run_one(BertModel& bm, VitsModel& vm, VitsBatch v, const in
     vm.forward(v);
 }
 
+// Batches are PIPELINED ACROSS CALLS: call n runs on execution context n % depth (own HIP stream + workspace, shared weights), so the
+// latency-bound part of batch n+1 (DeBERTa, text encoder, duration predictors, flow: ~1300 small launches, ~55 ms whatever the
+// batch size) executes beside the throughput-bound HiFi-GAN kernels of batch n.  A call returns once its kernels are enqueued (the
+// host only waits for the batch's own integer durations); results are collected with sbv2_pipeline_wait / _fetch_pcm by ticket.
 int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens, const int64_t* word2ph,
                       int64_t* pcm_lens) {
     API_BEGIN
     SBV2_REQUIRE(p && token_ids && s_lens && word2ph && pcm_lens, "bad arguments");
-    const VitsBatch all = to_batch(batch);
-    // Micro-batch pipelining: the batch is cut into contiguous, cost-balanced ranges, each on its own context (stream + workspace).
-    // The host issues them one after the other; the DeBERTa / text-side kernels of range i+1 (small grids, latency bound) then run
-    // beside the decoder kernels of range i.  Every utterance's result is independent of the batch it is in (tests assert
-    // bit equality), so the cut does not change the output.
-    const int k = std::min(p->contexts(), all.n);
-    std::vector<int64_t> cost(all.n);
-    int64_t total = 0;
-    for (int u = 0; u < all.n; ++u) total += (cost[u] = all.t_lens[u]);
-    p->mb_first.assign(k, 0);
-    p->mb_count.assign(k, 0);
-    {
-        int u = 0;
-        int64_t acc = 0;
-        for (int j = 0; j < k; ++j) {
-            p->mb_first[j] = u;
-            const int64_t target = total * (j + 1) / k;
-            while (u < all.n && (acc < target || p->mb_count[j] == 0) && all.n - u > k - 1 - j) {
-                acc += cost[u];
-                ++u;
-                ++p->mb_count[j];
-            }
-        }
-        p->mb_count[k - 1] += all.n - u;   // remainder
-    }
-    std::vector<int64_t> t_off(all.n + 1, 0), s_off(all.n + 1, 0);
-    for (int u = 0; u < all.n; ++u) {
-        t_off[u + 1] = t_off[u] + all.t_lens[u];
-        s_off[u + 1] = s_off[u] + s_lens[u];
-    }
-    for (int j = 0; j < k; ++j) {
-        const int f = p->mb_first[j], c = p->mb_count[j];
-        if (c == 0) continue;
-        VitsBatch v = all;
-        v.n = c;
-        v.t_lens = all.t_lens + f;
-        v.phones = all.phones + t_off[f];
-        v.tones = all.tones + t_off[f];
-        v.langs = all.langs + t_off[f];
-        v.sids = all.sids + f;
-        v.styles = all.styles + (int64_t)f * p->vits->m->cfg().style_dim;
-        v.forced_durations = all.forced_durations ? all.forced_durations + t_off[f] : nullptr;
-        v.utt0 = f;   // noise streams are keyed by the utterance's index in the whole batch
-        pipeline_run_one(p->bm(j), p->vm(j), v, token_ids + s_off[f], s_lens + f, word2ph + s_off[f]);
-        for (int i = 0; i < c; ++i) pcm_lens[f + i] = p->vm(j).pcm_lens()[i];
-    }
+    const VitsBatch v = to_batch(batch);
+    const int ctx = (int)(p->calls % p->contexts());
+    p->last_ctx = ctx;
+    ++p->calls;
+    pipeline_run_one(p->bm(ctx), p->vm(ctx), v, token_ids, s_lens, word2ph);
+    for (int i = 0; i < v.n; ++i) pcm_lens[i] = p->vm(ctx).pcm_lens()[i];
+    API_END
+}
+
+int sbv2_pipeline_last_ticket(sbv2_pipeline* p) { return p ? p->last_ctx : -1; }
+
+int sbv2_pipeline_wait(sbv2_pipeline* p, int ticket) {
+    API_BEGIN
+    SBV2_REQUIRE(p && ticket >= 0 && ticket < p->contexts(), "bad ticket");
+    HIP_CHECK(hipSetDevice(p->vits->m->device()));
+    HIP_CHECK(hipStreamSynchronize(p->vm(ticket).stream()));
     API_END
 }
 
 int sbv2_pipeline_sync(sbv2_pipeline* p) {
     API_BEGIN
     SBV2_REQUIRE(p, "bad arguments");
-    for (size_t j = 0; j < p->mb_count.size(); ++j)
-        if (p->mb_count[j]) HIP_CHECK(hipStreamSynchronize(p->vm((int)j).stream()));
+    HIP_CHECK(hipSetDevice(p->vits->m->device()));
+    for (int j = 0; j < p->contexts(); ++j) HIP_CHECK(hipStreamSynchronize(p->vm(j).stream()));
     API_END
 }
 
-// Concatenated PCM of the last run in utterance order; `device` != 0: dst is device memory (e.g. the RCCL send buffer)
-int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int device) {
+// Concatenated PCM of the run with this ticket (utterance order); dst_is_device != 0: dst is device memory (the RCCL send buffer)
+int sbv2_pipeline_fetch_pcm_ticket(sbv2_pipeline* p, int ticket, float* dst, int dst_is_device) {
     API_BEGIN
-    SBV2_REQUIRE(p && dst, "bad arguments");
-    int64_t off = 0;
-    for (size_t j = 0; j < p->mb_count.size(); ++j) {
-        if (!p->mb_count[j]) continue;
-        VitsModel& vm = p->vm((int)j);
-        HIP_CHECK(hipMemcpyAsync(dst + off, vm.pcm_device(), sizeof(float) * (size_t)vm.pcm_total(),
-                                 device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, vm.stream()));
-        off += vm.pcm_total();
-    }
-    for (size_t j = 0; j < p->mb_count.size(); ++j)
-        if (p->mb_count[j]) HIP_CHECK(hipStreamSynchronize(p->vm((int)j).stream()));
+    SBV2_REQUIRE(p && dst && ticket >= 0 && ticket < p->contexts(), "bad arguments");
+    VitsModel& vm = p->vm(ticket);
+    HIP_CHECK(hipSetDevice(vm.device()));
+    HIP_CHECK(hipMemcpyAsync(dst, vm.pcm_device(), sizeof(float) * (size_t)vm.pcm_total(),
+                             dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, vm.stream()));
+    HIP_CHECK(hipStreamSynchronize(vm.stream()));
     API_END
+}
+int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int dst_is_device) {
+    return sbv2_pipeline_fetch_pcm_ticket(p, p ? p->last_ctx : -1, dst, dst_is_device);
 }
 
 int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out) {

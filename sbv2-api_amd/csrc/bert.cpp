@@ -39,7 +39,7 @@ std::vector<int> BertModel::bucket_table(int maxS, int buckets, int max_rel) {
 BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(blob.kind == 1, "weight container is not a DeBERTa (kind 1) model");
     HIP_CHECK(hipSetDevice(device));
-    HIP_CHECK(hipStreamCreate(&stream_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));  // never serialised against the NULL stream (e.g. RCCL launched by the caller)
     const std::string& js = blob.config_json;
     cfg_.vocab = (int)json_number(js, "vocab_size");
     cfg_.hidden = (int)json_number(js, "hidden");
@@ -119,7 +119,7 @@ BertModel* BertModel::clone() const {
     HIP_CHECK(hipSetDevice(device_));
     BertModel* c = new BertModel(*this);   // shares ws_ (device weights); Arena copies are empty
     c->stream_ = nullptr;
-    HIP_CHECK(hipStreamCreate(&c->stream_));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
     c->out_ = Plane{};
     c->layout_ = SegLayout{};
     return c;

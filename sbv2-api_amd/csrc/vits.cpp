@@ -130,7 +130,7 @@ VitsModel::DDS VitsModel::load_dds(const std::string& p, int) {
 VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(blob.kind == 2, "weight container is not a VITS (kind 2) model");
     HIP_CHECK(hipSetDevice(device));
-    HIP_CHECK(hipStreamCreate(&stream_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));  // never serialised against the NULL stream (e.g. RCCL launched by the caller)
     const std::string& js = blob.config_json;
     auto I = [&](const char* k) { return (int)json_number(js, k); };
     cfg_.n_vocab = I("n_vocab"); cfg_.n_tones = I("n_tones"); cfg_.n_langs = I("n_langs"); cfg_.n_speakers = I("n_speakers");
@@ -255,7 +255,7 @@ VitsModel* VitsModel::clone() const {
     HIP_CHECK(hipSetDevice(device_));
     VitsModel* c = new VitsModel(*this);   // shares ws_ (device weights); Arena copies are empty
     c->stream_ = nullptr;
-    HIP_CHECK(hipStreamCreate(&c->stream_));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
     c->pcm_ = nullptr;
     c->pcm_total_ = 0;
     c->pcm_lens_.clear();

@@ -174,7 +174,14 @@ class Pipeline:
     def run(self, b):
         check(_lib.lib().sbv2_pipeline_run(self.h, C.byref(b.c), b.ids.ctypes.data_as(i64p), b.s_lens.ctypes.data_as(i64p),
                                            b.w2p.ctypes.data_as(i64p), b.lens.ctypes.data_as(i64p)))
+        b.ticket = _lib.lib().sbv2_pipeline_last_ticket(self.h)   # identifies this run's results until `depth` further runs
         return b.lens
+
+    def wait(self, ticket: int):
+        check(_lib.lib().sbv2_pipeline_wait(self.h, ticket))
+
+    def fetch_ticket_to_device(self, ticket: int, device_ptr: int):
+        check(_lib.lib().sbv2_pipeline_fetch_pcm_ticket(self.h, ticket, C.c_void_p(device_ptr), 1))
 
     def sync(self):
         check(_lib.lib().sbv2_pipeline_sync(self.h))
