@@ -5,7 +5,9 @@ Workload (BASELINE.json `metric`, configs[2]): a batch of 32 synthetic utterance
 full ku-nlp/deberta-v2-large + Style-Bert-VITS2 JP-Extra shapes with procedurally generated weights.
 One step = DeBERTa -> word2ph feature repeat -> text encoder + both duration predictors -> flow -> HiFi-GAN for the
 whole batch, PCM left in HBM; with N > 1 ranks every rank synthesises its own 32 utterances (weak scaling, no
-data-path collective) and the PCM is gathered to rank 0 over RCCL inside the timed step.
+data-path collective) and the PCM is gathered to rank 0 over RCCL.  Steps are pipelined one deep (the library runs
+consecutive batches on alternating execution contexts): step n's PCM is collected / gathered right after step n+1 has been
+enqueued and the final fence drains the pipeline, so all K steps' work lies inside the timed region.
 
 Extra objects on the JSON line:
   roofline     — the dominant kernel (the implicit-GEMM conv tile configuration with the most time), algorithmic FLOP
