@@ -61,10 +61,8 @@ def main():
     if l.sbv2_device_count() < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
 
-    # model shapes (kept in synth-free dicts here: the oracle is not imported on the product path)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import sbv2_oracle as O  # configs + cpu_baseline only
-    bc, vc = (O.DEBERTA_TINY, O.VITS_TINY) if args.tiny else (O.DEBERTA_FULL, O.VITS_FULL)
+    from sbv2_api_amd import configs   # the oracle is imported by the cpu_baseline leg only
+    bc, vc = (configs.DEBERTA_TINY, configs.VITS_TINY) if args.tiny else (configs.DEBERTA_FULL, configs.VITS_FULL)
     bw = synth.make_deberta_weights(bc)
     vw = synth.make_vits_weights(vc)
     bs = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, bw), True, device=local_rank)
@@ -128,7 +126,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    audio_s_per_rank = float(b.lens.sum()) / O.SAMPLE_RATE
+    audio_s_per_rank = float(b.lens.sum()) / configs.SAMPLE_RATE
     total_audio = audio_s_per_rank * world * args.steps
     value = total_audio / dt
 
@@ -174,6 +172,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import torch as _t
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import sbv2_oracle as O   # the checker / CPU baseline: never on the measured path
         O.set_conv_backend("torch")
         u = utts[0]
         t1 = time.perf_counter()

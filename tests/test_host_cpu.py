@@ -86,3 +86,10 @@ def test_gather_pcm_world2_gloo():
     lens = [5, 17, 1, 9, 12]
     for i, n in enumerate(lens):
         assert got[i] == (np.arange(n, dtype=np.float32) + 100 * i).tolist()
+
+
+def test_package_configs_match_oracle():
+    import sbv2_oracle as O
+    from sbv2_api_amd import configs
+    for name in ("DEBERTA_FULL", "DEBERTA_TINY", "VITS_FULL", "VITS_TINY", "SAMPLE_RATE"):
+        assert getattr(configs, name) == getattr(O, name), name
