@@ -54,7 +54,7 @@ class Arena {
     Arena(const Arena&) {}   // a copied model context starts with an empty workspace of its own
     Arena& operator=(const Arena&) = delete;
     ~Arena() { release(); }
-    // Start a new forward pass: keeps the memory, consolidates into one chunk if the last pass had to grow.
+    // Start a new forward pass: keeps every chunk (same shapes -> same placement, no allocation after the first pass).
     void reset();
     void* alloc(size_t bytes);
     Plane plane(int C, int L);
