@@ -311,6 +311,30 @@ def test_pipeline_tiny():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_edge_cases_tiny(vits_tiny, bert_tiny):
+    """Smallest inputs the front end can produce and the degenerate duration case (sum(w_ceil) == 0 -> clamp_min(1) frame)."""
+    cfg, W = weights("vits", "tiny", 5)
+    bc, bw = weights("bert", "tiny", 3)
+    # one BERT token, and the 2-token [CLS][SEP] sequence
+    for ids in (np.array([1]), np.array([1, 2])):
+        np.testing.assert_allclose(model.predict(bert_tiny, ids, np.ones_like(ids)), O.deberta_forward(bw, bc, ids), atol=5e-5, rtol=0)
+    # a single text position
+    rng = np.random.default_rng(5)
+    u = dict(bert=rng.standard_normal((cfg["bert_dim"], 1)).astype(np.float32), phones=np.array([7]), tones=np.array([6]), langs=np.array([1]),
+             style=rng.standard_normal(cfg["style_dim"]).astype(np.float32) * 0.1, sid=0, forced_durations=np.array([3]), T_text=1)
+    got = model.synthesize_batch(vits_tiny, [u], forced=True)[0]
+    ref = O.vits_forward(W, cfg, u["bert"], u["phones"], u["tones"], u["langs"], 0, u["style"], forced_durations=u["forced_durations"])
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+    # all durations zero in one utterance of a batch: exactly one frame (512 // hop samples here) of "silence through the decoder"
+    utts = make_utts([4, 6], O.DEBERTA_TINY, cfg, seed0=71)
+    utts[0]["forced_durations"] = np.zeros_like(utts[0]["forced_durations"])
+    pcms = model.synthesize_batch(vits_tiny, utts, forced=True)
+    assert pcms[0].shape[0] == O.hop_length(cfg)
+    for i, (u, got) in enumerate(zip(utts, pcms)):
+        r = _oracle_utt(W, cfg, u, i, 0.0, 1.0, 0.0, 0.0, 0, True)
+        np.testing.assert_allclose(got, r["pcm"], atol=1e-4, rtol=0)
+
+
 def test_error_paths(vits_tiny):
     cfg, _ = weights("vits", "tiny", 5)
     u = make_utts([4], O.DEBERTA_TINY, cfg, seed0=61)[0]
