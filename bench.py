@@ -148,6 +148,7 @@ def main():
                     "note": ("algorithmic FLOP; split-bf16 issues 3 bf16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi), so "
                              "executed MFMA FLOP/s = 3x achieved") if "split" in dom["kernel"] else "algorithmic FLOP",
                     "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "per_config_ms": {r["kernel"]: round(r["ms"], 3) for r in prof},
                     "all_conv_gemm_ms_per_step": round(sum(r["ms"] for r in prof), 3),
                     "all_conv_gemm_tflops": round(sum(r["flop"] for r in prof) / (sum(r["ms"] for r in prof) * 1e-3) / 1e12, 2)}
 

@@ -209,6 +209,18 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     }
     __syncthreads();
 
+    // the residual rows of the epilogue are requested now (branch-free, clamped) and land behind conv2's MFMAs; they were fetched
+    // for the conv1 window a moment ago, so these are L2 hits, but still a dependent ~1 us round trip if left to the epilogue
+    f32x4v rres[8];
+    {
+        const int c4r = min((lane & 7) * 4, C - 4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t posr = min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
+            rres[it] = *reinterpret_cast<const f32x4v*>(p.X + posr * C + c4r);
+        }
+    }
+
     // ---- phase 2: conv2 over the LDS-resident intermediate --------------------------------------------------------------------
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
         const int64_t pos = (int64_t)n0_cur + o;
         const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * 36 + c4);
         if (o >= nto || pos >= NB || c4 >= C) continue;
-        const f32x4v r = *reinterpret_cast<const f32x4v*>(p.X + pos * C + c4);
+        const f32x4v r = rres[it];
         f32x4v v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (a[e] + b4[e] + r[e]) * p.beta;
