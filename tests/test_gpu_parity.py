@@ -334,6 +334,40 @@ def test_pipeline_tiny():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_orchestrator_request_tiny():
+    """tts.rs:280-349 through ONE batched pipeline call == the reference's per-sentence loop (oracle), including the rule that
+    22050 zero samples follow every sentence that is not the request's last LINE (empty lines count), and the WAV framing."""
+    import io
+    import orchestrator_oracle as OO
+    from scipy.io import wavfile
+    from sbv2_api_amd import orchestrator as orch
+    bc, bw = weights("bert", "tiny", 3)
+    vc, vw = weights("vits", "tiny", 5)
+    bs, vs = model.load_model(blob("bert", "tiny", 3), True), model.load_model(blob("vits", "tiny", 5), False)
+    pipe = model.Pipeline(bs, vs)
+    us = make_utts([6, 11, 3], bc, vc, seed0=91, with_bert=False)
+    keys = ("input_ids", "word2ph", "phones", "tones", "langs")
+    sentences = [{k: us[0][k] for k in keys}, None, {k: us[1][k] for k in keys}, {k: us[2][k] for k in keys}, None]
+    sv = np.random.default_rng(9).standard_normal((3, vc["style_dim"])).astype(np.float32) * 0.1
+    opts = orch.SynthesizeOptions(style_weight=0.6, length_scale=1.1)
+    wav = orch.easy_synthesize(pipe, sentences, sv, style_id=2, speaker_id=0, options=opts, noise_scale=0.0, noise_scale_w=0.0)
+    style = OO.get_style_vector(sv, 2, 0.6)
+
+    def synth_one(s):
+        bert = O.expand_bert_features(O.deberta_forward(bw, bc, s["input_ids"]), s["word2ph"])
+        return O.vits_forward(vw, vc, bert, s["phones"], s["tones"], s["langs"], 0, style, sdp_ratio=0.0, length_scale=1.1)
+
+    ref = OO.easy_synthesize(sentences, synth_one)
+    rate, got = wavfile.read(io.BytesIO(wav))
+    assert rate == 44100 and got.shape[0] == ref.shape[2]      # same durations, same three gaps (trailing one included)
+    np.testing.assert_allclose(got, ref[0, 0], atol=2e-4, rtol=0)
+    assert np.all(got[-22050:] == 0.0)
+    assert wav[:68] == OO.array_to_wav(ref)[:68]
+    with pytest.raises(model.Sbv2Error):
+        orch.easy_synthesize(pipe, [None, None], sv)
+    pipe.close(); bs.close(); vs.close()
+
+
 def test_edge_cases_tiny(vits_tiny, bert_tiny):
     """Smallest inputs the front end can produce and the degenerate duration case (sum(w_ceil) == 0 -> clamp_min(1) frame)."""
     cfg, W = weights("vits", "tiny", 5)

@@ -93,3 +93,40 @@ def test_package_configs_match_oracle():
     from sbv2_api_amd import configs
     for name in ("DEBERTA_FULL", "DEBERTA_TINY", "VITS_FULL", "VITS_TINY", "SAMPLE_RATE"):
         assert getattr(configs, name) == getattr(O, name), name
+
+
+def test_style_vector_blend_and_json():
+    """style.rs:11-28 mirror vs the oracle restatement."""
+    import json
+    import orchestrator_oracle as OO
+    from sbv2_api_amd import orchestrator as orch, model
+    rng = np.random.default_rng(3)
+    sv = rng.standard_normal((4, 256)).astype(np.float32)
+    blob = json.dumps({"shape": [4, 256], "data": [[float(v) for v in row] for row in sv]}).encode()
+    got = orch.load_style(blob)
+    assert got.dtype == np.float32 and np.array_equal(got, sv)
+    for sid, w in ((0, 1.0), (2, 1.0), (3, 0.35), (1, 2.5)):
+        np.testing.assert_array_equal(orch.get_style_vector(got, sid, w), OO.get_style_vector(sv, sid, w))
+    np.testing.assert_array_equal(orch.get_style_vector(got, 0, 7.0), sv[0])
+    with pytest.raises(model.Sbv2Error):
+        orch.load_style(json.dumps({"shape": [4, 256], "data": [[0.0] * 255] * 4}).encode())
+    with pytest.raises(IndexError):
+        orch.get_style_vector(got, 4, 1.0)
+
+
+def test_wav_encoding_reads_back():
+    """tts_util.rs:163-180 mirror: same bytes as the oracle restatement; an independent reader (scipy) sees 44.1 kHz mono f32
+    with the samples of all batch rows back to back."""
+    import io
+    import orchestrator_oracle as OO
+    from scipy.io import wavfile
+    from sbv2_api_amd import orchestrator as orch
+    rng = np.random.default_rng(4)
+    audio = np.tanh(rng.standard_normal((2, 1, 1000))).astype(np.float32)
+    wav = orch.array_to_wav(audio)
+    assert wav == OO.array_to_wav(audio)
+    assert len(wav) == 68 + 4 * 2000 and wav[:4] == b"RIFF" and int.from_bytes(wav[4:8], "little") == len(wav) - 8
+    rate, data = wavfile.read(io.BytesIO(wav))
+    assert rate == 44100 and data.dtype == np.float32 and data.ndim == 1
+    np.testing.assert_array_equal(data, audio.reshape(-1))
+    assert orch.array_to_wav(np.zeros((1, 1, 0), np.float32))[-4:] == (0).to_bytes(4, "little")
