@@ -73,7 +73,8 @@ def main():
 
     hop = l.sbv2_vits_hop(vs.handle)
     dmode = l.sbv2_vits_decoder_mode(vs.handle)
-    dtype = {0: "f32", 1: "bf16x3-split (decoder convs: bf16 hi/lo MFMA, f32 accumulate/storage) + f32", 2: "bf16 (decoder convs) + f32"}[dmode]
+    dtype = {0: "f32", 1: "bf16x3-split (decoder convs: bf16 hi/lo MFMA, f32 accumulate/storage) + f32", 2: "bf16 (decoder convs) + f32",
+             3: "f16 (decoder convs: fp16 MFMA operands, f32 accumulate/storage) + f32"}[dmode]
     send = recv = None
 
     # Steps are pipelined one deep: step n's PCM is collected (and, with N > 1, gathered to rank 0 over RCCL) right after step n+1
@@ -141,7 +142,7 @@ def main():
     roofline = None
     if dom:
         ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
-        is_cl = dom["kernel"].startswith("conv_cl")
+        is_cl = dom["kernel"].startswith("conv_cl") or dom["kernel"].startswith("conv_ps")
         peak = PEAK_BF16_MFMA_TFLOPS if is_cl else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
@@ -158,11 +159,15 @@ def main():
         try:
             import csv, glob
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))[-1]
-            want = {"conv_cl<2,split-bf16>": "conv_cl_kernel<2, true, false, false>", "conv_cl<1,split-bf16>": "conv_cl_kernel<1, true, false, false>",
-                    "conv_cl<2,bf16>": "conv_cl_kernel<2, false, false, false>", "conv_gemm<32,2,2,1,4,16>": "conv_gemm_kernel<32, 2, 2, 1, 4, 16>",
-                    "conv_gemm<32,2,4,2,2,16>": "conv_gemm_kernel<32, 2, 4, 2, 2, 16>"}.get(dom["kernel"], "\0")
+            # kernel names as rocprofv3 prints them (the precision template argument was a bool before the fp16 mode: both spellings)
+            want = {"conv_cl<2,split-bf16>": ("conv_cl_kernel<2, 1, false, false>", "conv_cl_kernel<2, true, false, false>"),
+                    "conv_cl<1,split-bf16>": ("conv_cl_kernel<1, 1, false, false>", "conv_cl_kernel<1, true, false, false>"),
+                    "conv_cl<2,bf16>": ("conv_cl_kernel<2, 0, false, false>", "conv_cl_kernel<2, false, false, false>"),
+                    "conv_cl<2,f16>": ("conv_cl_kernel<2, 2, false, false>",),
+                    "conv_gemm<32,2,2,1,4,16>": ("conv_gemm_kernel<32, 2, 2, 1, 4, 16>",),
+                    "conv_gemm<32,2,4,2,2,16>": ("conv_gemm_kernel<32, 2, 4, 2, 2, 16>",)}.get(dom["kernel"], ("\0",))
             for r in csv.DictReader(open(pm)):
-                if want in r["kernel"]:
+                if any(w in r["kernel"] for w in want):
                     roofline["traffic"] = round(float(r["fetch_bytes_per_launch(x2 gfx950 correction)"]) + float(r["write_bytes_per_launch"]))
                     roofline["traffic_unit"] = "bytes per launch (HBM, PMC)"
                     roofline["traffic_source"] = os.path.relpath(pm, ROOT)

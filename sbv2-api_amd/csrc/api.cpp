@@ -421,10 +421,10 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
                          int64_t dilation, float pre_slope, int mode, int64_t iters, float* y, float* ms) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
-    SBV2_REQUIRE(mode == 1 || mode == 2, "mode: 1 = split-bf16, 2 = bf16");
+    SBV2_REQUIRE(mode >= 1 && mode <= 3, "mode: 1 = split-bf16, 2 = bf16, 3 = f16");
     Blob b = one_conv_blob(w, bias, {cout, cin, k}, cout);
     WeightStore ws(b);
-    ClConv c = pack_cl(ws, w, (int)cout, (int)cin, (int)k, mode == 1 ? 2 : 1, bias);
+    ClConv c = pack_cl(ws, w, (int)cout, (int)cin, (int)k, mode == 1 ? 2 : (mode == 2 ? 1 : 3), bias);
     std::vector<float> xt((size_t)L * cin), yt((size_t)L * cout);
     for (int64_t ci = 0; ci < cin; ++ci)
         for (int64_t n = 0; n < L; ++n) xt[(size_t)n * cin + ci] = x[(size_t)ci * L + n];
@@ -438,6 +438,7 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
     p.nmt = c.nmt;
     p.tm = c.tm;
     p.split = mode == 1;
+    p.f16 = mode == 3;
     p.M = (int)cout;
     p.N = (int)L;
     p.K = (int)cin;

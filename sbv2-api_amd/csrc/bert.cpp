@@ -58,7 +58,8 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
         const std::string v(m);
         if (v == "f32") gemm_parts = 0;
         else if (v == "bf16") gemm_parts = 1;
-        else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3 or bf16");
+        else if (v == "f16") gemm_parts = 0;   // a VITS-side knob; DeBERTa decides the integer durations and stays exact f32
+        else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3, bf16 or f16");
     }
     ws_.reset(new WeightStore(blob, gemm_parts));
     emb_ = ws_->tensor("deberta.embeddings.word_embeddings.weight");

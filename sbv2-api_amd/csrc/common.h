@@ -166,6 +166,7 @@ struct ConvClParams {
     int ldx = 0, NB = 0;
     const void* W = nullptr;   // bf16 fragment blocks [chunk][mtile][tap][part][64 lanes][8]
     int nmt = 0, tm = 2, split = 1;
+    int f16 = 0;               // fragments and window are fp16 instead of bf16 (exclusive with split)
     int M = 0, N = 0, K = 0, ntaps = 1;
     int shift[kMaxTaps] = {0};
     float* Y = nullptr;
@@ -215,7 +216,7 @@ struct ResPairParams {
     const void* W2 = nullptr;
     const float* b1 = nullptr;
     const float* b2 = nullptr;
-    int C = 0, N = 0, k = 1, dil = 1, split = 1;
+    int C = 0, N = 0, k = 1, dil = 1, split = 1, f16 = 0;
     float slope = 0.1f, beta = 1.0f;
     int accumulate = 0;
     const unsigned char* mask = nullptr;

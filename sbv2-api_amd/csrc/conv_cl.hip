@@ -26,8 +26,16 @@ namespace sbv2 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// operand precision of the matrix-core path: bf16 (1 MFMA per product), split bf16 hi/lo (3 MFMAs, f32-grade) or fp16 (1 MFMA,
+// 11-bit significands: 8x finer than bf16 at the same rate; f32 accumulation and f32 storage in every mode)
+enum { PREC_BF16 = 0, PREC_BF16X3 = 1, PREC_F16 = 2 };
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // compile-time loop: indices are constants before SROA runs, so per-thread staging arrays stay in registers (a late-unrolled
 // `for` over a 12-entry float4 array was left in scratch by hipcc)
@@ -53,8 +61,12 @@ struct ClKernelParams {
     int mask_shift;
 };
 
-template <int TM, bool SPLIT, bool IN_KM, bool OUT_KM>
+template <int TM, int PREC, bool IN_KM, bool OUT_KM>
 __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParams kp) {
+    constexpr bool SPLIT = PREC == PREC_BF16X3;
+    using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
+    using ex8 = std::conditional_t<PREC == PREC_F16, f16x8, bf16x8>;
+    using ex4 = std::conditional_t<PREC == PREC_F16, f16x4, bf16x4>;
     constexpr int PARTS = SPLIT ? 2 : 1;
     constexpr int TN = 2;
     constexpr int MAXW = (kMaxTaps * TM * PARTS * 64 + kClThreads - 1) / kClThreads;  // float4 per thread for one chunk's weights
@@ -176,14 +188,14 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                     if (pos < 0 || pos >= NB) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     lrelu4(v);
                     const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
-                    bf16x4 h;
-                    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-                    *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
+                    ex4 h;
+                    h[0] = (elem_t)v.x; h[1] = (elem_t)v.y; h[2] = (elem_t)v.z; h[3] = (elem_t)v.w;
+                    *reinterpret_cast<ex4*>(xs_hi + off) = h;
                     if (SPLIT) {
-                        bf16x4 l;
-                        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-                        l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-                        *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
+                        ex4 l;
+                        l[0] = (elem_t)(v.x - (float)h[0]); l[1] = (elem_t)(v.y - (float)h[1]);
+                        l[2] = (elem_t)(v.z - (float)h[2]); l[3] = (elem_t)(v.w - (float)h[3]);
+                        *reinterpret_cast<ex4*>(xs_lo + off) = l;
                     }
                 }
             }
@@ -207,14 +219,14 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                     lrelu4(v);
                     const int row = r0 + e;
                     const int off = row * 32 + ((((kq >> 1) ^ (row >> 3)) & 1) << 4) + ((kq & 1) << 3);
-                    bf16x4 h;
-                    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-                    *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
+                    ex4 h;
+                    h[0] = (elem_t)v.x; h[1] = (elem_t)v.y; h[2] = (elem_t)v.z; h[3] = (elem_t)v.w;
+                    *reinterpret_cast<ex4*>(xs_hi + off) = h;
                     if (SPLIT) {
-                        bf16x4 l;
-                        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-                        l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-                        *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
+                        ex4 l;
+                        l[0] = (elem_t)(v.x - (float)h[0]); l[1] = (elem_t)(v.y - (float)h[1]);
+                        l[2] = (elem_t)(v.z - (float)h[2]); l[3] = (elem_t)(v.w - (float)h[3]);
+                        *reinterpret_cast<ex4*>(xs_lo + off) = l;
                     }
                 }
             }
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         // sets, static ping-pong), so a wave's LDS latency hides under its own MFMA block instead of relying on the partner wave.
         // Tap offsets are an arithmetic progression (shift0 + tap * step): no scalar load shares the lgkm counter with the ds_reads.
         struct Frags {
-            bf16x8 bh[TN], bl[TN], ah[TM], al[TM];
+            ex8 bh[TN], bl[TN], ah[TM], al[TM];
         };
         auto load_frags = [&](Frags& f, int tap) {
             const int sh = kp.sh0 + tap * kp.sh_step;
@@ -247,14 +259,14 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lcol + sh;
                 const int off = row * 32 + (((lh ^ (row >> 3)) & 1) << 4);
-                f.bh[j] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
-                if (SPLIT) f.bl[j] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+                f.bh[j] = *reinterpret_cast<const ex8*>(xs_hi + off);
+                if (SPLIT) f.bl[j] = *reinterpret_cast<const ex8*>(xs_lo + off);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const char* blk = wsm + ((i * ntaps + tap) * PARTS) * 1024 + lane * 16;
-                f.ah[i] = *reinterpret_cast<const bf16x8*>(blk);
-                if (SPLIT) f.al[i] = *reinterpret_cast<const bf16x8*>(blk + 1024);
+                f.ah[i] = *reinterpret_cast<const ex8*>(blk);
+                if (SPLIT) f.al[i] = *reinterpret_cast<const ex8*>(blk + 1024);
             }
         };
         auto mfma_frags = [&](const Frags& f) {
@@ -263,10 +275,10 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_32x32x16(f.al[i], f.bh[j], acc[i][j]);
+                        acc[i][j] = mfma_32x32x16(f.ah[i], f.bl[j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16(f.ah[i], f.bh[j], acc[i][j]);
                 }
         };
         Frags fa, fb;
@@ -374,8 +386,9 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     }
 }
 
-template <int TM, bool SPLIT, bool IN_KM, bool OUT_KM>
+template <int TM, int PREC, bool IN_KM, bool OUT_KM>
 static void launch_cl(ClKernelParams kp, hipStream_t stream) {
+    constexpr bool SPLIT = PREC == PREC_BF16X3;
     constexpr int PARTS = SPLIT ? 2 : 1;
     const ConvClParams& p = kp.p;
     kp.wbytes = p.ntaps * TM * PARTS * 1024;
@@ -384,7 +397,7 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     static const int pad_lds = getenv("SBV2_CL_PADLDS") ? atoi(getenv("SBV2_CL_PADLDS")) : 0;   // occupancy experiments only
     lds += pad_lds;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
-    auto kern = conv_cl_kernel<TM, SPLIT, IN_KM, OUT_KM>;
+    auto kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -403,19 +416,19 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add((SPLIT ? 8 : 10) + (TM == 2 ? 0 : 1) + (IN_KM ? 4 : 0), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+        conv_prof_add(PREC == PREC_F16 ? 19 + (TM == 2 ? 0 : 1) + (IN_KM ? 2 : 0) : (SPLIT ? 8 : 10) + (TM == 2 ? 0 : 1) + (IN_KM ? 4 : 0), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
     }
 }
 
-template <int TM, bool SPLIT>
+template <int TM, int PREC>
 static void launch_cl_layout(const ClKernelParams& kp, hipStream_t stream) {
     const ConvClParams& p = kp.p;
     if (p.in_km) {
-        if (p.out_km) launch_cl<TM, SPLIT, true, true>(kp, stream);
-        else launch_cl<TM, SPLIT, true, false>(kp, stream);
+        if (p.out_km) launch_cl<TM, PREC, true, true>(kp, stream);
+        else launch_cl<TM, PREC, true, false>(kp, stream);
     } else {
         SBV2_REQUIRE(!p.out_km, "conv_cl: channels-last input with k-major output is not instantiated");
-        launch_cl<TM, SPLIT, false, false>(kp, stream);
+        launch_cl<TM, PREC, false, false>(kp, stream);
     }
 }
 
@@ -451,12 +464,16 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         while ((1 << s) < p.mask_div) ++s;
         kp.mask_shift = s;
     }
+    SBV2_REQUIRE(!(p.split && p.f16), "conv_cl: split and f16 are exclusive");
     if (p.split) {
-        if (p.tm == 2) launch_cl_layout<2, true>(kp, stream);
-        else launch_cl_layout<1, true>(kp, stream);
+        if (p.tm == 2) launch_cl_layout<2, PREC_BF16X3>(kp, stream);
+        else launch_cl_layout<1, PREC_BF16X3>(kp, stream);
+    } else if (p.f16) {
+        if (p.tm == 2) launch_cl_layout<2, PREC_F16>(kp, stream);
+        else launch_cl_layout<1, PREC_F16>(kp, stream);
     } else {
-        if (p.tm == 2) launch_cl_layout<2, false>(kp, stream);
-        else launch_cl_layout<1, false>(kp, stream);
+        if (p.tm == 2) launch_cl_layout<2, PREC_BF16>(kp, stream);
+        else launch_cl_layout<1, PREC_BF16>(kp, stream);
     }
 }
 

@@ -1,6 +1,7 @@
 // HiFi-GAN generator (models_jp_extra.Generator) on channels-last planes with the bf16 / split-bf16 MFMA kernel of conv_cl.hip.
 // Same arithmetic graph as VitsModel::run_decoder (vits.cpp), different layout and matrix-core data type:
-//   dec_mode_ 1 = split-bf16 (hi/lo operands, 3 MFMAs per product, f32-grade), 2 = plain bf16 operands.
+//   dec_mode_ 1 = split-bf16 (hi/lo operands, 3 MFMAs per product, f32-grade), 2 = plain bf16 operands, 3 = fp16 operands
+//   (1 MFMA per product like bf16, 11-bit significands).  pack_cl's precision code: 1 = bf16, 2 = bf16 hi + lo, 3 = fp16.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -15,6 +16,23 @@ static inline uint16_t f32_to_bf16_rne(float f) {
     if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+// f32 -> IEEE binary16, round to nearest even (subnormals kept, overflow -> inf)
+static inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (u > 0x7F800000u ? 0x200u : 0u));
+    if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            // >= 65520 rounds to inf
+    if (u < 0x33000001u) return (uint16_t)sign;                          // < 2^-25 rounds to zero
+    int e = (int)(u >> 23) - 127;
+    uint32_t m = (u & 0x7FFFFFu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                           // bits dropped from the 24-bit significand
+    uint32_t half = m >> shift, rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1u))) ++half;
+    if (e < -14) return (uint16_t)(sign | half);                         // subnormal (a carry into bit 10 gives the smallest normal)
+    return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (half - 0x400u)));   // mantissa carry propagates into the exponent
 }
 static inline float bf16_to_f32(uint16_t h) {
     uint32_t u = (uint32_t)h << 16;
@@ -33,7 +51,9 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
     static const int tm_min = getenv("SBV2_CL_TM2_MIN") ? atoi(getenv("SBV2_CL_TM2_MIN")) : 64;   // experiments
     c.tm = M >= tm_min ? 2 : 1;
     c.nmt = round_up((M + 31) / 32, c.tm);
-    c.parts = parts;
+    c.parts = parts;                      // precision code: 1 = bf16, 2 = bf16 hi + lo, 3 = fp16
+    const bool f16 = parts == 3;
+    if (f16) parts = 1;                   // one fragment block per tap
     const int nchunks = (K + 15) / 16;
     std::vector<uint16_t> h((size_t)nchunks * c.nmt * k * parts * 512, 0);
     for (int ch = 0; ch < nchunks; ++ch)
@@ -47,7 +67,7 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
                         const int kk = ch * 16 + 8 * (l >> 5) + j;
                         if (kk >= K) continue;
                         const float v = w[((size_t)m * K + kk) * k + t];
-                        const uint16_t hi = f32_to_bf16_rne(v);
+                        const uint16_t hi = f16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
                         blk[l * 8 + j] = hi;
                         if (parts == 2) blk[512 + l * 8 + j] = f32_to_bf16_rne(v - bf16_to_f32(hi));
                     }
@@ -62,7 +82,7 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
     auto conv = [&](const std::string& prefix) {
         const HostTensor& t = blob.get(prefix + ".weight");
         const float* b = blob.has(prefix + ".bias") ? blob.get(prefix + ".bias").data : nullptr;
-        return pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], dec_mode_ == 1 ? 2 : 1, b);
+        return pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], dec_mode_ == 1 ? 2 : (dec_mode_ == 2 ? 1 : 3), b);
     };
     cl_pre_ = conv("dec.conv_pre");
     int C = cfg_.up_initial;
@@ -108,7 +128,7 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
                 }
             for (int ti = 0; ti < g.ntaps; ++ti) g.shift[ti] = -tsets[r][ti];
             for (int pi = 0; pi < kMaxPhases; ++pi) g.phase_off[pi] = pi < g.nph ? phases[pi] : 0;
-            g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, dec_mode_ == 1 ? 2 : 1, bias.data());
+            g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, dec_mode_ == 1 ? 2 : (dec_mode_ == 2 ? 1 : 3), bias.data());
             st.up.push_back(g);
         }
         for (int j = 0; j < nk; ++j) {
@@ -136,6 +156,7 @@ void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float*
     p.nmt = c.nmt;
     p.tm = c.tm;
     p.split = dec_mode_ == 1;
+    p.f16 = dec_mode_ == 3;
     p.M = c.M;
     p.N = N;
     p.K = c.K;
@@ -189,6 +210,7 @@ void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
             p.nmt = g.c.nmt;
             p.tm = g.c.tm;
             p.split = dec_mode_ == 1;
+            p.f16 = dec_mode_ == 3;
             p.M = g.c.M;
             p.N = (int)Lcur;
             p.K = st.cin;
@@ -227,6 +249,7 @@ void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
                     rp.k = rb.k;
                     rp.dil = d;
                     rp.split = dec_mode_ == 1;
+                    rp.f16 = dec_mode_ == 3;
                     rp.slope = 0.1f;
                     rp.beta = last ? 1.0f / nk : 1.0f;
                     rp.accumulate = last && j > 0;

@@ -161,6 +161,7 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
         q.nmt = w.cl.nmt;
         q.tm = w.cl.tm;
         q.split = w.cl.parts == 2;
+        q.f16 = w.cl.parts == 3;
         q.M = w.cout;
         q.N = y.L;
         q.K = w.cin;
@@ -226,6 +227,7 @@ void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_
         q.nmt = w.cl.nmt;
         q.tm = w.cl.tm;
         q.split = w.cl.parts == 2;
+        q.f16 = w.cl.parts == 3;
         q.M = w.cout;
         q.N = x.L;
         q.K = w.cin;

@@ -60,7 +60,7 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
 
 class WeightStore {
   public:
-    // cl_parts: 0 = f32 MFMA only, 1 = also pack plain-bf16 fragments, 2 = also pack split-bf16 (hi/lo) fragments
+    // cl_parts: 0 = f32 MFMA only, 1 = also pack plain-bf16 fragments, 2 = also pack split-bf16 (hi/lo) fragments, 3 = fp16 fragments
     explicit WeightStore(const Blob& b, int cl_parts = 0) : blob_(b), cl_parts_(cl_parts) {}
     int cl_parts() const { return cl_parts_; }
     void set_cl_parts(int parts) { cl_parts_ = parts; }
@@ -274,7 +274,7 @@ class VitsModel {
     int dec_post_k_ = 7;
     std::vector<Stage> stages_;
     bool fuse_pairs_ = true;  // SBV2_FUSE_PAIRS=0 disables the fused ResBlock step of the 16/32-channel stages
-    int dec_mode_ = 0;  // 0 = exact f32 MFMA (k-major), 1 = split-bf16 (f32-grade), 2 = plain bf16
+    int dec_mode_ = 0;  // 0 = exact f32 MFMA (k-major), 1 = split-bf16 (f32-grade), 2 = plain bf16, 3 = fp16 operands
     ClConv cl_pre_;
     std::vector<ClStage> cl_stages_;
     // last-forward results

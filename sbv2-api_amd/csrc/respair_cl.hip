@@ -16,8 +16,14 @@ namespace sbv2 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+enum { PREC_BF16 = 0, PREC_BF16X3 = 1, PREC_F16 = 2 };   // as in conv_cl.hip
+__device__ __forceinline__ f32x16 rp_mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 rp_mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 constexpr int kRpThreads = 256;
 constexpr int kRpNT = 256;        // positions of the intermediate per workgroup
@@ -31,8 +37,12 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
     }
 }
 
-template <bool SPLIT, bool PERSIST>
+template <int PREC, bool PERSIST>
 __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairParams p) {
+    constexpr bool SPLIT = PREC == PREC_BF16X3;
+    using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
+    using ex8 = std::conditional_t<PREC == PREC_F16, f16x8, bf16x8>;
+    using ex4 = std::conditional_t<PREC == PREC_F16, f16x4, bf16x4>;
     constexpr int PARTS = SPLIT ? 2 : 1;
     constexpr int TN = 2;
     constexpr int MAXW = (kMaxTaps * PARTS * 64 + kRpThreads - 1) / kRpThreads;
@@ -108,39 +118,39 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
                 const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
-                bf16x4 h;
+                ex4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4*>(x1_hi + off) = h;
+                for (int e = 0; e < 4; ++e) h[e] = (elem_t)v[e];
+                *reinterpret_cast<ex4*>(x1_hi + off) = h;
                 if (SPLIT) {
-                    bf16x4 l;
+                    ex4 l;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
-                    *reinterpret_cast<bf16x4*>(x1_lo + off) = l;
+                    for (int e = 0; e < 4; ++e) l[e] = (elem_t)(v[e] - (float)h[e]);
+                    *reinterpret_cast<ex4*>(x1_lo + off) = l;
                 }
             }
         }
     };
     auto mfma_chunk = [&](const char* bhi, const char* blo, int tap_stride) {
         for (int tap = 0; tap < ntaps; ++tap) {
-            bf16x8 bh[TN], bl[TN], ah, al;
+            ex8 bh[TN], bl[TN], ah, al;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lcol + tap * tap_stride;
                 const int off = row * 32 + (((lh ^ (row >> 3)) & 1) << 4);
-                bh[j] = *reinterpret_cast<const bf16x8*>(bhi + off);
-                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(blo + off);
+                bh[j] = *reinterpret_cast<const ex8*>(bhi + off);
+                if (SPLIT) bl[j] = *reinterpret_cast<const ex8*>(blo + off);
             }
             const char* blk = wsm + (tap * PARTS) * 1024 + lane * 16;
-            ah = *reinterpret_cast<const bf16x8*>(blk);
-            if (SPLIT) al = *reinterpret_cast<const bf16x8*>(blk + 1024);
+            ah = *reinterpret_cast<const ex8*>(blk);
+            if (SPLIT) al = *reinterpret_cast<const ex8*>(blk + 1024);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (SPLIT) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+                    acc[j] = rp_mfma(al, bh[j], acc[j]);
+                    acc[j] = rp_mfma(ah, bl[j], acc[j]);
                 }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+                acc[j] = rp_mfma(ah, bh[j], acc[j]);
             }
         }
     };
@@ -184,15 +194,15 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
                     v[e] = keep ? t : 0.f;
                 }
                 const int off = (co >> 4) * (kRpWin2Rows * 32) + row * 32 + (((((co >> 3) & 1) ^ (row >> 3)) & 1) << 4) + ((co & 7) << 1);
-                bf16x4 h;
+                ex4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4*>(x2_hi + off) = h;
+                for (int e = 0; e < 4; ++e) h[e] = (elem_t)v[e];
+                *reinterpret_cast<ex4*>(x2_hi + off) = h;
                 if (SPLIT) {
-                    bf16x4 l;
+                    ex4 l;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
-                    *reinterpret_cast<bf16x4*>(x2_lo + off) = l;
+                    for (int e = 0; e < 4; ++e) l[e] = (elem_t)(v[e] - (float)h[e]);
+                    *reinterpret_cast<ex4*>(x2_lo + off) = l;
                 }
             }
         }
@@ -272,15 +282,15 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
   }
 }
 
-template <bool SPLIT, bool PERSIST>
+template <int PREC, bool PERSIST>
 static void launch_rp(const ResPairParams& p, hipStream_t stream) {
-    constexpr int PARTS = SPLIT ? 2 : 1;
+    constexpr int PARTS = PREC == PREC_BF16X3 ? 2 : 1;
     const int h1 = p.dil * (p.k - 1) / 2, h2 = (p.k - 1) / 2;
     const int rows1 = kRpNT + 2 * h1;
     size_t lds = (size_t)p.k * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
     lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));
     SBV2_REQUIRE(lds <= 160 * 1024, "respair: LDS budget exceeded");
-    auto kern = respair_cl_kernel<SPLIT, PERSIST>;
+    auto kern = respair_cl_kernel<PREC, PERSIST>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -313,11 +323,14 @@ void launch_respair_cl(const ResPairParams& p, hipStream_t stream) {
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
     if (p.N <= 0) return;
     static const int persist = getenv("SBV2_RESPAIR_PERSIST") ? atoi(getenv("SBV2_RESPAIR_PERSIST")) : 0;
+    SBV2_REQUIRE(!(p.split && p.f16), "respair: split and f16 are exclusive");
     if (p.split) {
-        if (persist) launch_rp<true, true>(p, stream);
-        else launch_rp<true, false>(p, stream);
+        if (persist) launch_rp<PREC_BF16X3, true>(p, stream);
+        else launch_rp<PREC_BF16X3, false>(p, stream);
+    } else if (p.f16) {
+        launch_rp<PREC_F16, false>(p, stream);
     } else {
-        launch_rp<false, false>(p, stream);
+        launch_rp<PREC_BF16, false>(p, stream);
     }
 }
 

@@ -159,7 +159,8 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         const std::string v(m);
         if (v == "f32") gemm_parts = 0;
         else if (v == "bf16") gemm_parts = 1;
-        else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3 or bf16");
+        else if (v == "f16") gemm_parts = 3;
+        else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3, bf16 or f16");
     }
     ws_.reset(new WeightStore(blob, gemm_parts));
     WeightStore& w = *ws_;
@@ -235,7 +236,8 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     }
     // decoder arithmetic: exact f32 MFMA (default) | split-bf16 MFMA, f32-grade | plain bf16 MFMA
     //   bf16x3 (default when every decoder channel count is a multiple of 16): split-bf16 MFMA, waveform within ~2e-6 of the f32 path
-    //   f32: exact f32 MFMA on k-major planes;  bf16: plain bf16 operands (~1e-3 waveform error)
+    //   f32: exact f32 MFMA on k-major planes;  bf16: plain bf16 operands (~9e-4 waveform error at a 0.1 peak);
+    //   f16: fp16 operands, same speed as bf16, 1.3e-4 (relative to the signal that is ~1e-3: opt-in, not the default)
     bool cl_ok = cfg_.inter % 16 == 0;
     for (const Stage& st : stages_) cl_ok = cl_ok && st.ch % 16 == 0;
     dec_mode_ = cl_ok ? 1 : 0;
@@ -243,8 +245,9 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         const std::string v(m);
         if (v == "bf16x3") dec_mode_ = 1;
         else if (v == "bf16") dec_mode_ = 2;
+        else if (v == "f16") dec_mode_ = 3;
         else if (v == "f32") dec_mode_ = 0;
-        else SBV2_REQUIRE(v.empty(), "SBV2_DECODER must be f32, bf16x3 or bf16");
+        else SBV2_REQUIRE(v.empty(), "SBV2_DECODER must be f32, bf16x3, bf16 or f16");
         SBV2_REQUIRE(dec_mode_ == 0 || cl_ok, "SBV2_DECODER: the bf16 MFMA decoder needs channel counts that are multiples of 16");
     }
     if (const char* f = getenv("SBV2_FUSE_PAIRS")) fuse_pairs_ = atoi(f) != 0;

@@ -80,6 +80,8 @@ def test_conv1d_cl_kernel(cin, cout, k, dil, L):
     np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
     got = _conv_cl_dev(x, w, b, dil, 0.1, 2)
     np.testing.assert_allclose(got, ref, atol=3e-2, rtol=0)
+    got = _conv_cl_dev(x, w, b, dil, 0.1, 3)       # fp16 operands: 8x finer than bf16
+    np.testing.assert_allclose(got, ref, atol=4e-3, rtol=0)
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,L,res", [(64, 64, 3, 1, 777, 1), (128, 128, 11, 1, 1030, 0), (256, 256, 7, 5, 515, 1),
@@ -248,7 +250,7 @@ def test_vits_full_small_utterance():
     s.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-4), ("bf16", 5e-2), ("f16", 5e-4)])
 def test_vits_decoder_cl_modes(mode, tol):
     """The channels-last bf16-MFMA decoder (SBV2_DECODER=bf16x3 | bf16) against the oracle: tiny batch + full-shape utterance."""
     os.environ["SBV2_DECODER"] = mode
