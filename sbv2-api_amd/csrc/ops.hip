@@ -210,39 +210,46 @@ __global__ __launch_bounds__(256) void k_vits_softmax(const AttnGroup* groups, f
         if (r >= 0 && r <= 2 * w) v += rks[r][tx];
         return v;
     };
-    float mx = -FLT_MAX;
+    // Two sweeps over the column instead of four (max | exp + store | scale | band): the first keeps a running maximum and the sum
+    // rescaled to it (one read), the second stores exp(s - max) / sum (one read, one write).  The kernel is HBM bound (T^2 floats per
+    // head and utterance), so this is 3 passes of traffic instead of 5.  Slices are combined in a fixed order: deterministic.
+    float mx = -FLT_MAX, sum = 0.f;
     int j = ty;
     for (; j + 12 < T; j += 16) {
         const float a = score(j), b = score(j + 4), c = score(j + 8), d = score(j + 12);
-        mx = fmaxf(fmaxf(mx, fmaxf(a, b)), fmaxf(c, d));
-    }
-    for (; j < T; j += 4) mx = fmaxf(mx, score(j));
-    red[ty][tx] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0][tx], red[1][tx]), fmaxf(red[2][tx], red[3][tx]));
-    __syncthreads();
-    float sum = 0.f;
-    j = ty;
-    for (; j + 12 < T; j += 16) {
-        const float a = expf(score(j) - mx), b = expf(score(j + 4) - mx), c = expf(score(j + 8) - mx), d = expf(score(j + 12) - mx);
-        if (ok) {
-            Sg[(size_t)j * lds] = a;
-            Sg[(size_t)(j + 4) * lds] = b;
-            Sg[(size_t)(j + 8) * lds] = c;
-            Sg[(size_t)(j + 12) * lds] = d;
+        const float m4 = fmaxf(fmaxf(a, b), fmaxf(c, d));
+        if (m4 > mx) {
+            sum *= expf(mx - m4);   // exp(-inf) = 0 on the first block
+            mx = m4;
         }
-        sum += (a + b) + (c + d);
+        sum += (expf(a - mx) + expf(b - mx)) + (expf(c - mx) + expf(d - mx));
     }
     for (; j < T; j += 4) {
-        const float a = expf(score(j) - mx);
-        if (ok) Sg[(size_t)j * lds] = a;
-        sum += a;
+        const float a = score(j);
+        if (a > mx) {
+            sum *= expf(mx - a);
+            mx = a;
+        }
+        sum += expf(a - mx);
     }
-    red[ty][tx] = sum;
+    red[ty][tx] = mx;
+    __syncthreads();
+    const float mall = fmaxf(fmaxf(red[0][tx], red[1][tx]), fmaxf(red[2][tx], red[3][tx]));
+    __syncthreads();
+    red[ty][tx] = sum * expf(mx - mall);   // a slice without rows (T < 4) contributes 0 * exp(-FLT_MAX - mall) = 0
     __syncthreads();
     const float inv = 1.0f / ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
     if (!ok) return;
-    for (j = ty; j < T; j += 4) Sg[(size_t)j * lds] *= inv;
+    j = ty;
+    for (; j + 12 < T; j += 16) {
+        const float a = expf(score(j) - mall) * inv, b = expf(score(j + 4) - mall) * inv, c = expf(score(j + 8) - mall) * inv,
+                    d = expf(score(j + 12) - mall) * inv;
+        Sg[(size_t)j * lds] = a;
+        Sg[(size_t)(j + 4) * lds] = b;
+        Sg[(size_t)(j + 8) * lds] = c;
+        Sg[(size_t)(j + 12) * lds] = d;
+    }
+    for (; j < T; j += 4) Sg[(size_t)j * lds] = expf(score(j) - mall) * inv;
     __syncthreads();
     if (ty == 0) {
         float* pw = pwin + g.aux_off;
