@@ -1,0 +1,10 @@
+# Re-collects the round's profile artifacts (run on the GPU box from the repo root): kernel stats of the bench command, and the PMC passes
+# for HBM traffic and MFMA / LDS utilisation.  Outputs land in gpurun_out/; tests/prof_summarise.py turns them into profiles/<tag>_*.
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out
+python3 bench.py --steps 8 --warmup 2 > $O/final_bench.json 2> $O/final_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/final_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/final_pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+tail -c 600 $O/final_bench.json

@@ -1,0 +1,65 @@
+"""Turns the raw rocprofv3 outputs of tests/prof_final.sh (gpurun_out/final_*) into the tracked summaries under profiles/.
+usage: python tests/prof_summarise.py <tag>      (e.g. r01i)"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1]
+P = lambda name: os.path.join(ROOT, "profiles", f"{tag}_{name}")
+
+
+def one(pattern):
+    f = sorted(glob.glob(os.path.join(G, pattern)))
+    return f[-1] if f else None
+
+
+def per_kernel(path, counters):
+    """-> {kernel: (launches, avg_us, {counter: mean per launch})} from a counter_collection.csv"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen, cnt, dur = set(), collections.Counter(), collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if r["Counter_Name"] in counters:
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            cnt[k] += 1
+            dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return {k: (cnt[k], dur[k] / cnt[k] / 1e3, {c: agg[k][c] / cnt[k] for c in counters}) for k in cnt}
+
+
+shutil.copy(os.path.join(G, "final_bench.json"), P("bench.json"))
+st = one("final_stats/*/*kernel_stats.csv")
+if st:
+    shutil.copy(st, P("bench_kernel_stats.csv"))
+fe, wr = one("final_pmc_fetch/*/*counter_collection.csv"), one("final_pmc_write/*/*counter_collection.csv")
+if fe and wr:
+    F, W = per_kernel(fe, ["FETCH_SIZE"]), per_kernel(wr, ["WRITE_SIZE"])
+    rows = ["kernel,launches,avg_us,FETCH_SIZE_KB_per_launch(raw),fetch_bytes_per_launch(x2 gfx950 correction),WRITE_SIZE_KB_per_launch,"
+            "write_bytes_per_launch,hbm_GBps"]
+    for k in sorted(F, key=lambda k: -F[k][0] * F[k][1])[:14]:
+        n, us, c = F[k]
+        fkb = c["FETCH_SIZE"]
+        wkb = W.get(k, (0, 0, {"WRITE_SIZE": 0.0}))[2]["WRITE_SIZE"]
+        fb, wb = fkb * 1024 * 2, wkb * 1024
+        rows.append(f"\"{k[:110]}\",{n},{us:.1f},{fkb:.1f},{fb:.3e},{wkb:.1f},{wb:.3e},{(fb + wb) / (us * 1e-6) / 1e9:.0f}")
+    open(P("pmc_hbm_traffic.csv"), "w").write("\n".join(rows) + "\n")
+mf = one("final_pmc_mfma/*/*counter_collection.csv")
+if mf:
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+    M = per_kernel(mf, names)
+    rows = ["kernel,launches,avg_us,MFMA_busy_cycles_per_launch,GRBM_GUI_ACTIVE_per_launch,mfma_util(busy/(1024 SIMD * GUI_ACTIVE/8)),"
+            "SQ_WAIT_ANY/SQ_WAVE_CYCLES,LDS_bank_conflict/LDS_idx_active"]
+    for k in sorted(M, key=lambda k: -M[k][0] * M[k][1])[:12]:
+        n, us, c = M[k]
+        cyc = c["GRBM_GUI_ACTIVE"] / 8
+        rows.append(f"\"{k[:110]}\",{n},{us:.1f},{c['SQ_VALU_MFMA_BUSY_CYCLES']:.3e},{c['GRBM_GUI_ACTIVE']:.3e},"
+                    f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) if cyc else 0:.3f},{c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1):.3f},"
+                    f"{c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.3f}")
+    open(P("pmc_mfma_util.csv"), "w").write("\n".join(rows) + "\n")
+print("wrote", sorted(os.path.basename(f) for f in glob.glob(P("*"))))
