@@ -1,0 +1,224 @@
+// Fused window-relative attention of the VITS encoders (attentions.MultiHeadAttention.attention, upstream style_bert_vits2;
+// same block as transformers modeling_vits.py:844-997) on k-major planes, exact f32 MFMA, online softmax:
+//
+//   s[i][j]  = (q_i . k_j + q_i . emb_rel_k[j - i + w]  (|j - i| <= w)) / sqrt(dk)
+//   p        = softmax_j(s)
+//   ctx[:, i] = sum_j p[i][j] v_j + sum_{|r| <= w} p[i][i + r] emb_rel_v[r + w]
+//
+// The unfused path (grouped GEMM S^T = K^T Q -> k_vits_softmax -> grouped GEMM V P^T -> k_vits_relv_add) writes the T x T score block
+// of every (utterance, head) to HBM and sweeps it five times; at 897 frames x 2 heads x 32 utterances x 24 flow layers that is
+// ~20 GB per step, and the block grows quadratically for long-form input (784 MB per head at 14 001 frames).  Here a wave owns
+// 32 query columns, keeps q in registers (one value per lane and k-step: exactly the B operand of v_mfma_f32_32x32x2_f32), and walks
+// the keys in tiles of 32 staged through LDS for the four waves of the workgroup:
+//
+//   S^T tile = K_tile^T Q       A = K[d][j] (row j = lane & 31, k = d),  B = q            -> 16 accumulators: rows j, column i = lane
+//   online softmax per column   (16 registers + one cross-half exchange), band scores (|j - i| <= w) kept in LDS for the emb_rel_v term
+//   ctx     += V_tile P         the accumulator registers ARE the B operand: MFMA k-step s, lane half h consumes key row
+//                               (s & 3) + 8 (s >> 2) + 4 h, which is exactly the row accumulator register s holds in half h; the A
+//                               operand reads V[d][that row] from the LDS tile (pitch 33: conflict free)
+//
+// Summation order is fixed (no atomics, no scheduling dependence): a column's result does not depend on which other utterances share
+// the batch, as the packed-batch contract requires.
+#include <cfloat>
+
+#include "common.h"
+#include "ops.h"
+
+namespace sbv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int kFaThreads = 256;
+constexpr int kFaPitch = 33;
+constexpr int kFaMaxWin = 4;
+constexpr int kFaBand = 2 * kFaMaxWin + 1;
+constexpr float kFaNegBig = -1e30f;
+
+template <int DT>
+__global__ __launch_bounds__(kFaThreads) void k_vits_flash(const AttnGroup* groups, const float* Q, const float* K, const float* V, int ld,
+                                                            float* ctx, int ldc, int dk, const float* erk, const float* erv, int w,
+                                                            float qscale) {
+    constexpr int DR = DT * 32;   // head dimension padded to whole 32-row MFMA tiles
+    constexpr int NS = DR / 2;    // k-steps of the 32x32x2 MFMA over the head dimension
+    constexpr int NP = DR / 8;    // rows of a tile each thread stages (256 threads = 8 rows x 32 columns per pass)
+    __shared__ float Kt[DR * kFaPitch], Vt[DR * kFaPitch];
+    __shared__ float erk_s[kFaBand * DR], erv_s[kFaBand * DR];
+    __shared__ float rk_s[4][kFaBand][32], band_s[4][kFaBand][32];
+
+    const AttnGroup g = groups[blockIdx.y];
+    const int T = g.T;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < T;           // wave-uniform: inactive waves only help staging
+    const int i = i0 + col;
+    const int ic = min(i, T - 1);
+    const int64_t off = (int64_t)g.head * dk * ld + g.col0;
+    const float* Qg = Q + off;
+    const float* Kg = K + off;
+    const float* Vg = V + off;
+    const int nb = 2 * w + 1;
+
+    for (int idx = tid; idx < kFaBand * DR; idx += kFaThreads) {
+        const int r = idx / DR, d = idx - r * DR;
+        const bool in = r < nb && d < dk;
+        erk_s[idx] = in ? erk[r * dk + d] : 0.f;
+        erv_s[idx] = in ? erv[r * dk + d] : 0.f;
+    }
+
+    // staging registers: thread t owns column t & 31 and rows (t >> 5) + 8 p of both tiles
+    const int sc = tid & 31, sr = tid >> 5;
+    float kreg[NP], vreg[NP];
+    auto load_tile = [&](int j0) {
+        const int jc = min(j0 + sc, T - 1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int d = min(sr + 8 * p, dk - 1);
+            kreg[p] = Kg[(int64_t)d * ld + jc];
+            vreg[p] = Vg[(int64_t)d * ld + jc];
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int d = sr + 8 * p;
+            const bool in = d < dk;
+            Kt[d * kFaPitch + sc] = in ? kreg[p] : 0.f;
+            Vt[d * kFaPitch + sc] = in ? vreg[p] : 0.f;
+        }
+    };
+    load_tile(0);
+
+    // q: one value per lane and k-step (B operand), constant over the key loop
+    float qv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int d = 2 * s + kh;
+        qv[s] = d < dk ? Qg[(int64_t)d * ld + ic] : 0.f;
+    }
+    __syncthreads();   // erk_s / erv_s
+
+    // relative-key logits of this wave's columns: rk[r][i] = qscale * q_i . emb_rel_k[r]
+    {
+        float part[kFaBand];
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < kFaBand; ++r) part[r] += qv[s] * erk_s[r * DR + 2 * s + kh];
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) {
+            const float other = __shfl_xor(part[r], 32);   // executed by every lane (not inside the select)
+            const float lo = kh ? other : part[r];          // fixed order: (even d) + (odd d) in both halves
+            const float hi = kh ? part[r] : other;
+            rk_s[wave][r][col] = (lo + hi) * qscale;
+            band_s[wave][r][col] = kFaNegBig;
+        }
+    }
+
+    f32x16 cacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[dt][r] = 0.f;
+    float m = kFaNegBig, l = 0.f;
+
+    const int ntiles = (T + 31) >> 5;
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int j0 = jt * 32;
+        store_tile();
+        __syncthreads();
+        if (jt + 1 < ntiles) load_tile(j0 + 32);   // lands behind this tile's MFMAs
+        if (active) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * s + kh) * kFaPitch + col], qv[s], sacc, 0, 0, 0);
+            const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;   // wave-uniform: the tile touches the +-w band
+            float mt = kFaNegBig;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float sv = sacc[r] * qscale;
+                if (diag) {
+                    const int rr = j - i + w;
+                    if (rr >= 0 && rr < nb && j < T) {
+                        sv += rk_s[wave][rr][col];
+                        band_s[wave][rr][col] = sv;
+                    }
+                }
+                sv = j < T ? sv : kFaNegBig;
+                sacc[r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);
+            const float alpha = expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(sacc[r] - mn);
+                sacc[r] = e;
+                ps += e;
+            }
+            {
+                const float other = __shfl_xor(ps, 32);
+                const float lo = kh ? other : ps;
+                const float hi = kh ? ps : other;
+                l = l * alpha + (lo + hi);
+            }
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int jj = (s & 3) + 8 * (s >> 2) + 4 * kh;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[(dt * 32 + col) * kFaPitch + jj], sacc[s], cacc[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // every wave is done with the tiles before they are overwritten
+    }
+    if (!active) return;
+
+    // relative-value term from the band probabilities, normalisation, store
+    const float inv = 1.0f / l;
+    float pb[kFaBand];
+#pragma unroll
+    for (int r = 0; r < kFaBand; ++r) pb[r] = expf(band_s[wave][r][col] - m) * inv;   // untouched entries: exp(-1e30 - m) = 0
+    float* Cg = ctx + (int64_t)g.head * dk * ldc + g.col0;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = cacc[dt][r] * inv;
+#pragma unroll
+            for (int b = 0; b < kFaBand; ++b) v += pb[b] * erv_s[b * DR + d];
+            if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
+        }
+}
+}  // namespace
+
+void vits_flash_attention(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, const float* V, int ld, float* ctx,
+                          int ldc, int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
+    SBV2_REQUIRE(window <= kFaMaxWin, "relative attention window larger than the compiled maximum");
+    SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
+    if (ngroups <= 0 || maxT <= 0) return;
+    const dim3 grid((maxT + 127) / 128, ngroups), block(kFaThreads);
+    if (dk <= 32) hipLaunchKernelGGL(k_vits_flash<1>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+    else if (dk <= 64) hipLaunchKernelGGL(k_vits_flash<2>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+    else hipLaunchKernelGGL(k_vits_flash<3>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sbv2

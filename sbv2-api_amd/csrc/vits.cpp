@@ -28,7 +28,7 @@ struct AttnPlan {
     double flops = 0;  // algorithmic FLOP of one grouped product over all (utterance, head) problems
 };
 
-AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int window, Arena& ar, hipStream_t stream) {
+AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int window, Arena& ar, hipStream_t stream, bool scores) {
     AttnPlan pl;
     const int dk = H / heads;
     pl.ng = lay.n * heads;
@@ -56,8 +56,10 @@ AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int wind
             s_off += (int64_t)T * pl.lds;
             w_off += (int64_t)(2 * window + 1) * pl.lds;
         }
-    pl.S = ar.array<float>((size_t)s_off);
-    pl.PW = ar.array<float>((size_t)w_off);
+    if (scores) {   // the unfused path materialises the T x T score block and the band of probabilities
+        pl.S = ar.array<float>((size_t)s_off);
+        pl.PW = ar.array<float>((size_t)w_off);
+    }
     pl.d_ag = ar.array<AttnGroup>(pl.ng);
     pl.d_st = ar.array<GemmGroup>(pl.ng);
     pl.d_pv = ar.array<GemmGroup>(pl.ng);
@@ -299,11 +301,14 @@ bool VitsModel::get_trace(const std::string& name, int utt, std::vector<float>& 
 void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, const float* spk_vec, Arena& ar) {
     const int H = x.C, heads = cfg_.heads, dk = H / heads, N = lay.L;
     const Arena::Mark mk = ar.mark();
-    const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar, stream_);
+    // SBV2_ATTN=unfused keeps the four-launch attention (grouped GEMM, softmax, grouped GEMM, relative-value add) for A/B runs
+    static const bool fused = !(getenv("SBV2_ATTN") && std::string(getenv("SBV2_ATTN")) == "unfused");
+    const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar, stream_, !fused);
     Plane Q = ar.plane(H, N), K = ar.plane(H, N), ctx = ar.plane(H, N), Y = ar.plane(H, N);
     SBV2_REQUIRE(Q.ld == x.ld, "plane pitch mismatch");
     Plane F = ar.plane(e.layers[0].ffn1.cout, N);
-    float* VT = ar.array<float>((size_t)N * H);
+    float* VT = fused ? nullptr : ar.array<float>((size_t)N * H);
+    Plane Vp = fused ? ar.plane(H, N) : Plane();
     fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);
     const float qscale = 1.0f / std::sqrt((float)dk);
     for (size_t i = 0; i < e.layers.size(); ++i) {
@@ -311,11 +316,17 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
         if ((int)i == cfg_.cond_layer_idx && spk_vec) add_segvec(x, spk_vec, H, lay.d_seg_of, 1, lay.d_mask, stream_);
         conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
         conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
-        linear_tokmajor(L.attn.v, x, VT, H, stream_);
-        grouped_gemm(K.p, K.ld, Q.p, Q.ld, pl.S, pl.lds, pl.d_st, pl.ng, pl.maxT, pl.maxT, qscale, pl.flops, stream_);
-        vits_softmax(pl.d_ag, pl.ng, pl.maxT, pl.S, Q.p, Q.ld, dk, L.attn.erk, cfg_.window, qscale, pl.PW, stream_);
-        grouped_gemm(VT, H, pl.S, pl.lds, ctx.p, ctx.ld, pl.d_pv, pl.ng, dk, pl.maxT, 1.0f, pl.flops, stream_);
-        vits_relv_add(pl.d_ag, pl.ng, pl.maxT, ctx.p, ctx.ld, dk, L.attn.erv, cfg_.window, pl.PW, stream_);
+        if (fused) {
+            conv_plain(L.attn.v, x, Vp, 1, 0, nullptr, 1, stream_);
+            vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
+                                 stream_);
+        } else {
+            linear_tokmajor(L.attn.v, x, VT, H, stream_);
+            grouped_gemm(K.p, K.ld, Q.p, Q.ld, pl.S, pl.lds, pl.d_st, pl.ng, pl.maxT, pl.maxT, qscale, pl.flops, stream_);
+            vits_softmax(pl.d_ag, pl.ng, pl.maxT, pl.S, Q.p, Q.ld, dk, L.attn.erk, cfg_.window, qscale, pl.PW, stream_);
+            grouped_gemm(VT, H, pl.S, pl.lds, ctx.p, ctx.ld, pl.d_pv, pl.ng, dk, pl.maxT, 1.0f, pl.flops, stream_);
+            vits_relv_add(pl.d_ag, pl.ng, pl.maxT, ctx.p, ctx.ld, dk, L.attn.erv, cfg_.window, pl.PW, stream_);
+        }
         conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
         layernorm_ch(Y, x, L.n1g, L.n1b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
         const int k = L.ffn1.k;
