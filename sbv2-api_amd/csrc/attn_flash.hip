@@ -36,7 +36,7 @@ constexpr int kFaBand = 2 * kFaMaxWin + 1;
 constexpr float kFaNegBig = -1e30f;
 
 template <int DT>
-__global__ __launch_bounds__(kFaThreads) void k_vits_flash(const AttnGroup* groups, const float* Q, const float* K, const float* V, int ld,
+__global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_vits_flash(const AttnGroup* groups, const float* Q, const float* K, const float* V, int ld,
                                                             float* ctx, int ldc, int dk, const float* erk, const float* erv, int w,
                                                             float qscale) {
     constexpr int DR = DT * 32;   // head dimension padded to whole 32-row MFMA tiles
@@ -93,24 +93,21 @@ __global__ __launch_bounds__(kFaThreads) void k_vits_flash(const AttnGroup* grou
     };
     load_tile(0);
 
-    // q: one value per lane and k-step (B operand), constant over the key loop
-    float qv[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int d = 2 * s + kh;
-        qv[s] = d < dk ? Qg[(int64_t)d * ld + ic] : 0.f;
-    }
     __syncthreads();   // erk_s / erv_s
 
-    // relative-key logits of this wave's columns: rk[r][i] = qscale * q_i . emb_rel_k[r]
+    // relative-key logits of this wave's columns: rk[r][i] = qscale * q_i . emb_rel_k[r].  A rolled loop that re-reads q from the
+    // cache (once per workgroup): fully unrolled on the register copy of q it cost 250 VGPRs + AGPR spills and halved the occupancy.
     {
         float part[kFaBand];
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
+#pragma unroll 2
+        for (int s = 0; s < NS; ++s) {
+            const int d = 2 * s + kh;
+            const float qd = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int r = 0; r < kFaBand; ++r) part[r] += qv[s] * erk_s[r * DR + 2 * s + kh];
+            for (int r = 0; r < kFaBand; ++r) part[r] += qd * erk_s[r * DR + d];
+        }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
             const float other = __shfl_xor(part[r], 32);   // executed by every lane (not inside the select)
@@ -119,6 +116,14 @@ __global__ __launch_bounds__(kFaThreads) void k_vits_flash(const AttnGroup* grou
             rk_s[wave][r][col] = (lo + hi) * qscale;
             band_s[wave][r][col] = kFaNegBig;
         }
+    }
+
+    // q: one value per lane and k-step (B operand), constant over the key loop
+    float qv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int d = 2 * s + kh;
+        qv[s] = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
     }
 
     f32x16 cacc[DT];
