@@ -46,6 +46,39 @@ PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
     return pc;
 }
 
+// Several 1x1 convolutions of the same input as ONE product: rows are the concatenated output channels (q | k | v projections of an
+// attention layer: one launch with 3x the rows instead of three under-filled ones).  f32 MFMA packing only.
+PackedConv WeightStore::conv_cat(const std::vector<std::string>& prefixes) {
+    PackedConv pc;
+    pc.k = 1;
+    std::vector<const HostTensor*> ts;
+    for (const auto& pre : prefixes) {
+        const HostTensor& t = blob_.get(pre + ".weight");
+        SBV2_REQUIRE(t.dims.size() == 3 && t.dims[2] == 1, "conv_cat: 1x1 conv weights only: " + pre);
+        SBV2_REQUIRE(ts.empty() || t.dims[1] == ts[0]->dims[1], "conv_cat: input channel mismatch: " + pre);
+        ts.push_back(&t);
+        pc.cout += (int)t.dims[0];
+    }
+    pc.cin = (int)ts[0]->dims[1];
+    pc.lda = round_up(pc.cout, 4);
+    std::vector<float> h((size_t)pc.cin * pc.lda, 0.f), b((size_t)pc.cout, 0.f);
+    int row0 = 0;
+    for (size_t n = 0; n < ts.size(); ++n) {
+        const HostTensor& t = *ts[n];
+        const int co_n = (int)t.dims[0];
+        for (int co = 0; co < co_n; ++co)
+            for (int ci = 0; ci < pc.cin; ++ci) h[(size_t)ci * pc.lda + row0 + co] = t.data[(size_t)co * pc.cin + ci];
+        if (blob_.has(prefixes[n] + ".bias")) {
+            const HostTensor& bt = blob_.get(prefixes[n] + ".bias");
+            for (int co = 0; co < co_n; ++co) b[row0 + co] = bt.data[co];
+        }
+        row0 += co_n;
+    }
+    pc.w = upload(h.data(), h.size());
+    pc.bias = upload(b.data(), b.size());
+    return pc;
+}
+
 PackedConv WeightStore::linear(const std::string& prefix) {
     const HostTensor& t = blob_.get(prefix + ".weight");
     SBV2_REQUIRE(t.dims.size() == 2, "linear weight must be [out][in]: " + prefix);

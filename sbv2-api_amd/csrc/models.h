@@ -68,6 +68,7 @@ class WeightStore {
     float* upload(const float* host, size_t n);
     float* tensor(const std::string& name);                      // raw copy
     PackedConv conv(const std::string& prefix, bool bias = true);  // <prefix>.weight [Cout][Cin][k] (+ .bias)
+    PackedConv conv_cat(const std::vector<std::string>& prefixes);  // 1x1 convs of one input stacked along Cout
     PackedConv linear(const std::string& prefix);                // <prefix>.weight [Cout][Cin] + .bias
     PackedUpsample upsample(const std::string& prefix, int stride, int padding);  // weight [Cin][Cout][k]
     size_t bytes() const { return bytes_; }
@@ -184,6 +185,7 @@ class VitsModel {
   private:
     struct Attn {
         PackedConv q, k, v, o;
+        PackedConv qkv;   // rows q | k | v: one launch for the three projections (fused attention path)
         float *erk, *erv;
     };
     struct EncLayer {

@@ -100,6 +100,7 @@ VitsModel::Encoder VitsModel::load_encoder(const std::string& p, int n_layers) {
         L.attn.k = ws_->conv(a + "conv_k");
         L.attn.v = ws_->conv(a + "conv_v");
         L.attn.o = ws_->conv(a + "conv_o");
+        L.attn.qkv = ws_->conv_cat({a + "conv_q", a + "conv_k", a + "conv_v"});
         L.attn.erk = ws_->tensor(a + "emb_rel_k");
         L.attn.erv = ws_->tensor(a + "emb_rel_v");
         L.n1g = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".gamma");
@@ -304,23 +305,24 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     // SBV2_ATTN=unfused keeps the four-launch attention (grouped GEMM, softmax, grouped GEMM, relative-value add) for A/B runs
     static const bool fused = !(getenv("SBV2_ATTN") && std::string(getenv("SBV2_ATTN")) == "unfused");
     const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar, stream_, !fused);
-    Plane Q = ar.plane(H, N), K = ar.plane(H, N), ctx = ar.plane(H, N), Y = ar.plane(H, N);
+    Plane QKV = ar.plane(3 * H, N);
+    Plane Q = QKV.rows(0, H), K = QKV.rows(H, H), ctx = ar.plane(H, N), Y = ar.plane(H, N);
     SBV2_REQUIRE(Q.ld == x.ld, "plane pitch mismatch");
     Plane F = ar.plane(e.layers[0].ffn1.cout, N);
     float* VT = fused ? nullptr : ar.array<float>((size_t)N * H);
-    Plane Vp = fused ? ar.plane(H, N) : Plane();
+    Plane Vp = QKV.rows(2 * H, H);
     fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);
     const float qscale = 1.0f / std::sqrt((float)dk);
     for (size_t i = 0; i < e.layers.size(); ++i) {
         const EncLayer& L = e.layers[i];
         if ((int)i == cfg_.cond_layer_idx && spk_vec) add_segvec(x, spk_vec, H, lay.d_seg_of, 1, lay.d_mask, stream_);
-        conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
-        conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
         if (fused) {
-            conv_plain(L.attn.v, x, Vp, 1, 0, nullptr, 1, stream_);
+            conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
             vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
                                  stream_);
         } else {
+            conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
+            conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
             linear_tokmajor(L.attn.v, x, VT, H, stream_);
             grouped_gemm(K.p, K.ld, Q.p, Q.ld, pl.S, pl.lds, pl.d_st, pl.ng, pl.maxT, pl.maxT, qscale, pl.flops, stream_);
             vits_softmax(pl.d_ag, pl.ng, pl.maxT, pl.S, Q.p, Q.ld, dk, L.attn.erk, cfg_.window, qscale, pl.PW, stream_);
