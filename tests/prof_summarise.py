@@ -14,8 +14,8 @@ P = lambda name: os.path.join(ROOT, "profiles", f"{tag}_{name}")
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(G, pattern)))
-    return f[-1] if f else None
+    f = glob.glob(os.path.join(G, pattern))
+    return max(f, key=os.path.getmtime) if f else None   # gpurun_out/ accumulates: take the newest run
 
 
 def per_kernel(path, counters):
