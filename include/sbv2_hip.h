@@ -50,8 +50,8 @@ void sbv2_vits_destroy(sbv2_vits* h);
 int64_t sbv2_vits_hop(const sbv2_vits* h);       /* samples per frame (512) */
 int64_t sbv2_vits_bert_dim(const sbv2_vits* h);  /* 1024 */
 int64_t sbv2_vits_style_dim(const sbv2_vits* h); /* 256 */
-/* Decoder arithmetic chosen at create time (env SBV2_DECODER = f32 | bf16x3 | bf16): 0 = exact f32 MFMA, 1 = split-bf16 MFMA
- * (hi/lo operands, f32-grade, default), 2 = plain bf16 MFMA. */
+/* Decoder arithmetic chosen at create time (env SBV2_DECODER = f32 | bf16x3 | bf16 | f16): 0 = exact f32 MFMA, 1 = split-bf16 MFMA
+ * (hi/lo operands, f32-grade, default), 2 = plain bf16 MFMA, 3 = fp16 MFMA operands. */
 int sbv2_vits_decoder_mode(const sbv2_vits* h);
 
 /* ---- model::synthesize(session, bert_ori, x_tst, sid, tones, lang_ids, style_vector, sdp_ratio, length_scale,

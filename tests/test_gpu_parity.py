@@ -370,6 +370,34 @@ def test_orchestrator_request_tiny():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_cpp_host_mirror(tmp_path):
+    """include/sbv2_core.hpp (C++ mirror of model.rs / bert.rs: load_model, predict, synthesize, Error) through a plain g++ program
+    linked against the C ABI only: same results as the oracle, errors surface as exceptions with the library's message."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "sbv2_core_demo")
+    assert os.path.exists(exe), "tests/cpp/sbv2_core_demo is built by sbv2-api_amd/csrc/Makefile (__graft_entry__.build())"
+    bc, bw = weights("bert", "tiny", 3)
+    vc, vw = weights("vits", "tiny", 5)
+    u = make_utts([8], bc, vc, seed0=77, with_bert=False)[0]
+    h = O.deberta_forward(bw, bc, u["input_ids"])
+    bert_ori = O.expand_bert_features(h, u["word2ph"])
+    d = str(tmp_path)
+    open(os.path.join(d, "bert.blob"), "wb").write(blob("bert", "tiny", 3))
+    open(os.path.join(d, "vits.blob"), "wb").write(blob("vits", "tiny", 5))
+    for name, arr, dt in (("ids.i64", u["input_ids"], "<i8"), ("mask.i64", np.ones_like(u["input_ids"]), "<i8"), ("x.i64", u["phones"], "<i8"),
+                          ("tones.i64", u["tones"], "<i8"), ("langs.i64", u["langs"], "<i8"), ("style.f32", u["style"], "<f4"),
+                          ("bertori.f32", bert_ori, "<f4")):
+        np.ascontiguousarray(arr).astype(dt).tofile(os.path.join(d, name))
+    r = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got_h = np.fromfile(os.path.join(d, "predict.f32"), "<f4").reshape(len(u["input_ids"]), bc["hidden"])
+    np.testing.assert_allclose(got_h, h, atol=5e-5, rtol=0)
+    ref = O.vits_forward(vw, vc, bert_ori, u["phones"], u["tones"], u["langs"], 0, u["style"])
+    got = np.fromfile(os.path.join(d, "pcm.f32"), "<f4")
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=2e-4, rtol=0)
+
+
 def test_edge_cases_tiny(vits_tiny, bert_tiny):
     """Smallest inputs the front end can produce and the degenerate duration case (sum(w_ceil) == 0 -> clamp_min(1) frame)."""
     cfg, W = weights("vits", "tiny", 5)
