@@ -251,27 +251,7 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s) {
     SBV2_REQUIRE(w.k == 1 && x.C == w.cin, "token-major linear: shape mismatch");
-    if (false && w.cl.parts && (w.cout & 3) == 0 && (ldy & 3) == 0) {  // k-major plane in, token-major out: 1x1, see conv_plain
-        ConvClParams q;
-        q.X = x.p;
-        q.ldx = x.ld;
-        q.NB = x.L;
-        q.W = w.cl.w;
-        q.nmt = w.cl.nmt;
-        q.tm = w.cl.tm;
-        q.split = w.cl.parts == 2;
-        q.f16 = w.cl.parts == 3;
-        q.M = w.cout;
-        q.N = x.L;
-        q.K = w.cin;
-        q.Y = y;
-        q.ldy = ldy;
-        q.bias = w.bias;
-        q.in_km = 1;
-        q.out_km = 0;
-        launch_conv_cl(q, s);
-        return;
-    }
+    // (the bf16 matrix-core variant of this 1x1 product was measured slower than the f32 kernel: see conv_plain)
     ConvParams p;
     p.A = x.p;  // A[k = cin][m = token]
     p.lda = x.ld;

@@ -154,9 +154,10 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(cfg_.inter % 8 == 0, "flow channels must be a multiple of 8");
     SBV2_REQUIRE(cfg_.res_dilations.size() == cfg_.res_kernels.size(), "resblock config mismatch");
 
-    // GEMM / conv arithmetic outside the decoder: exact f32 MFMA (default) | split-bf16 | plain bf16 through the k-major variant of
-    // conv_cl.hip.  Measured on MI355X (round 1): the k-major variant transposes while staging (32 ds_write_b16 per thread and
-    // chunk) and reaches only ~48 TFLOP/s on these 1x1 shapes, slower than the f32 MFMA kernel, so it is opt-in only.
+    // Arithmetic of the k >= 3 convolutions outside the decoder, i.e. the flow's k = 5 FFN convs (SBV2_GEMM): split-bf16 through the
+    // k-major variant of conv_cl.hip by default (203 TFLOP/s algorithmic against ~60 for the f32 MFMA kernel on those shapes), or
+    // f32 | bf16 | f16.  1x1 products always stay on the f32 MFMA kernel: the k-major variant transposes while staging and a 1x1 has too
+    // few MFMAs per chunk to pay for it (~48 TFLOP/s measured).
     int gemm_parts = 2;
     if (const char* m = getenv("SBV2_GEMM")) {
         const std::string v(m);
