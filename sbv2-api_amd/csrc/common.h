@@ -221,6 +221,7 @@ struct ResPairParams {
     int accumulate = 0;
     const unsigned char* mask = nullptr;
     int mask_div = 1;
+    int mask_shift = -1;   // set by launch_respair_cl
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
 

@@ -131,28 +131,44 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
             }
         }
     };
+    // software-pipelined over the taps (two fragment sets, static ping-pong as in conv_cl.hip): the LDS reads of tap t+1 are in
+    // flight while the MFMAs of tap t issue, instead of one exposed LDS round trip per tap
+    struct Frags {
+        ex8 bh[TN], bl[TN], ah, al;
+    };
     auto mfma_chunk = [&](const char* bhi, const char* blo, int tap_stride) {
-        for (int tap = 0; tap < ntaps; ++tap) {
-            ex8 bh[TN], bl[TN], ah, al;
+        auto load_frags = [&](Frags& f, int tap) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lcol + tap * tap_stride;
                 const int off = row * 32 + (((lh ^ (row >> 3)) & 1) << 4);
-                bh[j] = *reinterpret_cast<const ex8*>(bhi + off);
-                if (SPLIT) bl[j] = *reinterpret_cast<const ex8*>(blo + off);
+                f.bh[j] = *reinterpret_cast<const ex8*>(bhi + off);
+                if (SPLIT) f.bl[j] = *reinterpret_cast<const ex8*>(blo + off);
             }
             const char* blk = wsm + (tap * PARTS) * 1024 + lane * 16;
-            ah = *reinterpret_cast<const ex8*>(blk);
-            if (SPLIT) al = *reinterpret_cast<const ex8*>(blk + 1024);
+            f.ah = *reinterpret_cast<const ex8*>(blk);
+            if (SPLIT) f.al = *reinterpret_cast<const ex8*>(blk + 1024);
+        };
+        auto mfma_frags = [&](const Frags& f) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (SPLIT) {
-                    acc[j] = rp_mfma(al, bh[j], acc[j]);
-                    acc[j] = rp_mfma(ah, bl[j], acc[j]);
+                    acc[j] = rp_mfma(f.al, f.bh[j], acc[j]);
+                    acc[j] = rp_mfma(f.ah, f.bl[j], acc[j]);
                 }
-                acc[j] = rp_mfma(ah, bh[j], acc[j]);
+                acc[j] = rp_mfma(f.ah, f.bh[j], acc[j]);
             }
+        };
+        Frags fa, fb;
+        load_frags(fa, 0);
+        int tap = 0;
+        for (; tap + 2 <= ntaps; tap += 2) {
+            load_frags(fb, tap + 1);
+            mfma_frags(fa);
+            load_frags(fa, min(tap + 2, ntaps - 1));
+            mfma_frags(fb);
         }
+        if (tap < ntaps) mfma_frags(fa);
     };
 
     // ---- phase 1: t = lrelu(conv1(lrelu(y)) + b1) on positions [t0, t0 + 256) -> LDS ----------------------------------------
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
                 const int row = wn0 + j * 32 + lcol;
                 const int pos = t0 + row;
                 bool keep = pos >= 0 && pos < NB;
-                if (keep && p.mask) keep = p.mask[pos / p.mask_div] != 0;
+                if (keep && p.mask) keep = p.mask[p.mask_shift >= 0 ? (pos >> p.mask_shift) : (pos / p.mask_div)] != 0;
                 f32x4v v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += old[e];
         }
-        if (p.mask && !p.mask[pos / p.mask_div]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (p.mask && !p.mask[p.mask_shift >= 0 ? (pos >> p.mask_shift) : (pos / p.mask_div)]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
         *dst = v;
     }
     if (!next_tile) break;
@@ -317,7 +333,13 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     }
 }
 
-void launch_respair_cl(const ResPairParams& p, hipStream_t stream) {
+void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
+    ResPairParams p = p0;
+    p.mask_shift = -1;   // the column mask is indexed by position / upsampling factor: a shift when that is a power of two
+    if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
+        p.mask_shift = 0;
+        while ((1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
+    }
     SBV2_REQUIRE(p.C == 16 || p.C == 32, "respair: only the 16- and 32-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
