@@ -59,7 +59,9 @@ void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamm
 // ------------------------------------------------------------------------------------------------
 // Channel LayerNorm over a plane: 32 columns x 8 channel groups per workgroup
 // ------------------------------------------------------------------------------------------------
-template <bool DW>
+// CPT > 0: every thread keeps its <= CPT channel values in registers, so the plane is read once (the value is needed three times: mean,
+// centred sum of squares, output); CPT == 0: generic fallback that re-reads it.  Same operations in the same order either way.
+template <bool DW, int CPT>
 __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps,
                                                        int act, const float* res, int ldr, const unsigned char* mask,
                                                        const float* dw_w, const float* dw_b, int dil) {
@@ -67,21 +69,36 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + tx;
     const bool ok = n < in.L;
+    const int nc = ok ? n : in.L - 1;
     const int C = in.C;
     auto val = [&](int c) -> float {
-        if (!DW) return in.p[(size_t)c * in.ld + n];
+        if (!DW) return in.p[(size_t)c * in.ld + nc];
         const float* r = in.p + (size_t)c * in.ld;
         float v = dw_b[c];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int q = n + (j - 1) * dil;
+            const int q = nc + (j - 1) * dil;
             if (q >= 0 && q < in.L) v += dw_w[c * 3 + j] * r[q];
         }
         return v;
     };
+    constexpr int NV = CPT > 0 ? CPT : 1;
+    float xv[NV];
+    if (CPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = ty + 8 * k;
+            xv[k] = c < C ? val(c) : 0.f;
+        }
+    }
     float s = 0.f;
-    if (ok)
+    if (CPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (ty + 8 * k < C) s += xv[k];
+    } else {
         for (int c = ty; c < C; c += 8) s += val(c);
+    }
     red[ty][tx] = s;
     __syncthreads();
     float mean = 0.f;
@@ -90,11 +107,19 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     mean /= C;
     __syncthreads();
     float q = 0.f;
-    if (ok)
+    if (CPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (ty + 8 * k < C) {
+                const float d = xv[k] - mean;
+                q += d * d;
+            }
+    } else {
         for (int c = ty; c < C; c += 8) {
             const float d = val(c) - mean;
             q += d * d;
         }
+    }
     red[ty][tx] = q;
     __syncthreads();
     float var = 0.f;
@@ -103,23 +128,39 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     const float rstd = 1.0f / sqrtf(var / C + eps);
     if (!ok) return;
     const bool keep = !mask || mask[n];
-    for (int c = ty; c < C; c += 8) {
-        float v = (val(c) - mean) * rstd * gamma[c] + beta[c];
+    auto emit = [&](int c, float x) {
+        float v = (x - mean) * rstd * gamma[c] + beta[c];
         if (act == ACT_GELU) v = gelu_exact(v);
         if (res) v += res[(size_t)c * ldr + n];
         out.p[(size_t)c * out.ld + n] = keep ? v : 0.f;
+    };
+    if (CPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (ty + 8 * k < C) emit(ty + 8 * k, xv[k]);
+    } else {
+        for (int c = ty; c < C; c += 8) emit(c, val(c));
     }
+}
+template <bool DW>
+static void launch_layernorm(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
+                             const unsigned char* mask, const float* w, const float* b, int dil, hipStream_t s) {
+    const dim3 grid((in.L + 31) / 32), block(256);
+    const int cpt = (in.C + 7) / 8;
+    if (cpt <= 8) hipLaunchKernelGGL((k_layernorm_ch<DW, 8>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else if (cpt <= 24) hipLaunchKernelGGL((k_layernorm_ch<DW, 24>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else if (cpt <= 32) hipLaunchKernelGGL((k_layernorm_ch<DW, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else if (cpt <= 128) hipLaunchKernelGGL((k_layernorm_ch<DW, 128>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else hipLaunchKernelGGL((k_layernorm_ch<DW, 0>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
 }
 void layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
                   const unsigned char* mask, hipStream_t s) {
-    hipLaunchKernelGGL(k_layernorm_ch<false>, dim3((in.L + 31) / 32), dim3(256), 0, s, in, out, gamma, beta, eps, act, res, ldr,
-                       mask, nullptr, nullptr, 1);
+    launch_layernorm<false>(in, out, gamma, beta, eps, act, res, ldr, mask, nullptr, nullptr, 1, s);
 }
 void dds_dw_ln_gelu(Plane in, Plane out, const float* w, const float* b, int dil, const float* gamma, const float* beta,
                     const unsigned char* mask, hipStream_t s) {
     SBV2_REQUIRE(in.p != out.p, "depthwise conv cannot run in place");
-    hipLaunchKernelGGL(k_layernorm_ch<true>, dim3((in.L + 31) / 32), dim3(256), 0, s, in, out, gamma, beta, 1e-5f, (int)ACT_GELU,
-                       nullptr, 0, mask, w, b, dil);
+    launch_layernorm<true>(in, out, gamma, beta, 1e-5f, (int)ACT_GELU, nullptr, 0, mask, w, b, dil, s);
 }
 
 // ------------------------------------------------------------------------------------------------
