@@ -57,17 +57,18 @@ void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamm
 }
 
 // ------------------------------------------------------------------------------------------------
-// Channel LayerNorm over a plane: 32 columns x 8 channel groups per workgroup
+// Channel LayerNorm over a plane: COLS columns x 256 / COLS channel groups per workgroup
 // ------------------------------------------------------------------------------------------------
 // CPT > 0: every thread keeps its <= CPT channel values in registers, so the plane is read once (the value is needed three times: mean,
 // centred sum of squares, output); CPT == 0: generic fallback that re-reads it.  Same operations in the same order either way.
-template <bool DW, int CPT>
+template <bool DW, int CPT, int COLS>
 __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps,
                                                        int act, const float* res, int ldr, const unsigned char* mask,
                                                        const float* dw_w, const float* dw_b, int dil) {
-    __shared__ float red[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int n = blockIdx.x * 32 + tx;
+    constexpr int G = 256 / COLS;   // channel groups: thread (tx, ty) owns column tx and channels ty, ty + G, ...
+    __shared__ float red[G][COLS + 1];
+    const int tx = threadIdx.x % COLS, ty = threadIdx.x / COLS;
+    const int n = blockIdx.x * COLS + tx;
     const bool ok = n < in.L;
     const int nc = ok ? n : in.L - 1;
     const int C = in.C;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     if (CPT > 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int c = ty + 8 * k;
+            const int c = ty + G * k;
             xv[k] = c < C ? val(c) : 0.f;
         }
     }
@@ -95,27 +96,27 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     if (CPT > 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k)
-            if (ty + 8 * k < C) s += xv[k];
+            if (ty + G * k < C) s += xv[k];
     } else {
-        for (int c = ty; c < C; c += 8) s += val(c);
+        for (int c = ty; c < C; c += G) s += val(c);
     }
     red[ty][tx] = s;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) mean += red[g][tx];
+    for (int g = 0; g < G; ++g) mean += red[g][tx];
     mean /= C;
     __syncthreads();
     float q = 0.f;
     if (CPT > 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k)
-            if (ty + 8 * k < C) {
+            if (ty + G * k < C) {
                 const float d = xv[k] - mean;
                 q += d * d;
             }
     } else {
-        for (int c = ty; c < C; c += 8) {
+        for (int c = ty; c < C; c += G) {
             const float d = val(c) - mean;
             q += d * d;
         }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) var += red[g][tx];
+    for (int g = 0; g < G; ++g) var += red[g][tx];
     const float rstd = 1.0f / sqrtf(var / C + eps);
     if (!ok) return;
     const bool keep = !mask || mask[n];
@@ -137,21 +138,27 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     if (CPT > 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k)
-            if (ty + 8 * k < C) emit(ty + 8 * k, xv[k]);
+            if (ty + G * k < C) emit(ty + G * k, xv[k]);
     } else {
-        for (int c = ty; c < C; c += 8) emit(c, val(c));
+        for (int c = ty; c < C; c += G) emit(c, val(c));
     }
 }
 template <bool DW>
 static void launch_layernorm(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
                              const unsigned char* mask, const float* w, const float* b, int dil, hipStream_t s) {
-    const dim3 grid((in.L + 31) / 32), block(256);
+    const dim3 block(256);
+    // few, wide columns (DeBERTa: 1024 channels x ~2k tokens): 8 columns x 32 channel groups per workgroup, or the grid is 64 workgroups
+    if (!DW && in.C >= 512 && in.L <= 8192 && in.C <= 32 * 32) {
+        hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 8>), dim3((in.L + 7) / 8), block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+        return;
+    }
+    const dim3 grid((in.L + 31) / 32);
     const int cpt = (in.C + 7) / 8;
-    if (cpt <= 8) hipLaunchKernelGGL((k_layernorm_ch<DW, 8>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else if (cpt <= 24) hipLaunchKernelGGL((k_layernorm_ch<DW, 24>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else if (cpt <= 32) hipLaunchKernelGGL((k_layernorm_ch<DW, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else if (cpt <= 128) hipLaunchKernelGGL((k_layernorm_ch<DW, 128>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else hipLaunchKernelGGL((k_layernorm_ch<DW, 0>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    if (cpt <= 8) hipLaunchKernelGGL((k_layernorm_ch<DW, 8, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else if (cpt <= 24) hipLaunchKernelGGL((k_layernorm_ch<DW, 24, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else if (cpt <= 32) hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else if (cpt <= 128) hipLaunchKernelGGL((k_layernorm_ch<DW, 128, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    else hipLaunchKernelGGL((k_layernorm_ch<DW, 0, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
 }
 void layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
                   const unsigned char* mask, hipStream_t s) {
