@@ -427,8 +427,8 @@ static void launch_cl_layout(const ClKernelParams& kp, hipStream_t stream) {
         if (p.out_km) launch_cl<TM, PREC, true, true>(kp, stream);
         else launch_cl<TM, PREC, true, false>(kp, stream);
     } else {
-        SBV2_REQUIRE(!p.out_km, "conv_cl: channels-last input with k-major output is not instantiated");
-        launch_cl<TM, PREC, false, false>(kp, stream);
+        if (p.out_km) launch_cl<TM, PREC, false, true>(kp, stream);
+        else launch_cl<TM, PREC, false, false>(kp, stream);
     }
 }
 

@@ -249,6 +249,64 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
     launch_conv(p, s);
 }
 
+// The two halves of a conv -> activation -> conv pair whose wide intermediate stays channels-last (the encoders' FFN: 192 -> 768 -> 192):
+// the k-major <-> fragment transposition of conv_cl.hip's k-major variant is then paid on the narrow side only, the wide tensor is
+// written by the full-line channels-last epilogue and read back by the full-line staging.  Both return false (nothing launched) when
+// the weights carry no matrix-core fragments or the shapes do not fit, and the caller falls back to conv_plain.
+static void fill_cl(ConvClParams& q, const PackedConv& w, int dil, int pad_l, const unsigned char* mask, int mask_div) {
+    q.W = w.cl.w;
+    q.nmt = w.cl.nmt;
+    q.tm = w.cl.tm;
+    q.split = w.cl.parts == 2;
+    q.f16 = w.cl.parts == 3;
+    q.M = w.cout;
+    q.K = w.cin;
+    q.ntaps = w.k;
+    for (int j = 0; j < w.k; ++j) q.shift[j] = j * dil - pad_l;
+    q.bias = w.bias;
+    q.mask = mask;
+    q.mask_div = mask_div;
+}
+bool conv_km_to_cl(const PackedConv& w, Plane x, float* y, int ldy, int dil, int pad_l, const unsigned char* mask, int mask_div,
+                   hipStream_t s) {
+    if (!w.cl.parts || w.k < 3 || (w.cout & 15) || (ldy & 3)) return false;
+    SBV2_REQUIRE(x.C == w.cin, "conv channel mismatch");
+    ConvClParams q;
+    fill_cl(q, w, dil, pad_l, mask, mask_div);
+    q.X = x.p;
+    q.ldx = x.ld;
+    q.NB = x.L;
+    q.N = x.L;
+    q.Y = y;
+    q.ldy = ldy;
+    q.in_km = 1;
+    q.out_km = 0;
+    launch_conv_cl(q, s);
+    return true;
+}
+bool conv_cl_to_km(const PackedConv& w, const float* x, int ldx, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div,
+                   hipStream_t s, float pre_slope, const Plane* res) {
+    if (!w.cl.parts || w.k < 3 || (w.cin & 15) || (ldx & 3)) return false;
+    SBV2_REQUIRE(y.C == w.cout, "conv channel mismatch");
+    ConvClParams q;
+    fill_cl(q, w, dil, pad_l, mask, mask_div);
+    q.X = x;
+    q.ldx = ldx;
+    q.NB = y.L;
+    q.N = y.L;
+    q.Y = y.p;
+    q.ldy = y.ld;
+    if (res) {
+        q.R = res->p;
+        q.ldr = res->ld;
+    }
+    q.pre_slope = pre_slope;
+    q.in_km = 0;
+    q.out_km = 1;
+    launch_conv_cl(q, s);
+    return true;
+}
+
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s) {
     SBV2_REQUIRE(w.k == 1 && x.C == w.cin, "token-major linear: shape mismatch");
     // (the bf16 matrix-core variant of this 1x1 product was measured slower than the f32 kernel: see conv_plain)

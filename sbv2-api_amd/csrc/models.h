@@ -86,6 +86,10 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
                 int act = ACT_NONE, float pre_slope = 1.0f, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f,
                 int accumulate = 0);
 // y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
+bool conv_km_to_cl(const PackedConv& w, Plane x, float* y, int ldy, int dil, int pad_l, const unsigned char* mask, int mask_div,
+                   hipStream_t s);
+bool conv_cl_to_km(const PackedConv& w, const float* x, int ldx, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div,
+                   hipStream_t s, float pre_slope, const Plane* res);
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s);
 
 struct BertConfig {

@@ -310,6 +310,10 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     Plane Q = QKV.rows(0, H), K = QKV.rows(H, H), ctx = ar.plane(H, N), Y = ar.plane(H, N);
     SBV2_REQUIRE(Q.ld == x.ld, "plane pitch mismatch");
     Plane F = ar.plane(e.layers[0].ffn1.cout, N);
+    static const bool cl_ffn = !(getenv("SBV2_FFN") && std::string(getenv("SBV2_FFN")) == "km");   // A/B knob
+    const PackedConv& f1 = e.layers[0].ffn1;
+    const PackedConv& f2 = e.layers[0].ffn2;
+    float* Fcl = (cl_ffn && f1.cl.parts && f2.cl.parts && f1.k >= 3 && f2.k >= 3 && (f1.cout & 15) == 0) ? ar.array<float>((size_t)N * f1.cout) : nullptr;
     float* VT = fused ? nullptr : ar.array<float>((size_t)N * H);
     Plane Vp = QKV.rows(2 * H, H);
     fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);
@@ -333,8 +337,15 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
         conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
         layernorm_ch(Y, x, L.n1g, L.n1b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
         const int k = L.ffn1.k;
-        conv_plain(L.ffn1, x, F, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_RELU);
-        conv_plain(L.ffn2, F, Y, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_NONE, 1.0f, &x);
+        // FFN: conv_1 -> ReLU -> conv_2 (+ x).  On the matrix-core path the 768-channel intermediate stays channels-last and the ReLU is
+        // conv_2's pre-activation (leaky slope 0); otherwise (exact-f32 text side) both convs run on k-major planes.
+        const int Fc = L.ffn1.cout;
+        if (Fcl && conv_km_to_cl(L.ffn1, x, Fcl, Fc, 1, (k - 1) / 2, lay.d_mask, 1, stream_)) {
+            SBV2_REQUIRE(conv_cl_to_km(L.ffn2, Fcl, Fc, Y, 1, (k - 1) / 2, lay.d_mask, 1, stream_, 0.0f, &x), "FFN: conv_2 has no matrix-core path");
+        } else {
+            conv_plain(L.ffn1, x, F, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_RELU);
+            conv_plain(L.ffn2, F, Y, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_NONE, 1.0f, &x);
+        }
         layernorm_ch(Y, x, L.n2g, L.n2b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
     }
     ar.rewind(mk);
