@@ -53,6 +53,9 @@ int64_t sbv2_vits_style_dim(const sbv2_vits* h); /* 256 */
 /* Decoder arithmetic chosen at create time (env SBV2_DECODER = f32 | bf16x3 | bf16 | f16): 0 = exact f32 MFMA, 1 = split-bf16 MFMA
  * (hi/lo operands, f32-grade, default), 2 = plain bf16 MFMA, 3 = fp16 MFMA operands. */
 int sbv2_vits_decoder_mode(const sbv2_vits* h);
+/* Device workspace (activation arena) the handle currently holds, in bytes.  It is sized by the largest recent batch: after a dozen
+ * calls with much smaller batches it is released and re-grown on demand (a long-running server does not accumulate one arena per shape). */
+int64_t sbv2_vits_workspace_bytes(const sbv2_vits* h);
 
 /* ---- model::synthesize(session, bert_ori, x_tst, sid, tones, lang_ids, style_vector, sdp_ratio, length_scale,
  *                        noise_scale, noise_scale_w) -> Array3<f32>[1, 1, L]      crates/sbv2_core/src/model.rs:53-111

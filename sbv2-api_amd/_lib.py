@@ -34,6 +34,7 @@ SYMBOLS = {
     "sbv2_vits_bert_dim": (C.c_int64, [C.c_void_p]),
     "sbv2_vits_style_dim": (C.c_int64, [C.c_void_p]),
     "sbv2_vits_decoder_mode": (C.c_int, [C.c_void_p]),
+    "sbv2_vits_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "sbv2_vits_synthesize": (C.c_int, [C.c_void_p, f32p, i64p, i64p, i64p, C.c_int64, C.c_int64, f32p, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_uint64, C.POINTER(f32p), i64p]),
     "sbv2_pcm_free": (None, [f32p]),

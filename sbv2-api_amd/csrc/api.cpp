@@ -135,6 +135,7 @@ int64_t sbv2_vits_hop(const sbv2_vits* h) { return h ? h->m->cfg().hop() : 0; }
 int64_t sbv2_vits_bert_dim(const sbv2_vits* h) { return h ? h->m->cfg().bert_dim : 0; }
 int64_t sbv2_vits_style_dim(const sbv2_vits* h) { return h ? h->m->cfg().style_dim : 0; }
 int sbv2_vits_decoder_mode(const sbv2_vits* h) { return h ? h->m->decoder_mode() : -1; }
+int64_t sbv2_vits_workspace_bytes(const sbv2_vits* h) { return h ? (int64_t)h->m->workspace_bytes() : -1; }
 
 int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* pcm_lens) {
     API_BEGIN

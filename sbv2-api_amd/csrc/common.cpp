@@ -38,16 +38,25 @@ void Arena::upload(void* dst, const void* src, size_t bytes, hipStream_t stream)
     c.off += need;
 }
 void Arena::reset() {
-    // The chunk list is kept as it is: a pass with the same shapes replays the same allocation sequence and lands on the same chunks,
-    // so after the first pass of a context there is no hipMalloc / hipFree on the path (a consolidation here cost a 9 GB
-    // free + malloc + device sync inside the second call of every execution context).
-    for (auto& c : chunks_) c.off = 0;
+    // The chunk list is normally kept as it is: a pass with the same shapes replays the same allocation sequence and lands on the same
+    // chunks, so after the first pass of a context there is no hipMalloc / hipFree on the path (consolidating here on every pass cost a
+    // 9 GB free + malloc + device sync inside the second call of every execution context).
+    size_t used = 0;
+    for (auto& c : chunks_) used += std::max(c.hi, c.off);
+    last_used_ = used;
+    recent_peak_ = std::max(used, recent_peak_ - recent_peak_ / 8);   // decays over ~a dozen passes
+    if (capacity() > 2 * recent_peak_ + ((size_t)1 << 30)) {
+        for (auto& c : chunks_) (void)hipFree(c.base);
+        chunks_.clear();
+    }
+    for (auto& c : chunks_) c.off = c.hi = 0;
     cur_ = 0;
     for (auto& c : pinned_) c.off = 0;  // callers guarantee the previous pass's copies are complete
     pcur_ = 0;
 }
 void Arena::rewind(const Mark& m) {
     if (chunks_.empty()) return;
+    for (auto& c : chunks_) c.hi = std::max(c.hi, c.off);
     for (size_t i = m.chunk + 1; i < chunks_.size(); ++i) chunks_[i].off = 0;
     chunks_[m.chunk].off = m.off;
     cur_ = m.chunk;
@@ -62,7 +71,7 @@ void* Arena::alloc(size_t bytes) {
             return p;
         }
     }
-    Chunk c{nullptr, std::max(bytes, (size_t)256 << 20), 0};
+    Chunk c{nullptr, std::max(bytes, (size_t)256 << 20), 0, 0};
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.base), c.cap));
     c.off = bytes;
     chunks_.push_back(c);

@@ -54,8 +54,11 @@ class Arena {
     Arena(const Arena&) {}   // a copied model context starts with an empty workspace of its own
     Arena& operator=(const Arena&) = delete;
     ~Arena() { release(); }
-    // Start a new forward pass: keeps every chunk (same shapes -> same placement, no allocation after the first pass).
+    // Start a new forward pass: keeps every chunk (same shapes -> same placement, no allocation after the first pass), unless the
+    // workspace has grown far beyond what recent passes used (a server sees many shapes: every new maximum appends chunks): then
+    // the device chunks are released and the next pass allocates afresh.  Callers have drained the stream before reset().
     void reset();
+    size_t used_last_pass() const { return last_used_; }
     void* alloc(size_t bytes);
     Plane plane(int C, int L);
     template <class T>
@@ -72,9 +75,11 @@ class Arena {
     struct Chunk {
         char* base;
         size_t cap, off;
+        size_t hi = 0;   // high-water mark of `off` in the current pass
     };
     std::vector<Chunk> chunks_;
     size_t cur_ = 0;
+    size_t last_used_ = 0, recent_peak_ = 0;
     std::vector<Chunk> pinned_;
     size_t pcur_ = 0;
 };

@@ -183,6 +183,7 @@ class VitsModel {
     hipStream_t stream() const { return stream_; }
     void set_trace(bool on) { trace_ = on; }
     int decoder_mode() const { return dec_mode_; }
+    size_t workspace_bytes() const { return arena_.capacity() + keep_.capacity(); }
     // copies a traced plane of the last forward for utterance `utt`: returns rows/cols
     bool get_trace(const std::string& name, int utt, std::vector<float>& out, int& rows, int& cols);
 

@@ -398,6 +398,28 @@ def test_cpp_host_mirror(tmp_path):
     np.testing.assert_allclose(got, ref, atol=2e-4, rtol=0)
 
 
+def test_workspace_does_not_accumulate():
+    """A handle that has served one large batch gives the workspace back after a run of small ones (Arena::reset trims when the
+    capacity is far above what recent passes used), and results are unaffected by the re-allocation."""
+    cfg, W = weights("vits", "full")
+    s = model.load_model(blob("vits", "full"), False)
+    l = _lib.lib()
+    small = make_utts([6], O.DEBERTA_FULL, cfg, seed0=301)
+    big = make_utts([200, 180, 150, 120], O.DEBERTA_FULL, cfg, seed0=311)
+    first = model.synthesize_batch(s, small, forced=True)[0]
+    ws_small = l.sbv2_vits_workspace_bytes(s.handle)
+    model.synthesize_batch(s, big, forced=True, fetch=False)
+    model.synthesize_batch(s, big, forced=True, fetch=False)
+    ws_big = l.sbv2_vits_workspace_bytes(s.handle)
+    assert ws_big > 4 * ws_small and ws_big >= (2 << 30)
+    for _ in range(40):
+        got = model.synthesize_batch(s, small, forced=True)[0]
+    ws_after = l.sbv2_vits_workspace_bytes(s.handle)
+    assert ws_after < ws_big / 2, (ws_small, ws_big, ws_after)
+    np.testing.assert_array_equal(got, first)
+    s.close()
+
+
 def test_edge_cases_tiny(vits_tiny, bert_tiny):
     """Smallest inputs the front end can produce and the degenerate duration case (sum(w_ceil) == 0 -> clamp_min(1) frame)."""
     cfg, W = weights("vits", "tiny", 5)
