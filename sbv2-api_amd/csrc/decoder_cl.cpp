@@ -235,7 +235,7 @@ void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
                 const int d = rb.dil[q];
                 const bool last = q + 1 == nd;
                 float* yn = last ? XS : ((y == YA) ? YB : YA);
-                if (fuse_pairs_ && C <= 32) {
+                if (fuse_pairs_ && C <= 32 && (U & (U - 1)) == 0) {
                     // narrow stages are HBM bound: conv1 -> conv2 fused, the intermediate stays in LDS (respair_cl.hip)
                     ResPairParams rp;
                     rp.X = y;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     constexpr int NX = ((kRpNT + 64) * 4 + kRpThreads - 1) / kRpThreads;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntaps = p.k, C = p.C, nchunks = C >> 4;
+    const int lc = C == 32 ? 5 : 4;   // C is 16 or 32: row addressing by shift (a 64-bit multiply is a quarter-rate VALU op)
     const int h2 = (p.k - 1) / 2, h1 = p.dil * (p.k - 1) / 2;
     const int rows1 = kRpNT + 2 * h1;
     const int wbytes = ntaps * PARTS * 1024;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
         for (int i = 0; i < NX; ++i) {
             const int idx = min(tid + i * kRpThreads, nxf4 - 1);
             const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
-            const float* src = p.X + (int64_t)pos * C + (idx & 3) * 4;
+            const float* src = p.X + ((int64_t)pos << lc) + (idx & 3) * 4;
             rx[i] = *reinterpret_cast<const f32x4v*>(src);
             rx1[i] = *reinterpret_cast<const f32x4v*>(nchunks > 1 ? src + 16 : src);
         }
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
                 f32x4v v = chunk ? rx1[i] : rx[i];
                 if (pos < 0 || pos >= NB) v = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.slope);   // leaky ReLU for 0 <= slope <= 1
                 const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
                 ex4 h;
 #pragma unroll
@@ -191,6 +192,13 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
         }
     }
     {
+        bool keepj[TN];   // the column mask depends on the position only: once per column, not once per channel quad
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pos = t0 + wn0 + j * 32 + lcol;
+            keepj[j] = pos >= 0 && pos < NB;
+            if (keepj[j] && p.mask) keepj[j] = p.mask[pos >> p.mask_shift] != 0;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co = 8 * q + 4 * lh;
@@ -199,14 +207,12 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lcol;
-                const int pos = t0 + row;
-                bool keep = pos >= 0 && pos < NB;
-                if (keep && p.mask) keep = p.mask[p.mask_shift >= 0 ? (pos >> p.mask_shift) : (pos / p.mask_div)] != 0;
+                const bool keep = keepj[j];
                 f32x4v v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[j][4 * q + e] + b4[e];
-                    t = t >= 0.f ? t : t * p.slope;
+                    t = fmaxf(t, t * p.slope);
                     v[e] = keep ? t : 0.f;
                 }
                 const int off = (co >> 4) * (kRpWin2Rows * 32) + row * 32 + (((((co >> 3) & 1) ^ (row >> 3)) & 1) << 4) + ((co & 7) << 1);
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int64_t posr = min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
-            rres[it] = *reinterpret_cast<const f32x4v*>(p.X + posr * C + c4r);
+            rres[it] = *reinterpret_cast<const f32x4v*>(p.X + (posr << lc) + c4r);
         }
     }
 
@@ -276,20 +282,20 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3);
         const int o = wn0 + row;          // output index inside the workgroup's range
-        const int64_t pos = (int64_t)n0_cur + o;
+        const int pos = n0_cur + o;                 // < 2^31 (checked by the caller)
         const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * 36 + c4);
         if (o >= nto || pos >= NB || c4 >= C) continue;
         const f32x4v r = rres[it];
         f32x4v v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (a[e] + b4[e] + r[e]) * p.beta;
-        f32x4v* dst = reinterpret_cast<f32x4v*>(p.Y + pos * C + c4);
+        f32x4v* dst = reinterpret_cast<f32x4v*>(p.Y + ((int64_t)pos << lc) + c4);
         if (p.accumulate) {
             const f32x4v old = *dst;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += old[e];
         }
-        if (p.mask && !p.mask[p.mask_shift >= 0 ? (pos >> p.mask_shift) : (pos / p.mask_div)]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (p.mask && !p.mask[pos >> p.mask_shift]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
         *dst = v;
     }
     if (!next_tile) break;
@@ -335,11 +341,11 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
 
 void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     ResPairParams p = p0;
-    p.mask_shift = -1;   // the column mask is indexed by position / upsampling factor: a shift when that is a power of two
-    if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
-        p.mask_shift = 0;
-        while ((1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
-    }
+    // the column mask is indexed by position / upsampling factor; only powers of two are supported here (a shift: the 64-bit integer
+    // division this replaced was ~100 VALU instructions per output row, 8 rows per thread, in a kernel that is VALU-issue bound)
+    SBV2_REQUIRE(!p.mask || (p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0), "respair: mask_div must be a power of two");
+    p.mask_shift = 0;
+    while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
     SBV2_REQUIRE(p.C == 16 || p.C == 32, "respair: only the 16- and 32-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
