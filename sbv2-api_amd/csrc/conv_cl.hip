@@ -337,7 +337,10 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     // directly that is 16 bytes per lane scattered over 32 rows.  Instead each wave transposes its 32 x 64 sub-tile through a private
     // LDS tile [64 positions][32 channels (+4 pad)] so that 8 consecutive lanes write (and read the residual as) one full 128-byte
     // line of a row.
+    // Address arithmetic is incremental (64-bit pointers advanced by wave-uniform strides, 32-bit positions, mask index by shift):
+    // the straightforward form cost ~75 VALU + 10 quarter-rate integer multiplies per output row, 16 rows per thread.
     float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
+    const float beta = p.beta;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -359,29 +362,37 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         }
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && m < M) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+        const int nfirst = n0 + wn0 + (lane >> 3);
+        int pos = nfirst * ostride + po;              // < 2^31 (checked by the callers)
+        const int pstep = 8 * ostride;
+        const float* rp = p.R ? p.R + (int64_t)pos * p.ldr + co : nullptr;
+        float* yp = p.Y + (int64_t)pos * p.ldy + co;
+        const int64_t rstep = (int64_t)pstep * p.ldr, ystep = (int64_t)pstep * p.ldy;
+        const float* trow = tile + (lane >> 3) * 36 + c4;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const int n = n0 + wn0 + row;
-            const f32x4v a = *reinterpret_cast<const f32x4v*>(tile + row * 36 + c4);
-            if (n >= N || m >= M) continue;
-            const int64_t pos = (int64_t)n * ostride + po;
-            float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
-            if (p.R) {
-                const float4 r = *reinterpret_cast<const float4*>(p.R + pos * p.ldr + co);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            const int n = nfirst + it * 8;
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
+            if (n < N && m < M) {
+                float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+                if (rp) {
+                    const float4 r = *reinterpret_cast<const float4*>(rp);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (beta != 1.0f) { v.x *= beta; v.y *= beta; v.z *= beta; v.w *= beta; }
+                if (p.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(yp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (p.mask) {
+                    const int mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
+                    if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *reinterpret_cast<float4*>(yp) = v;
             }
-            v.x *= p.beta; v.y *= p.beta; v.z *= p.beta; v.w *= p.beta;
-            float4* dst = reinterpret_cast<float4*>(p.Y + pos * p.ldy + co);
-            if (p.accumulate) {
-                const float4 o = *dst;
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-            }
-            if (p.mask) {
-                const int64_t mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
-                if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            *dst = v;
+            pos += pstep;
+            if (rp) rp += rstep;
+            yp += ystep;
         }
     }
 }
