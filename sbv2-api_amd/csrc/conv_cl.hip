@@ -427,7 +427,7 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(PREC == PREC_F16 ? 19 + (TM == 2 ? 0 : 1) + (IN_KM ? 2 : 0) : (SPLIT ? 8 : 10) + (TM == 2 ? 0 : 1) + (IN_KM ? 4 : 0), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+        conv_prof_add(PREC == PREC_F16 ? 19 + (TM == 2 ? 0 : 1) + ((IN_KM || OUT_KM) ? 2 : 0) : (SPLIT ? 8 : 10) + (TM == 2 ? 0 : 1) + ((IN_KM || OUT_KM) ? 4 : 0), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
     }
 }
 
