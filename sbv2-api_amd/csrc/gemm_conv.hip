@@ -262,6 +262,78 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
 
     // ---- epilogue --------------------------------------------------------------------------------
     const bool phased = p.phase_rows < (1 << 30);
+    if constexpr (MF == 32 && TM * TN <= 4) {   // (the 8-tile experiment configuration keeps the scalar form: its unrolled body spills)
+        // Vector form (everything but the polyphase launches): in the accumulators a lane owns ONE column and 16 rows, i.e. a direct
+        // store is sixteen 4-byte stores per 32 x 32 tile (and as many 4-byte residual loads): ablating that epilogue was worth 4 ms of
+        // the 23 ms these kernels take per step.  Each wave passes its tiles through a private 32 x 36 LDS tile instead and leaves with
+        // four 16-byte stores per lane: 8 lanes cover 128 bytes of a row, a wave-instruction 8 rows.  Same arithmetic per element.
+        if (!phased && (p.ldc & 3) == 0 && (!Rg || (p.ldr & 3) == 0)) {
+            float* tile = smem + wave * (32 * 36);
+            const int lrow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < MM::NACC; ++r) tile[MM::row(lane, r) * 36 + lcol] = acc[i][j][r];
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = ps * 8 + lrow;
+                        const float4 a = *reinterpret_cast<const float4*>(tile + row * 36 + c4);
+                        const int m = m0 + wm0 + i * MF + row;
+                        const int n = n0 + wn0 + j * MF + c4;
+                        if (m < M && n < N) {
+                        const float brow = (p.bias_mode == BIAS_ROW) ? p.bias[m] : 0.f;
+                        float v[4] = {a.x + brow, a.y + brow, a.z + brow, a.w + brow};
+                        const bool full = n + 3 < N;
+                        float* dst = Cg + (int64_t)m * p.ldc + n;
+                        float rr[4] = {0.f, 0.f, 0.f, 0.f}, old[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (full) {
+                            if (Rg) {
+                                const float4 t = *reinterpret_cast<const float4*>(Rg + (int64_t)m * p.ldr + n);
+                                rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w;
+                            }
+                            if (p.accumulate) {
+                                const float4 t = *reinterpret_cast<const float4*>(dst);
+                                old[0] = t.x; old[1] = t.y; old[2] = t.z; old[3] = t.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < N) {
+                                    if (Rg) rr[e] = Rg[(int64_t)m * p.ldr + n + e];
+                                    if (p.accumulate) old[e] = dst[e];
+                                }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = v[e];
+                            if (p.bias_mode == BIAS_COL) x += p.bias[min(n + e, N - 1)];
+                            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                            else if (p.act == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                            x *= p.alpha;
+                            if (Rg) x += rr[e];
+                            x *= p.beta;
+                            if (p.accumulate) x += old[e];
+                            if (p.mask) {
+                                const int oc = min(n + e, N - 1);
+                                const int mi = kp.mask_shift >= 0 ? (oc >> kp.mask_shift) : (oc / p.mask_div);
+                                if (!p.mask[mi]) x = 0.f;
+                            }
+                            v[e] = x;
+                        }
+                        if (full) {
+                            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < N) dst[e] = v[e];
+                        }
+                        }
+                    }
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -382,7 +454,7 @@ static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stre
     }
     kp.xw = xw;
     kp.wshift0 = w0;
-    const size_t lds = sizeof(float) * (2 * KC * MT + 2 * KC * xw);
+    const size_t lds = std::max(sizeof(float) * (2 * KC * MT + 2 * KC * xw), sizeof(float) * 4 * 32 * 36);   // staging | epilogue tiles
     dim3 grid((Nx + NT - 1) / NT, (Mx + MT - 1) / MT, p.groups ? p.ngroups : 1);
     auto kern = conv_gemm_kernel<MF, TM, TN, WM, WN, KC>;
     static bool attr_set = false;
