@@ -369,6 +369,18 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         float* yp = p.Y + (int64_t)pos * p.ldy + co;
         const int64_t rstep = (int64_t)pstep * p.ldr, ystep = (int64_t)pstep * p.ldy;
         const float* trow = tile + (lane >> 3) * 36 + c4;
+        // accumulate (the last step of a ResBlock branch adds into the stage sum): the eight previous values are requested back to back
+        // before the row loop; read inside it, each load waited behind the previous row's store (eight dependent round trips per tile:
+        // the clock-stamp timeline of respair_cl.hip showed 5 us of a 12 us workgroup for the same pattern)
+        f32x4v rold[8];
+        if (p.accumulate) {
+            const int64_t last = (int64_t)(N - 1) * ostride + po;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t pp = min((int64_t)(nfirst + it * 8) * ostride + po, last);
+                rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + (m < M ? co : 0));
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int n = nfirst + it * 8;
@@ -381,8 +393,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                 }
                 if (beta != 1.0f) { v.x *= beta; v.y *= beta; v.z *= beta; v.w *= beta; }
                 if (p.accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(yp);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    v.x += rold[it][0]; v.y += rold[it][1]; v.z += rold[it][2]; v.w += rold[it][3];
                 }
                 if (p.mask) {
                     const int mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
