@@ -38,7 +38,7 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
 }
 
 template <int PREC, bool PERSIST>
-__global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairParams p) {
+__global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERSIST ? 1 : 3))) void respair_cl_kernel(const ResPairParams p) {
     constexpr bool SPLIT = PREC == PREC_BF16X3;
     using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
     using ex8 = std::conditional_t<PREC == PREC_F16, f16x8, bf16x8>;
@@ -278,6 +278,17 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
     const int c4 = (lane & 7) * 4;
     f32x4v b4 = {0.f, 0.f, 0.f, 0.f};
     if (c4 < C) b4 = *reinterpret_cast<const f32x4v*>(p.b2 + c4);
+    // accumulate: all eight rows' previous contents are requested back to back (read inside the row loop, each load waited behind the
+    // previous row's store: 8-9 us of epilogue instead of 3 in the clock-stamp timeline of this kernel)
+    f32x4v rold[8];
+    if (p.accumulate) {
+        const int c4o = min(c4, C - 4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t po = min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
+            rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + (po << lc) + c4o);
+        }
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3);
@@ -291,9 +302,8 @@ __global__ __launch_bounds__(kRpThreads) void respair_cl_kernel(const ResPairPar
         for (int e = 0; e < 4; ++e) v[e] = (a[e] + b4[e] + r[e]) * p.beta;
         f32x4v* dst = reinterpret_cast<f32x4v*>(p.Y + ((int64_t)pos << lc) + c4);
         if (p.accumulate) {
-            const f32x4v old = *dst;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += old[e];
+            for (int e = 0; e < 4; ++e) v[e] += rold[it][e];
         }
         if (p.mask && !p.mask[pos >> p.mask_shift]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
         *dst = v;
