@@ -58,6 +58,12 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
     char* x1_lo = x1_hi + rows1 * 32;
     char* x2_hi = x1_hi + rows1 * 32 * PARTS;                 // [chunk][kRpWin2Rows][32 B]
     char* x2_lo = x2_hi + nchunks * kRpWin2Rows * 32;
+    // biases and the column-mask bytes of this tile, staged once: read from LDS by the two epilogues instead of three dependent
+    // global round trips (~0.7-1 us each on a ~12 us workgroup in the clock-stamp timeline).  Placed behind everything the epilogue's
+    // transpose tiles overlay.
+    const int main_bytes = wbytes + rows1 * 32 * PARTS + nchunks * kRpWin2Rows * 32 * PARTS;
+    float* bias_s = reinterpret_cast<float*>(smem + max(main_bytes, 4 * 64 * 36 * 4));   // [0, 32): b1, [32, 64): b2
+    unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 64);                  // [kRpWin2Rows + 16]: rows of the intermediate
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lh = lane >> 5;
@@ -177,8 +183,20 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
     load_x();
   for (int tile = blockIdx.x;; tile += gridDim.x) {
     const bool next_tile = PERSIST && tile + (int)gridDim.x < ntiles;
-    store_w();
-    store_x(0);
+    {
+        const float bval = tid < 64 ? (tid < 32 ? p.b1[min(tid, C - 1)] : p.b2[min(tid - 32, C - 1)]) : 0.f;
+        unsigned char mval[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = min(max(t0 + tid + h * kRpThreads, 0), NB - 1);
+            mval[h] = p.mask ? p.mask[pos >> p.mask_shift] : (unsigned char)1;
+        }
+        store_w();
+        store_x(0);
+        if (tid < 64) bias_s[tid] = bval;
+        mask_s[tid] = mval[0];
+        if (tid < kRpWin2Rows + 16 - kRpThreads) mask_s[tid + kRpThreads] = mval[1];
+    }
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
@@ -196,14 +214,13 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int pos = t0 + wn0 + j * 32 + lcol;
-            keepj[j] = pos >= 0 && pos < NB;
-            if (keepj[j] && p.mask) keepj[j] = p.mask[pos >> p.mask_shift] != 0;
+            keepj[j] = pos >= 0 && pos < NB && mask_s[wn0 + j * 32 + lcol] != 0;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co = 8 * q + 4 * lh;
             if (co >= C) continue;
-            const f32x4v b4 = *reinterpret_cast<const f32x4v*>(p.b1 + co);
+            const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bias_s + co);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lcol;
@@ -276,8 +293,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
             *reinterpret_cast<f32x4v*>(ttile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
         }
     const int c4 = (lane & 7) * 4;
-    f32x4v b4 = {0.f, 0.f, 0.f, 0.f};
-    if (c4 < C) b4 = *reinterpret_cast<const f32x4v*>(p.b2 + c4);
+    const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bias_s + 32 + c4);   // (channels >= C are discarded below)
     // accumulate: all eight rows' previous contents are requested back to back (read inside the row loop, each load waited behind the
     // previous row's store: 8-9 us of epilogue instead of 3 in the clock-stamp timeline of this kernel)
     f32x4v rold[8];
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += rold[it][e];
         }
-        if (p.mask && !p.mask[pos >> p.mask_shift]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (!mask_s[o + h2]) v = f32x4v{0.f, 0.f, 0.f, 0.f};   // position n0 + o = intermediate row o + h2
         *dst = v;
     }
     if (!next_tile) break;
@@ -321,6 +337,8 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     const int rows1 = kRpNT + 2 * h1;
     size_t lds = (size_t)p.k * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
     lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));
+    lds += 64 * sizeof(float) + kRpWin2Rows + 16;   // biases + mask bytes (kernel: bias_s, mask_s)
+    lds = (lds + 15) / 16 * 16;
     SBV2_REQUIRE(lds <= 160 * 1024, "respair: LDS budget exceeded");
     auto kern = respair_cl_kernel<PREC, PERSIST>;
     static bool attr_set = false;
