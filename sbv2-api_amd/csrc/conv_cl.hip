@@ -59,6 +59,8 @@ struct ClKernelParams {
     int nmt;      // 32-row tiles in the packed weights (padded to a multiple of TM)
     int sh0, sh_step;   // tap t reads window row offset sh0 + t * sh_step (tap shifts are an arithmetic progression)
     int mask_shift;
+    int aux_off;      // LDS offset of the staged bias / mask bytes (channels-last epilogue), 0 = not staged
+    int mask_nshift;  // mask index of position n * out_stride + phase offset == n >> mask_nshift (power-of-two strides)
 };
 
 template <int TM, int PREC, bool IN_KM, bool OUT_KM>
@@ -235,8 +237,29 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
 
     load_w(0);
     if (IN_KM) load_xk(0); else load_x(0);
+    // The channels-last epilogue's bias (one value per row of this tile) and column-mask bytes (one per position) are fetched with the
+    // first tiles and parked in LDS: read in the epilogue they are dependent global round trips (~1 us each per workgroup; the same
+    // change in respair_cl.hip removed 2 ms per step).
+    float* bias_s = reinterpret_cast<float*>(smem + kp.aux_off);          // [TM * 32]
+    unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 64);   // [kClNT]
+    const bool staged = !OUT_KM && kp.aux_off != 0;
+    float bstage = 0.f;
+    unsigned char mstage = 1;
+    if (staged) {
+        if (tid < TM * 32) {
+            const int m = m0 + tid;
+            int co = m;
+            if (p.phase_rows < (1 << 30)) co = m - (m / p.phase_rows) * p.phase_rows;
+            bstage = (p.bias && m < M) ? p.bias[co] : 0.f;
+        }
+        if (p.mask) mstage = p.mask[min(n0 + tid, N - 1) >> kp.mask_nshift];
+    }
     store_w();
     if (IN_KM) store_xk(); else store_x();
+    if (staged) {
+        if (tid < TM * 32) bias_s[tid] = bstage;
+        mask_s[tid] = mstage;
+    }
     __syncthreads();
 
     const int lcol = lane & 31, lh = lane >> 5;
@@ -361,7 +384,8 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             for (int t = 0; t < kMaxPhases; ++t) po = (ph == t) ? p.phase_off[t] : po;
         }
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && m < M) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+        if (staged) b4 = *reinterpret_cast<const float4*>(bias_s + i * 32 + c4);
+        else if (p.bias && m < M) b4 = *reinterpret_cast<const float4*>(p.bias + co);
         const int nfirst = n0 + wn0 + (lane >> 3);
         int pos = nfirst * ostride + po;              // < 2^31 (checked by the callers)
         const int pstep = 8 * ostride;
@@ -395,7 +419,9 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                 if (p.accumulate) {
                     v.x += rold[it][0]; v.y += rold[it][1]; v.z += rold[it][2]; v.w += rold[it][3];
                 }
-                if (p.mask) {
+                if (staged) {
+                    if (!mask_s[n - n0]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (p.mask) {
                     const int mi = kp.mask_shift >= 0 ? (pos >> kp.mask_shift) : (pos / p.mask_div);
                     if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -416,6 +442,24 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     kp.wbytes = p.ntaps * TM * PARTS * 1024;
     size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
     if (!OUT_KM) lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));  // the epilogue's per-wave transpose tiles
+    kp.aux_off = 0;
+    kp.mask_nshift = 0;
+    if (!OUT_KM) {
+        // bias / mask staging needs "mask index = n >> const": mask_div and out_stride powers of two, mask_div a multiple of out_stride
+        bool ok = true;
+        if (p.mask) {
+            const int os = p.phase_rows < (1 << 30) ? p.out_stride : 1;
+            ok = kp.mask_shift >= 0 && os > 0 && (os & (os - 1)) == 0 && p.mask_div % os == 0;
+            int ls = 0;
+            while ((1 << ls) < os) ++ls;
+            kp.mask_nshift = kp.mask_shift - ls;
+        }
+        if (ok) {
+            lds = (lds + 15) / 16 * 16;
+            kp.aux_off = (int)lds;
+            lds += 64 * sizeof(float) + kClNT;
+        }
+    }
     static const int pad_lds = getenv("SBV2_CL_PADLDS") ? atoi(getenv("SBV2_CL_PADLDS")) : 0;   // occupancy experiments only
     lds += pad_lds;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
