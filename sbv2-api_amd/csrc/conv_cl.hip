@@ -326,31 +326,52 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
     const bool phased = p.phase_rows < (1 << 30);
     if (OUT_KM) {
-        // k-major output plane Y[m][ldy]: for one accumulator register the 32 lanes of a half-wave hold 32 consecutive columns
+        // k-major output plane Y[m][ldy]: for one accumulator register the 32 lanes of a half-wave hold 32 consecutive columns.
+        // Everything read from global memory (bias rows, column mask, residual, previous contents) is requested BEFORE the first store:
+        // on gfx9 loads and stores share the in-order vmcnt queue, so a load issued after a store is not usable before that store is
+        // acknowledged; interleaved per row that was one store round trip per accumulator row (32 per tile).
+        int nn[TN];
+        bool nok[TN], keepn[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            nn[j] = n0 + wn0 + j * 32 + lcol;
+            nok[j] = nn[j] < N;
+            keepn[j] = true;
+            if (p.mask) {
+                const int nc = min(nn[j], N - 1);
+                keepn[j] = p.mask[kp.mask_shift >= 0 ? (nc >> kp.mask_shift) : (nc / p.mask_div)] != 0;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float brow[16], rr[16][TN], old[16][TN];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mc = min(m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+                brow[r] = p.bias ? p.bias[mc] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nc = min(nn[j], N - 1);
+                    rr[r][j] = p.R ? p.R[(int64_t)mc * p.ldr + nc] : 0.f;
+                    old[r][j] = p.accumulate ? p.Y[(int64_t)mc * p.ldy + nc] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= M) continue;
-                const float brow = p.bias ? p.bias[m] : 0.f;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn0 + j * 32 + lcol;
-                    if (n >= N) continue;
-                    float v = acc[i][j][r] + brow;
+                    if (!nok[j]) continue;
+                    float v = acc[i][j][r] + brow[r];
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     v *= p.alpha;
-                    if (p.R) v += p.R[(int64_t)m * p.ldr + n];
+                    if (p.R) v += rr[r][j];
                     v *= p.beta;
-                    float* dst = p.Y + (int64_t)m * p.ldy + n;
-                    if (p.accumulate) v += *dst;
-                    if (p.mask) {
-                        const int mi = kp.mask_shift >= 0 ? (n >> kp.mask_shift) : (n / p.mask_div);
-                        if (!p.mask[mi]) v = 0.f;
-                    }
-                    *dst = v;
+                    if (p.accumulate) v += old[r][j];
+                    if (!keepn[j]) v = 0.f;
+                    p.Y[(int64_t)m * p.ldy + nn[j]] = v;
                 }
             }
         }
