@@ -417,13 +417,15 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
         // accumulate (the last step of a ResBlock branch adds into the stage sum): the eight previous values are requested back to back
         // before the row loop; read inside it, each load waited behind the previous row's store (eight dependent round trips per tile:
         // the clock-stamp timeline of respair_cl.hip showed 5 us of a 12 us workgroup for the same pattern)
-        f32x4v rold[8];
-        if (p.accumulate) {
+        f32x4v rold[8], rres[8];
+        if (p.accumulate || rp) {
             const int64_t last = (int64_t)(N - 1) * ostride + po;
+            const int cc = m < M ? co : 0;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int64_t pp = min((int64_t)(nfirst + it * 8) * ostride + po, last);
-                rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + (m < M ? co : 0));
+                if (p.accumulate) rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + cc);
+                if (rp) rres[it] = *reinterpret_cast<const f32x4v*>(p.R + pp * p.ldr + cc);   // the residual rows as well
             }
         }
 #pragma unroll
@@ -433,8 +435,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             if (n < N && m < M) {
                 float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
                 if (rp) {
-                    const float4 r = *reinterpret_cast<const float4*>(rp);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    v.x += rres[it][0]; v.y += rres[it][1]; v.z += rres[it][2]; v.w += rres[it][3];
                 }
                 if (beta != 1.0f) { v.x *= beta; v.y *= beta; v.z *= beta; v.w *= beta; }
                 if (p.accumulate) {
