@@ -135,7 +135,26 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
         if (res) v += res[(size_t)c * ldr + n];
         out.p[(size_t)c * out.ld + n] = keep ? v : 0.f;
     };
-    if (CPT > 0) {
+    if (CPT > 0 && CPT <= 32) {
+        // gamma / beta / residual of every owned channel are read before the first store: a load issued after a store is not usable
+        // until that store is acknowledged (in-order vmcnt), which made this loop one store round trip per channel
+        float gv[NV], bv[NV], rv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = min(ty + G * k, C - 1);
+            gv[k] = gamma[c];
+            bv[k] = beta[c];
+            rv[k] = res ? res[(size_t)c * ldr + n] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (ty + G * k < C) {
+                float v = (xv[k] - mean) * rstd * gv[k] + bv[k];
+                if (act == ACT_GELU) v = gelu_exact(v);
+                if (res) v += rv[k];
+                out.p[(size_t)(ty + G * k) * out.ld + n] = keep ? v : 0.f;
+            }
+    } else if (CPT > 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             if (ty + G * k < C) emit(ty + G * k, xv[k]);
