@@ -1,0 +1,188 @@
+// Fused DeBERTa-v2 disentangled self-attention for short sequences (T <= 64 tokens per utterance, head dim <= 64), exact f32 MFMA.
+//
+// Reference arithmetic (transformers modeling_deberta_v2.py:232-253, 276-346, share_att_key, pos_att_type = c2p | p2c):
+//
+//   s[i][j] = ( q_i . k_j  +  q_i . posk[ clamp(bucket(i - j) + span) ]  +  k_j . posq[ clamp(-bucket(j - i) + span) ] ) / sqrt(3 d)
+//   p = softmax_j(s)  (masked pairs: -FLT_MAX before the softmax),   ctx_i = sum_j p[i][j] v_j
+//
+// The unfused path runs this as four grouped GEMM launches (S^T = K^T Q, c2p = posK^T Q, p2c = K^T posQ, ctx = V P^T) and a softmax /
+// gather launch per layer: 110 launches of 64 x 64 (x 127) problems per forward, ~6 ms of an 18 ms DeBERTa at batch 32 and most of its
+// launch count at batch 1.  Here one workgroup owns one (utterance, head): the two relative-position products go to LDS once
+// (c2p^T [window][query], p2c [key][window]; the window is the range of bucket indices a sequence of this length can reach, <= 128),
+// each wave computes a 32 x 32 tile of S^T = K^T Q, gathers the two bias terms by bucket index, the column softmax is combined
+// across the two key tiles through LDS, P goes to LDS (over the c2p buffer) and each wave computes one 32 x 32 tile of ctx = V P^T.
+// Operands are read straight from the k-major planes (they are L2 resident; one value per lane and k-step is exactly the MFMA's
+// operand shape).  Fixed summation order: results do not depend on the batch composition.
+#include <cfloat>
+
+#include "common.h"
+#include "ops.h"
+
+namespace sbv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int kDaT = 64;         // max tokens
+constexpr int kDaW = 128;        // max window of relative-position buckets
+constexpr int kDaPc = kDaT + 1;  // pitch of c2p_s / p_s rows  (floats)
+constexpr int kDaPp = kDaW + 1;  // pitch of p2c_s rows
+
+__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+__global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, const float* Q, const float* K, int ld, const float* VT, int H,
+                                                      const float* posk, const float* posq, int ldp, int win_lo, int wlen, const int* tab,
+                                                      int tab_center, int span, float inv_scale, const unsigned char* tok_mask, int dh,
+                                                      float* ctx, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) float da_smem[];   // 67.8 KB: above the 64 KB static limit
+    float* c2p_s = da_smem;                          // [w][i]; reused for P[j][i] after the scores are formed
+    float* p2c_s = c2p_s + kDaW * kDaPc;             // [j][w]
+    float (*redm)[kDaT] = reinterpret_cast<float (*)[kDaT]>(p2c_s + kDaT * kDaPp);
+    float (*reds)[kDaT] = redm + 2;
+    int* tab_s = reinterpret_cast<int*>(reds + 2);   // [2 * kDaT]
+    const AttnGroup g = groups[blockIdx.x];
+    const int T = g.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int64_t hoff = (int64_t)g.head * dh;
+    const float* Qg = Q + hoff * ld + g.col0;
+    const float* Kg = K + hoff * ld + g.col0;
+    const float* Pk = posk + hoff * ldp + win_lo;
+    const float* Pq = posq + hoff * ldp + win_lo;
+    const float* Vg = VT + (int64_t)g.col0 * H + hoff;
+    const int ns = dh >> 1;   // k-steps over the head dimension
+
+    if (tid < 2 * T - 1) tab_s[tid] = tab[tab_center - (T - 1) + tid];   // tab_s[(i - j) + T - 1] = bucket(i - j)
+    if (tid < 2 * kDaT) (&redm[0][0])[tid] = -FLT_MAX;
+
+    auto tile_product = [&](const float* Abase, int lda_, int arow, int amax, const float* Bbase, int ldb_, int bcol, int bmax) {
+        // 32 x 32 tile of sum_d A[d][arow + row] * B[d][bcol + col]; rows / columns beyond amax / bmax read as zero
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int ar = arow + col, bc = bcol + col;
+        const bool aok = ar < amax, bok = bc < bmax;
+        const float* ap = Abase + min(ar, amax - 1);
+        const float* bp = Bbase + min(bc, bmax - 1);
+        float av[32], bv[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int dd = min(2 * s + kh, dh - 1);
+            av[s] = ap[(int64_t)dd * lda_];
+            bv[s] = bp[(int64_t)dd * ldb_];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            if (s < ns) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aok ? av[s] : 0.f, bok ? bv[s] : 0.f, acc, 0, 0, 0);
+        return acc;
+    };
+
+    // ---- c2p^T[w][i] = sum_d posk[d][w] q[d][i]   (8 tiles: wave -> window tile `wave`, both query tiles) ----------------------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const f32x16 a = tile_product(Pk, ldp, wave * 32, wlen, Qg, ld, it * 32, T);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2p_s[(wave * 32 + acc_row(r, kh)) * kDaPc + it * 32 + col] = a[r];
+    }
+    // ---- p2c[j][w] = sum_d k[d][j] posq[d][w]     (8 tiles: wave -> key tile wave & 1, window tiles 2 (wave >> 1) + {0, 1}) --------
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int jt = wave & 1, wt = 2 * (wave >> 1) + t;
+        const f32x16 a = tile_product(Kg, ld, jt * 32, T, Pq, ldp, wt * 32, wlen);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p2c_s[(jt * 32 + acc_row(r, kh)) * kDaPp + wt * 32 + col] = a[r];
+    }
+    __syncthreads();
+
+    // ---- scores: wave -> (key tile jt, query tile it) ----------------------------------------------------------------------------
+    const int jt = wave >> 1, it = wave & 1;
+    const int i = it * 32 + col;
+    const bool iok = i < T;
+    const int ic = min(i, T - 1);
+    f32x16 sacc = tile_product(Kg, ld, jt * 32, T, Qg, ld, it * 32, T);
+    const bool mi = tok_mask[g.col0 + ic] != 0;
+    const int hi = 2 * span - 1;
+    float mloc = -FLT_MAX;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + acc_row(r, kh);
+        const int jc = min(j, T - 1);
+        const int d1 = min(max(tab_s[(ic - jc) + T - 1] + span, 0), hi) - win_lo;
+        const int d2 = min(max(-tab_s[(jc - ic) + T - 1] + span, 0), hi) - win_lo;
+        float v = sacc[r] * inv_scale + c2p_s[d1 * kDaPc + ic] * inv_scale + p2c_s[jc * kDaPp + d2] * inv_scale;
+        if (!(mi && tok_mask[g.col0 + jc])) v = -FLT_MAX;
+        sacc[r] = v;
+        if (j < T) mloc = fmaxf(mloc, v);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    if (kh == 0 && jt * 32 < T) redm[jt][i] = mloc;
+    __syncthreads();   // (also: every wave is done reading c2p_s, which P overwrites below)
+    const float mx = fmaxf(redm[0][i], redm[1][i]);
+    float sloc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + acc_row(r, kh);
+        const float e = j < T ? expf(sacc[r] - mx) : 0.f;
+        sacc[r] = e;
+        sloc += e;
+    }
+    {
+        const float other = __shfl_xor(sloc, 32);
+        sloc = kh ? other + sloc : sloc + other;   // (rows of half 0) + (rows of half 1) in both halves
+    }
+    if (kh == 0) reds[jt][i] = sloc;
+    __syncthreads();
+    const float sum = reds[0][i] + reds[1][i];
+    float* p_s = c2p_s;   // P[j][i]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p_s[(jt * 32 + acc_row(r, kh)) * kDaPc + i] = sacc[r] / sum;
+    __syncthreads();
+
+    // ---- ctx[dd][i] = sum_j v[j][dd] p[j][i]: wave -> (channel tile ddt, query tile it) ---------------------------------------------
+    const int ddt = wave >> 1;
+    if (ddt * 32 < dh) {
+        f32x16 cacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+        const int dd = ddt * 32 + col;           // A row: channel
+        const bool dok = dd < dh;
+        float av[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int j = 2 * s + kh;
+            av[s] = (dok && j < T) ? Vg[(int64_t)j * H + dd] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int j = 2 * s + kh;
+            if (2 * s < T) cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], p_s[j * kDaPc + i], cacc, 0, 0, 0);
+        }
+        float* Cg = ctx + hoff * ldc + g.col0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d2 = ddt * 32 + acc_row(r, kh);
+            if (d2 < dh && iok) Cg[(int64_t)d2 * ldc + i] = cacc[r];
+        }
+    }
+}
+}  // namespace
+
+bool deberta_attention_fits(int maxT, int wlen, int dh) { return maxT >= 1 && maxT <= kDaT && wlen <= kDaW && dh <= 64 && (dh & 1) == 0; }
+
+void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* VT, int H, const float* posk,
+                       const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span, float inv_scale,
+                       const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s) {
+    if (ngroups <= 0) return;
+    constexpr size_t lds = sizeof(float) * (kDaW * kDaPc + kDaT * kDaPp + 4 * kDaT + 2 * kDaT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_deberta_attn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_deberta_attn, dim3(ngroups), dim3(256), lds, s, groups, Q, K, ld, VT, H, posk, posq, ldp, win_lo, wlen, tab,
+                       tab_center, span, inv_scale, tok_mask, dh, ctx, ldc);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sbv2

@@ -268,16 +268,24 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         fl_tw += 2.0 * nh * (double)L[u] * wlen * d;
     }
 
+    // short sequences (every utterance <= 64 tokens: the usual sentence) take the fused attention; SBV2_BERT_ATTN=unfused for A/B runs
+    static const bool want_fused = !(getenv("SBV2_BERT_ATTN") && std::string(getenv("SBV2_BERT_ATTN")) == "unfused");
+    const bool fused_attn = want_fused && deberta_attention_fits(maxT, wlen, d);
     for (int li = 0; li < cfg_.layers; ++li) {
         const Layer& Ly = layers_[li];
         conv_plain(Ly.q, X, Q, 1, 0, nullptr, 1, stream_);
         conv_plain(Ly.k, X, Kp, 1, 0, nullptr, 1, stream_);
         linear_tokmajor(Ly.v, X, VT, H, stream_);
-        grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxT, maxT, inv_scale, fl_tt);
-        grouped(Ly.pos_k.p, ldp, Q.p, Q.ld, C2P, lds, d_g + ng, wlen, maxT, 1.0f, fl_tw);
-        grouped(Kp.p, Kp.ld, Ly.pos_q.p, ldp, P2C, win_ld, d_g + 2 * ng, maxT, wlen, 1.0f, fl_tw);
-        deberta_softmax(d_ag, ng, maxT, S, C2P, P2C, d_tab, maxT - 1, span, win_lo, win_ld, inv_scale, lay.d_mask, stream_);
-        grouped(VT, H, S, lds, ctx.p, ctx.ld, d_g + 3 * ng, d, maxT, 1.0f, fl_tt);
+        if (fused_attn) {
+            deberta_attention(d_ag, ng, Q.p, Kp.p, Q.ld, VT, H, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo, wlen, d_tab, maxT - 1, span, inv_scale,
+                              lay.d_mask, d, ctx.p, ctx.ld, stream_);
+        } else {
+            grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxT, maxT, inv_scale, fl_tt);
+            grouped(Ly.pos_k.p, ldp, Q.p, Q.ld, C2P, lds, d_g + ng, wlen, maxT, 1.0f, fl_tw);
+            grouped(Kp.p, Kp.ld, Ly.pos_q.p, ldp, P2C, win_ld, d_g + 2 * ng, maxT, wlen, 1.0f, fl_tw);
+            deberta_softmax(d_ag, ng, maxT, S, C2P, P2C, d_tab, maxT - 1, span, win_lo, win_ld, inv_scale, lay.d_mask, stream_);
+            grouped(VT, H, S, lds, ctx.p, ctx.ld, d_g + 3 * ng, d, maxT, 1.0f, fl_tt);
+        }
         conv_plain(Ly.o, ctx, A, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &X);
         layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
         conv_plain(Ly.ffn1, A, F, 1, 0, nullptr, 1, stream_, ACT_GELU);
