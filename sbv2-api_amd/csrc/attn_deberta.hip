@@ -30,7 +30,7 @@ constexpr int kDaPp = kDaW + 1;  // pitch of p2c_s rows
 
 __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
-__global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, const float* Q, const float* K, int ld, const float* VT, int H,
+__global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, const float* Q, const float* K, int ld, const float* V,
                                                       const float* posk, const float* posq, int ldp, int win_lo, int wlen, const int* tab,
                                                       int tab_center, int span, float inv_scale, const unsigned char* tok_mask, int dh,
                                                       float* ctx, int ldc) {
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, c
     const float* Kg = K + hoff * ld + g.col0;
     const float* Pk = posk + hoff * ldp + win_lo;
     const float* Pq = posq + hoff * ldp + win_lo;
-    const float* Vg = VT + (int64_t)g.col0 * H + hoff;
+    const float* Vg = V + hoff * ld + g.col0;   // k-major like q and k: rows = channels
     const int ns = dh >> 1;   // k-steps over the head dimension
 
     if (tid < 2 * T - 1) tab_s[tid] = tab[tab_center - (T - 1) + tid];   // tab_s[(i - j) + T - 1] = bucket(i - j)
@@ -139,24 +139,25 @@ __global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, c
     for (int r = 0; r < 16; ++r) p_s[(jt * 32 + acc_row(r, kh)) * kDaPc + i] = sacc[r] / sum;
     __syncthreads();
 
-    // ---- ctx[dd][i] = sum_j v[j][dd] p[j][i]: wave -> (channel tile ddt, query tile it) ---------------------------------------------
+    // ---- ctx[dd][i] = sum_j v[dd][j] p[j][i]: wave -> (channel tile ddt, query tile it) ---------------------------------------------
+    // V is a k-major plane (rows = channels): the A operand wants, per lane, channel row `col` at key j.  Read coalesced (lanes along j)
+    // into the p2c buffer, which is free now, and picked up transposed from LDS.
+    float* v_s = p2c_s;   // [dd][j], pitch kDaPc
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int dd = idx >> 6, j = idx & 63;
+        v_s[dd * kDaPc + j] = (dd < dh && j < T) ? Vg[(int64_t)dd * ld + j] : 0.f;
+    }
+    __syncthreads();
     const int ddt = wave >> 1;
     if (ddt * 32 < dh) {
         f32x16 cacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
-        const int dd = ddt * 32 + col;           // A row: channel
-        const bool dok = dd < dh;
-        float av[32];
+        const float* vrow = v_s + (ddt * 32 + col) * kDaPc;   // A row: channel
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const int j = 2 * s + kh;
-            av[s] = (dok && j < T) ? Vg[(int64_t)j * H + dd] : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int j = 2 * s + kh;
-            if (2 * s < T) cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], p_s[j * kDaPc + i], cacc, 0, 0, 0);
+            if (2 * s < T) cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[j], p_s[j * kDaPc + i], cacc, 0, 0, 0);
         }
         float* Cg = ctx + hoff * ldc + g.col0;
 #pragma unroll
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, c
 
 bool deberta_attention_fits(int maxT, int wlen, int dh) { return maxT >= 1 && maxT <= kDaT && wlen <= kDaW && dh <= 64 && (dh & 1) == 0; }
 
-void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* VT, int H, const float* posk,
+void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* V, const float* posk,
                        const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span, float inv_scale,
                        const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s) {
     if (ngroups <= 0) return;
@@ -180,7 +181,7 @@ void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, con
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_deberta_attn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_deberta_attn, dim3(ngroups), dim3(256), lds, s, groups, Q, K, ld, VT, H, posk, posq, ldp, win_lo, wlen, tab,
+    hipLaunchKernelGGL(k_deberta_attn, dim3(ngroups), dim3(256), lds, s, groups, Q, K, ld, V, posk, posq, ldp, win_lo, wlen, tab,
                        tab_center, span, inv_scale, tok_mask, dh, ctx, ldc);
     HIP_CHECK(hipGetLastError());
 }

@@ -98,6 +98,7 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
         L.k = ws_->linear(p + "attention.self.key_proj");
         L.v = ws_->linear(p + "attention.self.value_proj");
         L.o = ws_->linear(p + "attention.output.dense");
+        L.qkv = ws_->conv_cat({p + "attention.self.query_proj", p + "attention.self.key_proj", p + "attention.self.value_proj"});
         L.ln1_g = ws_->tensor(p + "attention.output.LayerNorm.weight");
         L.ln1_b = ws_->tensor(p + "attention.output.LayerNorm.bias");
         L.ffn1 = ws_->linear(p + "intermediate.dense");
@@ -192,6 +193,7 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     Plane X = arena_.plane(H, N), Q = arena_.plane(H, N), Kp = arena_.plane(H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
     Plane F = arena_.plane(cfg_.inter, N);
     float* VT = arena_.array<float>((size_t)N * H);
+    Plane QKV = arena_.plane(3 * H, N);
     std::vector<AttnGroup> ag(ng);
     std::vector<GemmGroup> g_st(ng), g_c2p(ng), g_p2c(ng), g_pv(ng);
     int64_t s_off = 0, c_off = 0, p_off = 0;
@@ -273,13 +275,14 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     const bool fused_attn = want_fused && deberta_attention_fits(maxT, wlen, d);
     for (int li = 0; li < cfg_.layers; ++li) {
         const Layer& Ly = layers_[li];
-        conv_plain(Ly.q, X, Q, 1, 0, nullptr, 1, stream_);
-        conv_plain(Ly.k, X, Kp, 1, 0, nullptr, 1, stream_);
-        linear_tokmajor(Ly.v, X, VT, H, stream_);
         if (fused_attn) {
-            deberta_attention(d_ag, ng, Q.p, Kp.p, Q.ld, VT, H, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo, wlen, d_tab, maxT - 1, span, inv_scale,
-                              lay.d_mask, d, ctx.p, ctx.ld, stream_);
+            conv_plain(Ly.qkv, X, QKV, 1, 0, nullptr, 1, stream_);   // q | k | v in one product; V stays k-major
+            deberta_attention(d_ag, ng, QKV.p, QKV.rows(H, H).p, QKV.ld, QKV.rows(2 * H, H).p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo, wlen, d_tab,
+                              maxT - 1, span, inv_scale, lay.d_mask, d, ctx.p, ctx.ld, stream_);
         } else {
+            conv_plain(Ly.q, X, Q, 1, 0, nullptr, 1, stream_);
+            conv_plain(Ly.k, X, Kp, 1, 0, nullptr, 1, stream_);
+            linear_tokmajor(Ly.v, X, VT, H, stream_);
             grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxT, maxT, inv_scale, fl_tt);
             grouped(Ly.pos_k.p, ldp, Q.p, Q.ld, C2P, lds, d_g + ng, wlen, maxT, 1.0f, fl_tw);
             grouped(Kp.p, Kp.ld, Ly.pos_q.p, ldp, P2C, win_ld, d_g + 2 * ng, maxT, wlen, 1.0f, fl_tw);

@@ -54,7 +54,7 @@ PackedConv WeightStore::conv_cat(const std::vector<std::string>& prefixes) {
     std::vector<const HostTensor*> ts;
     for (const auto& pre : prefixes) {
         const HostTensor& t = blob_.get(pre + ".weight");
-        SBV2_REQUIRE(t.dims.size() == 3 && t.dims[2] == 1, "conv_cat: 1x1 conv weights only: " + pre);
+        SBV2_REQUIRE((t.dims.size() == 3 && t.dims[2] == 1) || t.dims.size() == 2, "conv_cat: 1x1 conv / linear weights only: " + pre);
         SBV2_REQUIRE(ts.empty() || t.dims[1] == ts[0]->dims[1], "conv_cat: input channel mismatch: " + pre);
         ts.push_back(&t);
         pc.cout += (int)t.dims[0];

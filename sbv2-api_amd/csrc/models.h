@@ -116,6 +116,7 @@ class BertModel {
   private:
     struct Layer {
         PackedConv q, k, v, o, ffn1, ffn2;
+        PackedConv qkv;   // rows q | k | v: one product for the fused-attention path (k-major V)
         float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
         Plane pos_k, pos_q;  // key_proj / query_proj of the LayerNorm'ed relative embeddings: [H][2*span]
     };

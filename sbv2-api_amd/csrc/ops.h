@@ -27,7 +27,7 @@ void dds_dw_ln_gelu(Plane in, Plane out, const float* w, const float* b, int dil
 
 // fused disentangled attention for short sequences (attn_deberta.hip); deberta_attention_fits says whether a batch qualifies
 bool deberta_attention_fits(int maxT, int wlen, int dh);
-void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* VT, int H, const float* posk,
+void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* V, const float* posk,
                        const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span, float inv_scale,
                        const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s);
 void deberta_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, const float* c2pT, const float* p2c,
