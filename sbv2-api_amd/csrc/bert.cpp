@@ -187,22 +187,37 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     int* d_tab = arena_.array<int>(tab.size());
     arena_.upload(d_tab, tab.data(), sizeof(int) * tab.size(), stream_);
 
-    // attention problem descriptors
+    // attention problem descriptors.  Utterances of <= 64 tokens (the usual sentence) take the fused kernel of attn_deberta.hip, longer
+    // ones the grouped-GEMM + softmax path; a batch may hold both.  SBV2_BERT_ATTN=unfused sends everything down the second path.
+    static const bool want_fused = !(getenv("SBV2_BERT_ATTN") && std::string(getenv("SBV2_BERT_ATTN")) == "unfused");
+    // bucket window reachable by a short utterance (|i - j| <= 63)
+    int win_lo_s = 0, wlen_s = 1;
+    {
+        int lo = 2 * span, hi2 = 0;
+        const int c = maxT - 1, r = std::min(maxT - 1, 63);
+        for (int dlt = -r; dlt <= r; ++dlt) {
+            const int v = tab[c + dlt];
+            lo = std::min(lo, std::min(clampi(v + span), clampi(-v + span)));
+            hi2 = std::max(hi2, std::max(clampi(v + span), clampi(-v + span)));
+        }
+        win_lo_s = lo / 4 * 4;
+        wlen_s = hi2 - win_lo_s + 1;
+    }
     const int lds = round_up(maxT, 4);
-    const int ng = n * nh;
-    Plane X = arena_.plane(H, N), Q = arena_.plane(H, N), Kp = arena_.plane(H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
+    Plane X = arena_.plane(H, N), QKV = arena_.plane(3 * H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
+    Plane Q = QKV.rows(0, H), Kp = QKV.rows(H, H), Vp = QKV.rows(2 * H, H);
     Plane F = arena_.plane(cfg_.inter, N);
-    float* VT = arena_.array<float>((size_t)N * H);
-    Plane QKV = arena_.plane(3 * H, N);
-    std::vector<AttnGroup> ag(ng);
-    std::vector<GemmGroup> g_st(ng), g_c2p(ng), g_p2c(ng), g_pv(ng);
+    std::vector<AttnGroup> ag_s, ag_l;
+    std::vector<GemmGroup> g_st, g_c2p, g_p2c, g_pv;
     int64_t s_off = 0, c_off = 0, p_off = 0;
+    int maxTL = 0;
     const int ldp = layers_[0].pos_k.ld;
-    for (int u = 0; u < n; ++u)
+    for (int u = 0; u < n; ++u) {
+        const int T = L[u];
+        const bool is_short = want_fused && deberta_attention_fits(T, wlen_s, d);
+        if (!is_short) maxTL = std::max(maxTL, T);
         for (int h = 0; h < nh; ++h) {
-            const int gi = u * nh + h;
-            const int T = L[u];
-            AttnGroup& a = ag[gi];
+            AttnGroup a;
             a.qk_off = (int64_t)h * d * X.ld + lay.start[u];
             a.s_off = s_off;
             a.aux_off = c_off;
@@ -211,24 +226,41 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
             a.lds = lds;
             a.col0 = lay.start[u];
             a.head = h;
-            g_st[gi] = GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, d, T};                                   // S^T = K^T Q
-            g_c2p[gi] = GemmGroup{(int64_t)h * d * ldp + win_lo, a.qk_off, c_off, 0, wlen, T, d, T};          // posK^T Q
-            g_p2c[gi] = GemmGroup{a.qk_off, (int64_t)h * d * ldp + win_lo, p_off, 0, T, wlen, d, wlen};       // K^T posQ
-            g_pv[gi] = GemmGroup{(int64_t)lay.start[u] * H + h * d, s_off, a.qk_off, 0, d, T, T, T};          // V P^T
+            if (is_short) {
+                ag_s.push_back(a);
+                continue;
+            }
+            ag_l.push_back(a);
+            g_st.push_back(GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, d, T});                                   // S^T = K^T Q
+            g_c2p.push_back(GemmGroup{(int64_t)h * d * ldp + win_lo, a.qk_off, c_off, 0, wlen, T, d, T});          // posK^T Q
+            g_p2c.push_back(GemmGroup{a.qk_off, (int64_t)h * d * ldp + win_lo, p_off, 0, T, wlen, d, wlen});       // K^T posQ
+            g_pv.push_back(GemmGroup{(int64_t)lay.start[u] * H + h * d, s_off, a.qk_off, 0, d, T, T, T});          // V P^T
             s_off += (int64_t)T * lds;
             c_off += (int64_t)wlen * lds;
             p_off += (int64_t)T * win_ld;
         }
-    float* S = arena_.array<float>((size_t)s_off);
-    float* C2P = arena_.array<float>((size_t)c_off);
-    float* P2C = arena_.array<float>((size_t)p_off);
-    AttnGroup* d_ag = arena_.array<AttnGroup>(ng);
-    GemmGroup* d_g = arena_.array<GemmGroup>((size_t)4 * ng);
-    arena_.upload(d_ag, ag.data(), sizeof(AttnGroup) * ng, stream_);
-    arena_.upload(d_g, g_st.data(), sizeof(GemmGroup) * ng, stream_);
-    arena_.upload(d_g + ng, g_c2p.data(), sizeof(GemmGroup) * ng, stream_);
-    arena_.upload(d_g + 2 * ng, g_p2c.data(), sizeof(GemmGroup) * ng, stream_);
-    arena_.upload(d_g + 3 * ng, g_pv.data(), sizeof(GemmGroup) * ng, stream_);
+    }
+    const int ngS = (int)ag_s.size(), ngL = (int)ag_l.size();
+    float *S = nullptr, *C2P = nullptr, *P2C = nullptr, *VT = nullptr;
+    AttnGroup *d_agS = nullptr, *d_agL = nullptr;
+    GemmGroup* d_g = nullptr;
+    if (ngS) {
+        d_agS = arena_.array<AttnGroup>(ngS);
+        arena_.upload(d_agS, ag_s.data(), sizeof(AttnGroup) * ngS, stream_);
+    }
+    if (ngL) {
+        S = arena_.array<float>((size_t)s_off);
+        C2P = arena_.array<float>((size_t)c_off);
+        P2C = arena_.array<float>((size_t)p_off);
+        VT = arena_.array<float>((size_t)N * H);
+        d_agL = arena_.array<AttnGroup>(ngL);
+        d_g = arena_.array<GemmGroup>((size_t)4 * ngL);
+        arena_.upload(d_agL, ag_l.data(), sizeof(AttnGroup) * ngL, stream_);
+        arena_.upload(d_g, g_st.data(), sizeof(GemmGroup) * ngL, stream_);
+        arena_.upload(d_g + ngL, g_c2p.data(), sizeof(GemmGroup) * ngL, stream_);
+        arena_.upload(d_g + 2 * ngL, g_p2c.data(), sizeof(GemmGroup) * ngL, stream_);
+        arena_.upload(d_g + 3 * ngL, g_pv.data(), sizeof(GemmGroup) * ngL, stream_);
+    }
 
     const float inv_scale = 1.0f / std::sqrt((float)d * 3.0f);  // c2p + p2c => scale_factor 3 (:226-232)
 
@@ -258,36 +290,31 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         p.ldc = ldc;
         p.alpha = alpha;
         p.groups = grp;
-        p.ngroups = ng;
+        p.ngroups = ngL;
         p.maxM = maxM;
         p.maxN = maxN;
         p.flops_hint = flops;
         launch_conv(p, stream_);
     };
     double fl_tt = 0, fl_tw = 0;  // algorithmic FLOP of the grouped products (profiling only)
-    for (int u = 0; u < n; ++u) {
-        fl_tt += 2.0 * nh * (double)L[u] * L[u] * d;
-        fl_tw += 2.0 * nh * (double)L[u] * wlen * d;
+    for (const AttnGroup& a : ag_l) {
+        fl_tt += 2.0 * (double)a.T * a.T * d;
+        fl_tw += 2.0 * (double)a.T * wlen * d;
     }
 
-    // short sequences (every utterance <= 64 tokens: the usual sentence) take the fused attention; SBV2_BERT_ATTN=unfused for A/B runs
-    static const bool want_fused = !(getenv("SBV2_BERT_ATTN") && std::string(getenv("SBV2_BERT_ATTN")) == "unfused");
-    const bool fused_attn = want_fused && deberta_attention_fits(maxT, wlen, d);
     for (int li = 0; li < cfg_.layers; ++li) {
         const Layer& Ly = layers_[li];
-        if (fused_attn) {
-            conv_plain(Ly.qkv, X, QKV, 1, 0, nullptr, 1, stream_);   // q | k | v in one product; V stays k-major
-            deberta_attention(d_ag, ng, QKV.p, QKV.rows(H, H).p, QKV.ld, QKV.rows(2 * H, H).p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo, wlen, d_tab,
-                              maxT - 1, span, inv_scale, lay.d_mask, d, ctx.p, ctx.ld, stream_);
-        } else {
-            conv_plain(Ly.q, X, Q, 1, 0, nullptr, 1, stream_);
-            conv_plain(Ly.k, X, Kp, 1, 0, nullptr, 1, stream_);
-            linear_tokmajor(Ly.v, X, VT, H, stream_);
-            grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxT, maxT, inv_scale, fl_tt);
-            grouped(Ly.pos_k.p, ldp, Q.p, Q.ld, C2P, lds, d_g + ng, wlen, maxT, 1.0f, fl_tw);
-            grouped(Kp.p, Kp.ld, Ly.pos_q.p, ldp, P2C, win_ld, d_g + 2 * ng, maxT, wlen, 1.0f, fl_tw);
-            deberta_softmax(d_ag, ng, maxT, S, C2P, P2C, d_tab, maxT - 1, span, win_lo, win_ld, inv_scale, lay.d_mask, stream_);
-            grouped(VT, H, S, lds, ctx.p, ctx.ld, d_g + 3 * ng, d, maxT, 1.0f, fl_tt);
+        conv_plain(Ly.qkv, X, QKV, 1, 0, nullptr, 1, stream_);   // q | k | v in one product (k-major planes)
+        if (ngS)
+            deberta_attention(d_agS, ngS, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo_s, wlen_s, d_tab, maxT - 1, span, inv_scale,
+                              lay.d_mask, d, ctx.p, ctx.ld, stream_);
+        if (ngL) {
+            linear_tokmajor(Ly.v, X, VT, H, stream_);   // the grouped V P^T product wants V token-major
+            grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxTL, maxTL, inv_scale, fl_tt);
+            grouped(Ly.pos_k.p, ldp, Q.p, Q.ld, C2P, lds, d_g + ngL, wlen, maxTL, 1.0f, fl_tw);
+            grouped(Kp.p, Kp.ld, Ly.pos_q.p, ldp, P2C, win_ld, d_g + 2 * ngL, maxTL, wlen, 1.0f, fl_tw);
+            deberta_softmax(d_agL, ngL, maxTL, S, C2P, P2C, d_tab, maxT - 1, span, win_lo, win_ld, inv_scale, lay.d_mask, stream_);
+            grouped(VT, H, S, lds, ctx.p, ctx.ld, d_g + 3 * ngL, d, maxTL, 1.0f, fl_tt);
         }
         conv_plain(Ly.o, ctx, A, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &X);
         layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
