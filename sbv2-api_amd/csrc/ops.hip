@@ -756,34 +756,52 @@ void add_segvec_cl(float* x, int L, int C, const float* vec, int vec_ld, const i
     hipLaunchKernelGGL(k_add_segvec_cl, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, L, C, vec, vec_ld, seg_of, mask);
 }
 
-// Generator tail on a channels-last plane: one thread per output sample, C*k MACs from k consecutive rows
+// Generator tail on a channels-last plane: leaky-ReLU -> conv_post (C -> 1, k taps, no bias) -> tanh, written de-gapped per utterance.
+// A workgroup stages its 256 + k - 1 rows (activated once) and the C x k weights in LDS; read straight from global memory every
+// sample re-read its k rows and issued C * k weight loads (0.8 ms for 786 MB = 1 TB/s).
+constexpr int kPostMaxC = 32, kPostMaxK = 12;
 __global__ __launch_bounds__(256) void k_conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope,
                                                             const int* seg_start, const int* seg_len, const int64_t* pcm_off, int up,
                                                             float* pcm) {
+    __shared__ float xs[(256 + kPostMaxK) * (kPostMaxC + 4)];
+    __shared__ float ws[kPostMaxC * kPostMaxK];
     const int sg = blockIdx.y;
     const int64_t len = (int64_t)seg_len[sg] * up;
-    const int64_t sidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (sidx >= len) return;
-    const int64_t col = (int64_t)seg_start[sg] * up + sidx;
+    const int64_t s0 = (int64_t)blockIdx.x * 256;
+    if (s0 >= len) return;
+    const int tid = threadIdx.x;
     const int half = k / 2;
+    const int pitch = C + 4;
+    const int c4n = C >> 2;
+    const int64_t row0 = (int64_t)seg_start[sg] * up + s0 - half;   // plane row of staged row 0
+    for (int idx = tid; idx < (256 + k - 1) * c4n; idx += 256) {
+        const int r = idx / c4n, c4 = idx - r * c4n;
+        const int64_t q = row0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q >= 0 && q < L) v = *reinterpret_cast<const float4*>(x + q * C + c4 * 4);
+        v.x = fmaxf(v.x, v.x * slope);
+        v.y = fmaxf(v.y, v.y * slope);
+        v.z = fmaxf(v.z, v.z * slope);
+        v.w = fmaxf(v.w, v.w * slope);
+        *reinterpret_cast<float4*>(xs + r * pitch + c4 * 4) = v;
+    }
+    for (int idx = tid; idx < C * k; idx += 256) ws[idx] = w[idx];   // [c][j]
+    __syncthreads();
+    const int64_t sidx = s0 + tid;
+    if (sidx >= len) return;
     float a = 0.f;
     for (int j = 0; j < k; ++j) {
-        const int64_t q = col + j - half;
-        if (q < 0 || q >= L) continue;
-        const float4* r = reinterpret_cast<const float4*>(x + q * C);
+        const float* r = xs + (tid + j) * pitch;
         for (int c = 0; c < C; c += 4) {
-            float4 v = r[c >> 2];
-            v.x = v.x >= 0.f ? v.x : v.x * slope;
-            v.y = v.y >= 0.f ? v.y : v.y * slope;
-            v.z = v.z >= 0.f ? v.z : v.z * slope;
-            v.w = v.w >= 0.f ? v.w : v.w * slope;
-            a += w[c * k + j] * v.x + w[(c + 1) * k + j] * v.y + w[(c + 2) * k + j] * v.z + w[(c + 3) * k + j] * v.w;
+            const float4 v = *reinterpret_cast<const float4*>(r + c);
+            a += ws[c * k + j] * v.x + ws[(c + 1) * k + j] * v.y + ws[(c + 2) * k + j] * v.z + ws[(c + 3) * k + j] * v.w;
         }
     }
     pcm[pcm_off[sg] + sidx] = tanhf(a);
 }
 void conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope, const int* seg_start, const int* seg_len,
                        const int64_t* pcm_off, int nseg, int up, int64_t max_samples, float* pcm, hipStream_t s) {
+    SBV2_REQUIRE(C <= kPostMaxC && (C & 3) == 0 && k <= kPostMaxK, "conv_post: more than 32 channels or 12 taps");
     hipLaunchKernelGGL(k_conv_post_tanh_cl, dim3((unsigned)((max_samples + 255) / 256), nseg), dim3(256), 0, s, x, C, L, w, k, slope,
                        seg_start, seg_len, pcm_off, up, pcm);
 }
