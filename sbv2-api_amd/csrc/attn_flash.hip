@@ -212,15 +212,240 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
         }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant for the flow (everything after the integer durations): the two big products run on v_mfma_f32_32x32x16_bf16 with
+// hi/lo operands (3 MFMAs per product, ~1e-5 relative like the decoder convs), 18 + 18 MFMAs of 32 cycles per 32-key tile instead of
+// 96 f32 MFMAs of 64.  Softmax, the relative terms and all accumulation stay f32.  Layouts:
+//   K tile  -> LDS [32 keys][dk] bf16 hi | lo (row pitch 2 dk + 16 bytes: 16 consecutive keys hit 16 distinct 16-byte slots);
+//              A fragment of key row j, k-step s = 16 bytes at d = 16 s + 8 h
+//   q       -> registers: B fragments (8 consecutive d per lane), hi and lo, 6 k-steps
+//   V tile  -> LDS [dk channels][32 keys] bf16 hi | lo, keys stored in the order the accumulator registers hold them
+//              (bits 2 and 3 of the key index swapped), so that the A fragment of PV's k-step s' is one 16-byte read and the B fragment is
+//              simply the eight score registers 8 s' .. 8 s' + 7 converted to bf16 hi / lo
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 fa_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void fa_split8(const float (&v)[8], fa_bf16x8& hi, fa_bf16x8& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        hi[t] = (__bf16)v[t];
+        lo[t] = (__bf16)(v[t] - (float)hi[t]);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_vits_flash_x3(
+    const AttnGroup* groups, const float* Q, const float* K, const float* V, int ld, float* ctx, int ldc, int dk, const float* erk,
+    const float* erv, int w, float qscale) {
+    constexpr int DR = DT * 32;
+    constexpr int NP = DR / 8;
+    constexpr int KS = DR / 16;            // bf16 k-steps over the (padded) head dimension
+    constexpr int PK = 2 * DR + 16;        // bytes per key row of the K tile
+    constexpr int PV = 2 * 32 + 16;        // bytes per channel row of the V tile
+    __shared__ __attribute__((aligned(16))) char kt_hi[32 * PK], kt_lo[32 * PK];
+    __shared__ __attribute__((aligned(16))) char vt_hi[DR * PV], vt_lo[DR * PV];
+    __shared__ float erk_s[kFaBand * DR], erv_s[kFaBand * DR];
+    __shared__ float rk_s[4][kFaBand][32], band_s[4][kFaBand][32];
+
+    const AttnGroup g = groups[blockIdx.y];
+    const int T = g.T;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < T;
+    const int i = i0 + col;
+    const int ic = min(i, T - 1);
+    const int64_t off = (int64_t)g.head * dk * ld + g.col0;
+    const float* Qg = Q + off;
+    const float* Kg = K + off;
+    const float* Vg = V + off;
+    const int nb = 2 * w + 1;
+
+    for (int idx = tid; idx < kFaBand * DR; idx += kFaThreads) {
+        const int r = idx / DR, d = idx - r * DR;
+        const bool in = r < nb && d < dk;
+        erk_s[idx] = in ? erk[r * dk + d] : 0.f;
+        erv_s[idx] = in ? erv[r * dk + d] : 0.f;
+    }
+    const int sc = tid & 31, sr = tid >> 5;
+    const int scp = (sc & ~12) | ((sc & 4) << 1) | ((sc & 8) >> 1);   // key order of the V tile (bits 2 and 3 swapped)
+    float kreg[NP], vreg[NP];
+    auto load_tile = [&](int j0) {
+        const int jc = min(j0 + sc, T - 1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int d = min(sr + 8 * p, dk - 1);
+            kreg[p] = Kg[(int64_t)d * ld + jc];
+            vreg[p] = Vg[(int64_t)d * ld + jc];
+        }
+    };
+    auto store_tile = [&](int j0) {
+        const bool jin = j0 + sc < T;     // keys beyond the utterance: zero operands (their scores are masked anyway, V must not be NaN)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int d = sr + 8 * p;
+            const bool in = d < dk && jin;
+            const float kv = in ? kreg[p] : 0.f, vv = in ? vreg[p] : 0.f;
+            const __bf16 kh_ = (__bf16)kv, vh_ = (__bf16)vv;
+            *reinterpret_cast<__bf16*>(kt_hi + sc * PK + d * 2) = kh_;
+            *reinterpret_cast<__bf16*>(kt_lo + sc * PK + d * 2) = (__bf16)(kv - (float)kh_);
+            *reinterpret_cast<__bf16*>(vt_hi + d * PV + scp * 2) = vh_;
+            *reinterpret_cast<__bf16*>(vt_lo + d * PV + scp * 2) = (__bf16)(vv - (float)vh_);
+        }
+    };
+    load_tile(0);
+    __syncthreads();   // erk_s / erv_s
+
+    {   // relative-key logits (f32, as in k_vits_flash)
+        float part[kFaBand];
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
+#pragma unroll 2
+        for (int s = 0; s < DR / 2; ++s) {
+            const int d = 2 * s + kh;
+            const float qd = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+#pragma unroll
+            for (int r = 0; r < kFaBand; ++r) part[r] += qd * erk_s[r * DR + d];
+        }
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) {
+            const float other = __shfl_xor(part[r], 32);
+            const float lo = kh ? other : part[r];
+            const float hi = kh ? part[r] : other;
+            rk_s[wave][r][col] = (lo + hi) * qscale;
+            band_s[wave][r][col] = kFaNegBig;
+        }
+    }
+    // q fragments: lane (column i, half h) holds d = 16 s + 8 h + t
+    fa_bf16x8 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = 16 * s + 8 * kh + t;
+            v[t] = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+        }
+        fa_split8(v, qh[s], ql[s]);
+    }
+
+    f32x16 cacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[dt][r] = 0.f;
+    float m = kFaNegBig, l = 0.f;
+
+    const int ntiles = (T + 31) >> 5;
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int j0 = jt * 32;
+        store_tile(j0);
+        __syncthreads();
+        if (jt + 1 < ntiles) load_tile(j0 + 32);
+        if (active) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const fa_bf16x8 ah = *reinterpret_cast<const fa_bf16x8*>(kt_hi + col * PK + (16 * s + 8 * kh) * 2);
+                const fa_bf16x8 al = *reinterpret_cast<const fa_bf16x8*>(kt_lo + col * PK + (16 * s + 8 * kh) * 2);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sacc, 0, 0, 0);
+            }
+            const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
+            float mt = kFaNegBig;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float sv = sacc[r] * qscale;
+                if (diag) {
+                    const int rr = j - i + w;
+                    if (rr >= 0 && rr < nb && j < T) {
+                        sv += rk_s[wave][rr][col];
+                        band_s[wave][rr][col] = sv;
+                    }
+                }
+                sv = j < T ? sv : kFaNegBig;
+                sacc[r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);
+            const float alpha = expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(sacc[r] - mn);
+                sacc[r] = e;
+                ps += e;
+            }
+            {
+                const float other = __shfl_xor(ps, 32);
+                const float lo = kh ? other : ps;
+                const float hi = kh ? ps : other;
+                l = l * alpha + (lo + hi);
+            }
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float pv8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pv8[t] = sacc[8 * sp + t];
+                fa_bf16x8 ph, pl;
+                fa_split8(pv8, ph, pl);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const fa_bf16x8 vh = *reinterpret_cast<const fa_bf16x8*>(vt_hi + (dt * 32 + col) * PV + (16 * sp + 8 * kh) * 2);
+                    const fa_bf16x8 vl = *reinterpret_cast<const fa_bf16x8*>(vt_lo + (dt * 32 + col) * PV + (16 * sp + 8 * kh) * 2);
+                    cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, cacc[dt], 0, 0, 0);
+                    cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, cacc[dt], 0, 0, 0);
+                    cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, cacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+
+    const float inv = 1.0f / l;
+    float pb[kFaBand];
+#pragma unroll
+    for (int r = 0; r < kFaBand; ++r) pb[r] = expf(band_s[wave][r][col] - m) * inv;
+    float* Cg = ctx + (int64_t)g.head * dk * ldc + g.col0;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = cacc[dt][r] * inv;
+#pragma unroll
+            for (int b = 0; b < kFaBand; ++b) v += pb[b] * erv_s[b * DR + d];
+            if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
+        }
+}
 }  // namespace
 
 void vits_flash_attention(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, const float* V, int ld, float* ctx,
-                          int ldc, int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
+                          int ldc, int dk, const float* erk, const float* erv, int window, float qscale, bool split_bf16, hipStream_t s) {
     SBV2_REQUIRE(window <= kFaMaxWin, "relative attention window larger than the compiled maximum");
     SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
     if (ngroups <= 0 || maxT <= 0) return;
     const dim3 grid((maxT + 127) / 128, ngroups), block(kFaThreads);
-    if (dk <= 32) hipLaunchKernelGGL(k_vits_flash<1>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+    if (split_bf16) {   // the flow: split-bf16 matrix cores (exact f32 is reserved for what decides the integer durations)
+        if (dk <= 32) hipLaunchKernelGGL(k_vits_flash_x3<1>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+        else if (dk <= 64) hipLaunchKernelGGL(k_vits_flash_x3<2>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+        else hipLaunchKernelGGL(k_vits_flash_x3<3>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
+    } else if (dk <= 32) hipLaunchKernelGGL(k_vits_flash<1>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
     else if (dk <= 64) hipLaunchKernelGGL(k_vits_flash<2>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
     else hipLaunchKernelGGL(k_vits_flash<3>, grid, block, 0, s, groups, Q, K, V, ld, ctx, ldc, dk, erk, erv, window, qscale);
     HIP_CHECK(hipGetLastError());

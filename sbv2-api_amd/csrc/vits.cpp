@@ -305,6 +305,10 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     const Arena::Mark mk = ar.mark();
     // SBV2_ATTN=unfused keeps the four-launch attention (grouped GEMM, softmax, grouped GEMM, relative-value add) for A/B runs
     static const bool fused = !(getenv("SBV2_ATTN") && std::string(getenv("SBV2_ATTN")) == "unfused");
+    // SBV2_ATTN=f32 keeps the fused kernel on the exact-f32 MFMA everywhere; by default an encoder whose convs run on the split-bf16
+    // matrix cores (the flow: nothing there feeds the integer durations) takes the split-bf16 attention as well
+    static const bool attn_f32 = getenv("SBV2_ATTN") && std::string(getenv("SBV2_ATTN")) == "f32";
+    const bool split_attn = !attn_f32 && e.layers[0].ffn1.cl.parts == 2 && (H / heads) % 16 == 0;
     const AttnPlan pl = make_attn_plan(lay, H, heads, x.ld, cfg_.window, ar, stream_, !fused);
     Plane QKV = ar.plane(3 * H, N);
     Plane Q = QKV.rows(0, H), K = QKV.rows(H, H), ctx = ar.plane(H, N), Y = ar.plane(H, N);
@@ -324,7 +328,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
         if (fused) {
             conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
             vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
-                                 stream_);
+                                 split_attn, stream_);
         } else {
             conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
             conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
