@@ -89,7 +89,7 @@ def main():
             if send is None:
                 send = torch.empty(n, dtype=torch.float32, device="cuda")
                 recv = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
-            pipe.fetch_ticket_to_device(ticket, send.data_ptr())
+            pipe.fetch_ticket_to_device(ticket, send.data_ptr(), send.numel())
             dist.gather(send, recv, dst=0)
         else:
             pipe.wait(ticket)

@@ -15,6 +15,7 @@
 #define SBV2_CORE_HPP
 
 #include <cstdint>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -102,9 +103,14 @@ inline Array2f predict(Session& session, const std::vector<int64_t>& token_ids, 
 
 // model.rs:53-111: bert_ori [1024, T]; x_tst, tones, lang_ids i64[T]; sid i64[1]; style_vector f32[256] -> [1, 1, L].
 // noise_seed is not part of the reference signature: it selects the counter-based stream standing in for the graph's RandomNormalLike.
+// Like the reference (ONNX Runtime draws fresh noise on every run) the default is a fresh seed per call; pass one for reproducible output.
+inline uint64_t fresh_noise_seed() {
+    static std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
 inline Array3f synthesize(Session& session, const Array2f& bert_ori, const std::vector<int64_t>& x_tst, const std::vector<int64_t>& sid,
                           const std::vector<int64_t>& tones, const std::vector<int64_t>& lang_ids, const std::vector<float>& style_vector,
-                          float sdp_ratio, float length_scale, float noise_scale, float noise_scale_w, uint64_t noise_seed = 0) {
+                          float sdp_ratio, float length_scale, float noise_scale, float noise_scale_w, uint64_t noise_seed = fresh_noise_seed()) {
     if (session.is_bert() || !session.vits()) throw Error("synthesize: the session does not hold the VITS graph");
     const size_t T = x_tst.size();
     if (bert_ori.cols != T || tones.size() != T || lang_ids.size() != T) throw Error("synthesize: sequence lengths differ");

@@ -85,16 +85,18 @@ typedef struct sbv2_batch {
 
 /* Runs the batch; results stay on the device until fetched.  pcm_lens: caller-allocated [n]. */
 int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* pcm_lens);
-/* Concatenated PCM of the last batch (sum of pcm_lens samples) -> host. */
-int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm);
+/* Concatenated PCM of the last batch (sum of pcm_lens samples) -> host.  capacity = samples `pcm` can hold; a batch that does not
+ * fit is refused (no write). */
+int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm, int64_t capacity);
 /* Device pointer to the concatenated PCM of the last batch (valid until the next call on the handle). */
 const float* sbv2_vits_pcm_device(sbv2_vits* h, int64_t* total);
 /* Copies the concatenated PCM of the last batch into caller-owned DEVICE memory (e.g. the send buffer of the RCCL gather). */
-int sbv2_vits_copy_pcm_device(sbv2_vits* h, void* dst_device);
+int sbv2_vits_copy_pcm_device(sbv2_vits* h, void* dst_device, int64_t capacity);
 /* Blocks until every kernel the handle has launched is complete (the batch calls are asynchronous up to the PCM). */
 int sbv2_sync(sbv2_vits* h);
-/* Predicted integer durations w_ceil (before any forcing) and log-durations of the last batch, concatenated [sum T]. */
-int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw);
+/* Predicted integer durations w_ceil (before any forcing) and log-durations of the last batch, concatenated [sum T];
+ * capacity = entries each non-NULL output can hold. */
+int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw, int64_t capacity);
 /* Debug/parity: keep named intermediates of the next calls (x_emb, x, stats, z_p, z, dec_pre, dec_stage<i>). */
 int sbv2_vits_set_trace(sbv2_vits* h, int on);
 int sbv2_vits_get_trace(sbv2_vits* h, const char* name, int64_t utt, float* out, int64_t cap, int64_t* rows, int64_t* cols);
@@ -109,14 +111,18 @@ int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* 
 
 /* Calls are pipelined: call n runs on execution context n % SBV2_PIPELINE_DEPTH (default 2; own stream + workspace, shared
  * weights) and returns once its kernels are enqueued, so the latency-bound DeBERTa / text / flow part of the next batch overlaps
- * the HiFi-GAN kernels of this one.  The ticket (= context index) of the most recent call identifies its results until that
- * context is used again (depth calls later). */
-int sbv2_pipeline_last_ticket(sbv2_pipeline* p);
-int sbv2_pipeline_wait(sbv2_pipeline* p, int ticket);   /* blocks until that run is complete */
-int sbv2_pipeline_sync(sbv2_pipeline* p);               /* ... until every run is complete */
-/* Concatenated PCM of a run in utterance order (waits for it); dst_is_device != 0: dst is device memory. */
-int sbv2_pipeline_fetch_pcm_ticket(sbv2_pipeline* p, int ticket, float* dst, int dst_is_device);
-int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int dst_is_device);   /* the most recent run */
+ * the HiFi-GAN kernels of this one.  Every run gets a TICKET (1, 2, 3, ...: the call number); its results stay available until the
+ * run `depth` calls later reuses its context, after which the ticket is stale and every call with it fails. */
+int64_t sbv2_pipeline_last_ticket(sbv2_pipeline* p);
+int sbv2_pipeline_wait(sbv2_pipeline* p, int64_t ticket);   /* blocks until that run is complete */
+int sbv2_pipeline_sync(sbv2_pipeline* p);                   /* ... until every run is complete */
+/* Concatenated PCM of a run in utterance order (waits for it); capacity = samples dst can hold (a longer result is refused);
+ * dst_is_device != 0: dst is device memory. */
+int sbv2_pipeline_fetch_pcm_ticket(sbv2_pipeline* p, int64_t ticket, float* dst, int64_t capacity, int dst_is_device);
+int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int64_t capacity, int dst_is_device);   /* the most recent run */
+/* Pinned (page-locked) host memory for PCM destinations: device -> host copies into it run at the full PCIe rate and overlap compute. */
+void* sbv2_host_alloc(size_t bytes);
+void sbv2_host_free(void* p);
 
 /* ---- test hooks (no reference counterpart) ------------------------------------------------------------------------ */
 /* bucket(rel) for rel in [-(max_s-1), max_s-1] (transformers modeling_deberta_v2.py:57-69); host only, no GPU needed. */

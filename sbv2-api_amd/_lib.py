@@ -39,23 +39,25 @@ SYMBOLS = {
                                        C.c_float, C.c_float, C.c_uint64, C.POINTER(f32p), i64p]),
     "sbv2_pcm_free": (None, [f32p]),
     "sbv2_vits_synthesize_batch": (C.c_int, [C.c_void_p, C.POINTER(Sbv2Batch), i64p]),
-    "sbv2_vits_fetch_pcm": (C.c_int, [C.c_void_p, f32p]),
+    "sbv2_vits_fetch_pcm": (C.c_int, [C.c_void_p, f32p, C.c_int64]),
     "sbv2_vits_pcm_device": (C.c_void_p, [C.c_void_p, i64p]),
-    "sbv2_vits_copy_pcm_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sbv2_vits_copy_pcm_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "sbv2_sync": (C.c_int, [C.c_void_p]),
     "sbv2_prof_begin": (C.c_int, []),
     "sbv2_prof_end": (C.c_int, [C.c_char_p, C.c_int64]),
-    "sbv2_vits_fetch_durations": (C.c_int, [C.c_void_p, i64p, f32p]),
+    "sbv2_vits_fetch_durations": (C.c_int, [C.c_void_p, i64p, f32p, C.c_int64]),
     "sbv2_vits_set_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "sbv2_vits_get_trace": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, f32p, C.c_int64, i64p, i64p]),
     "sbv2_pipeline_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "sbv2_pipeline_destroy": (None, [C.c_void_p]),
     "sbv2_pipeline_run": (C.c_int, [C.c_void_p, C.POINTER(Sbv2Batch), i64p, i64p, i64p, i64p]),
     "sbv2_pipeline_sync": (C.c_int, [C.c_void_p]),
-    "sbv2_pipeline_fetch_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
-    "sbv2_pipeline_fetch_pcm_ticket": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
-    "sbv2_pipeline_last_ticket": (C.c_int, [C.c_void_p]),
-    "sbv2_pipeline_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbv2_pipeline_fetch_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "sbv2_pipeline_fetch_pcm_ticket": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
+    "sbv2_pipeline_last_ticket": (C.c_int64, [C.c_void_p]),
+    "sbv2_pipeline_wait": (C.c_int, [C.c_void_p, C.c_int64]),
+    "sbv2_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "sbv2_host_free": (None, [C.c_void_p]),
     "sbv2_debug_bucket_table": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "sbv2_debug_conv1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
     "sbv2_debug_conv_transpose1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

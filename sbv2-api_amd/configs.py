@@ -5,14 +5,16 @@ here); tests/test_host_cpu.py checks that the two copies agree."""
 
 #: ku-nlp/deberta-v2-large-japanese-char-wwm as exported by convert_deberta.py:11,25 — output is
 #: hidden_states[-3] of 25 = the state after layer 22 (convert_deberta.py:34), so only 22 layers run.
+#: conv_kernel_size / conv_act = DebertaV2Encoder.conv, the ConvLayer after layer 0 (recalled for the ku-nlp checkpoint, see the oracle).
 DEBERTA_FULL = dict(
     vocab_size=22012, hidden=1024, layers=22, heads=16, intermediate=4096,
-    position_buckets=256, max_relative_positions=512, ln_eps=1e-7,
+    position_buckets=256, max_relative_positions=512, ln_eps=1e-7, conv_kernel_size=3, conv_act="gelu",
 )
 DEBERTA_TINY = dict(
     vocab_size=96, hidden=64, layers=2, heads=4, intermediate=128,
-    position_buckets=8, max_relative_positions=32, ln_eps=1e-7,
+    position_buckets=8, max_relative_positions=32, ln_eps=1e-7, conv_kernel_size=0, conv_act="gelu",
 )
+DEBERTA_TINY_CONV = dict(DEBERTA_TINY, conv_kernel_size=3, conv_act="gelu")
 
 #: Style-Bert-VITS2 JP-Extra defaults (configs/config_jp_extra.json upstream); n_vocab = 112 symbols
 #: (crates/sbv2_core/src/norm.rs:57-96), tones 12, languages 3.

@@ -23,11 +23,16 @@ struct sbv2_pipeline {
     // execution contexts: context 0 is the caller's pair of handles, the others are clones (shared weights, own stream + arena)
     std::vector<std::unique_ptr<BertModel>> bclones;
     std::vector<std::unique_ptr<VitsModel>> vclones;
-    int64_t calls = 0;
-    int last_ctx = 0;
+    int64_t calls = 0;   // tickets are call numbers 1, 2, ...: ticket t ran on context (t - 1) % depth and is valid until that context is reused
     BertModel& bm(int i) { return i == 0 ? *bert->m : *bclones[i - 1]; }
     VitsModel& vm(int i) { return i == 0 ? *vits->m : *vclones[i - 1]; }
     int contexts() const { return 1 + (int)vclones.size(); }
+    // context of a ticket; throws for tickets never issued or already overwritten by a later run on the same context
+    int ctx_of(int64_t ticket) const {
+        SBV2_REQUIRE(ticket >= 1 && ticket <= calls, "unknown pipeline ticket");
+        SBV2_REQUIRE(ticket > calls - contexts(), "stale pipeline ticket: its execution context has been reused by a later run");
+        return (int)((ticket - 1) % contexts());
+    }
 };
 
 #define API_BEGIN try {
@@ -146,9 +151,10 @@ int sbv2_vits_synthesize_batch(sbv2_vits* h, const sbv2_batch* batch, int64_t* p
     for (int i = 0; i < v.n; ++i) pcm_lens[i] = h->m->pcm_lens()[i];
     API_END
 }
-int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm) {
+int sbv2_vits_fetch_pcm(sbv2_vits* h, float* pcm, int64_t capacity) {
     API_BEGIN
     SBV2_REQUIRE(h && pcm, "bad arguments");
+    SBV2_REQUIRE(capacity >= h->m->pcm_total(), "PCM buffer too small: " + std::to_string(capacity) + " < " + std::to_string(h->m->pcm_total()));
     h->m->copy_pcm(pcm);
     API_END
 }
@@ -157,9 +163,10 @@ const float* sbv2_vits_pcm_device(sbv2_vits* h, int64_t* total) {
     if (total) *total = h->m->pcm_total();
     return h->m->pcm_device();
 }
-int sbv2_vits_copy_pcm_device(sbv2_vits* h, void* dst_device) {
+int sbv2_vits_copy_pcm_device(sbv2_vits* h, void* dst_device, int64_t capacity) {
     API_BEGIN
     SBV2_REQUIRE(h && dst_device, "bad arguments");
+    SBV2_REQUIRE(capacity >= h->m->pcm_total(), "PCM buffer too small");
     HIP_CHECK(hipSetDevice(h->m->device()));
     HIP_CHECK(hipMemcpyAsync(dst_device, h->m->pcm_device(), sizeof(float) * (size_t)h->m->pcm_total(), hipMemcpyDeviceToDevice,
                              h->m->stream()));
@@ -185,11 +192,12 @@ int sbv2_prof_end(char* json, int64_t cap) {
     std::memcpy(json, s.c_str(), s.size() + 1);
     API_END
 }
-int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw) {
+int sbv2_vits_fetch_durations(sbv2_vits* h, int64_t* durations, float* logw, int64_t capacity) {
     API_BEGIN
     SBV2_REQUIRE(h, "bad arguments");
     const auto& d = h->m->durations();
     const auto& l = h->m->logw();
+    SBV2_REQUIRE(capacity >= (int64_t)d.size(), "duration buffer too small");
     if (durations)
         for (size_t i = 0; i < d.size(); ++i) durations[i] = d[i];
     if (logw) std::memcpy(logw, l.data(), sizeof(float) * l.size());
@@ -309,20 +317,20 @@ int sbv2_pipeline_run(sbv2_pipeline* p, const sbv2_batch* batch, const int64_t* 
     SBV2_REQUIRE(p && token_ids && s_lens && word2ph && pcm_lens, "bad arguments");
     const VitsBatch v = to_batch(batch);
     const int ctx = (int)(p->calls % p->contexts());
-    p->last_ctx = ctx;
     ++p->calls;
     pipeline_run_one(p->bm(ctx), p->vm(ctx), v, token_ids, s_lens, word2ph);
     for (int i = 0; i < v.n; ++i) pcm_lens[i] = p->vm(ctx).pcm_lens()[i];
     API_END
 }
 
-int sbv2_pipeline_last_ticket(sbv2_pipeline* p) { return p ? p->last_ctx : -1; }
+int64_t sbv2_pipeline_last_ticket(sbv2_pipeline* p) { return p ? p->calls : -1; }
 
-int sbv2_pipeline_wait(sbv2_pipeline* p, int ticket) {
+int sbv2_pipeline_wait(sbv2_pipeline* p, int64_t ticket) {
     API_BEGIN
-    SBV2_REQUIRE(p && ticket >= 0 && ticket < p->contexts(), "bad ticket");
+    SBV2_REQUIRE(p, "bad arguments");
+    const int ctx = p->ctx_of(ticket);
     HIP_CHECK(hipSetDevice(p->vits->m->device()));
-    HIP_CHECK(hipStreamSynchronize(p->vm(ticket).stream()));
+    HIP_CHECK(hipStreamSynchronize(p->vm(ctx).stream()));
     API_END
 }
 
@@ -334,19 +342,35 @@ int sbv2_pipeline_sync(sbv2_pipeline* p) {
     API_END
 }
 
-// Concatenated PCM of the run with this ticket (utterance order); dst_is_device != 0: dst is device memory (the RCCL send buffer)
-int sbv2_pipeline_fetch_pcm_ticket(sbv2_pipeline* p, int ticket, float* dst, int dst_is_device) {
+// Concatenated PCM of the run with this ticket (utterance order); dst_is_device != 0: dst is device memory (the RCCL send buffer).
+// capacity = samples dst can hold: a run whose PCM is longer is refused instead of overflowing the buffer.
+int sbv2_pipeline_fetch_pcm_ticket(sbv2_pipeline* p, int64_t ticket, float* dst, int64_t capacity, int dst_is_device) {
     API_BEGIN
-    SBV2_REQUIRE(p && dst && ticket >= 0 && ticket < p->contexts(), "bad arguments");
-    VitsModel& vm = p->vm(ticket);
+    SBV2_REQUIRE(p && dst, "bad arguments");
+    VitsModel& vm = p->vm(p->ctx_of(ticket));
+    SBV2_REQUIRE(capacity >= vm.pcm_total(), "PCM buffer too small: " + std::to_string(capacity) + " < " + std::to_string(vm.pcm_total()));
     HIP_CHECK(hipSetDevice(vm.device()));
     HIP_CHECK(hipMemcpyAsync(dst, vm.pcm_device(), sizeof(float) * (size_t)vm.pcm_total(),
                              dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, vm.stream()));
     HIP_CHECK(hipStreamSynchronize(vm.stream()));
     API_END
 }
-int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int dst_is_device) {
-    return sbv2_pipeline_fetch_pcm_ticket(p, p ? p->last_ctx : -1, dst, dst_is_device);
+int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int64_t capacity, int dst_is_device) {
+    return sbv2_pipeline_fetch_pcm_ticket(p, p ? p->calls : -1, dst, capacity, dst_is_device);
+}
+
+// Pinned host memory for PCM destinations: a device -> host copy into pageable memory is staged by the runtime at a fraction of the
+// PCIe rate; into these buffers it is one DMA that overlaps the other execution context's kernels.
+void* sbv2_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 64), hipHostMallocDefault) != hipSuccess) {
+        set_last_error("hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+void sbv2_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out) {

@@ -49,6 +49,21 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     cfg_.buckets = (int)json_number(js, "position_buckets");
     cfg_.max_rel = (int)json_number(js, "max_relative_positions");
     cfg_.eps = (float)json_number(js, "ln_eps");
+    // DebertaV2Encoder.conv (modeling_deberta_v2.py:449-470,592,664): present iff the checkpoint's config has conv_kernel_size > 0
+    cfg_.conv_k = json_has(js, "conv_kernel_size") ? (int)json_number(js, "conv_kernel_size") : 0;
+    if (cfg_.conv_k > 0) {
+        const std::string a = json_has(js, "conv_act") ? json_string(js, "conv_act") : "tanh";
+        if (a == "gelu") cfg_.conv_act = ACT_GELU;
+        else if (a == "tanh") cfg_.conv_act = ACT_TANH;
+        else if (a == "relu") cfg_.conv_act = ACT_RELU;
+        else throw Error("DeBERTa conv_act '" + a + "' is not supported (gelu, tanh, relu)");
+        SBV2_REQUIRE(cfg_.conv_k % 2 == 1 && cfg_.conv_k <= kMaxTaps, "DeBERTa conv_kernel_size must be odd and <= 12");
+        SBV2_REQUIRE(!json_has(js, "conv_groups") || (int)json_number(js, "conv_groups") == 1, "DeBERTa conv_groups != 1 is not supported");
+    } else {
+        // a checkpoint that carries the ConvLayer but whose config does not declare it would silently produce wrong features
+        SBV2_REQUIRE(!blob.has("deberta.encoder.conv.conv.weight"),
+                     "the container holds deberta.encoder.conv.* but its config has no conv_kernel_size: refusing to ignore the ConvLayer");
+    }
     SBV2_REQUIRE(cfg_.hidden % cfg_.heads == 0 && (cfg_.hidden / cfg_.heads) % 4 == 0, "head size must be a multiple of 4");
     // GEMM / conv arithmetic outside the decoder: exact f32 MFMA (default) | split-bf16 | plain bf16 through the k-major variant of
     // conv_cl.hip.  Measured on MI355X (round 1): the k-major variant transposes while staging (32 ds_write_b16 per thread and
@@ -62,9 +77,17 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
         else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3, bf16 or f16");
     }
     ws_.reset(new WeightStore(blob, gemm_parts));
-    emb_ = ws_->tensor("deberta.embeddings.word_embeddings.weight");
-    emb_g_ = ws_->tensor("deberta.embeddings.LayerNorm.weight");
-    emb_b_ = ws_->tensor("deberta.embeddings.LayerNorm.bias");
+    const int Hc = cfg_.hidden;
+    SBV2_REQUIRE(cfg_.vocab >= 1 && Hc >= 4 && cfg_.layers >= 1 && cfg_.inter >= 1, "bad DeBERTa config");
+    emb_ = ws_->tensor("deberta.embeddings.word_embeddings.weight", {cfg_.vocab, Hc});
+    emb_g_ = ws_->tensor("deberta.embeddings.LayerNorm.weight", {Hc});
+    emb_b_ = ws_->tensor("deberta.embeddings.LayerNorm.bias", {Hc});
+    if (cfg_.conv_k > 0) {
+        conv_ = ws_->conv("deberta.encoder.conv.conv");
+        ws_->expect(conv_, "deberta.encoder.conv.conv", Hc, Hc, cfg_.conv_k);
+        conv_g_ = ws_->tensor("deberta.encoder.conv.LayerNorm.weight", {Hc});
+        conv_b_ = ws_->tensor("deberta.encoder.conv.LayerNorm.bias", {Hc});
+    }
 
     // LayerNorm of the relative embeddings on the host (modeling_deberta_v2.py:595-599), stored as a plane [H][2*span]
     const int H = cfg_.hidden;
@@ -72,7 +95,8 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     const HostTensor& re = blob.get("deberta.encoder.rel_embeddings.weight");
     const HostTensor& rg = blob.get("deberta.encoder.LayerNorm.weight");
     const HostTensor& rb = blob.get("deberta.encoder.LayerNorm.bias");
-    SBV2_REQUIRE(re.dims[0] >= 2 * span && re.dims[1] == H, "rel_embeddings shape");
+    SBV2_REQUIRE(re.dims.size() == 2 && re.dims[0] >= 2 * span && re.dims[1] == H, "rel_embeddings shape");
+    SBV2_REQUIRE(rg.numel() == H && rb.numel() == H, "encoder.LayerNorm shape");
     Plane rel;
     rel.C = H;
     rel.L = 2 * span;
@@ -99,12 +123,18 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
         L.v = ws_->linear(p + "attention.self.value_proj");
         L.o = ws_->linear(p + "attention.output.dense");
         L.qkv = ws_->conv_cat({p + "attention.self.query_proj", p + "attention.self.key_proj", p + "attention.self.value_proj"});
-        L.ln1_g = ws_->tensor(p + "attention.output.LayerNorm.weight");
-        L.ln1_b = ws_->tensor(p + "attention.output.LayerNorm.bias");
+        L.ln1_g = ws_->tensor(p + "attention.output.LayerNorm.weight", {H});
+        L.ln1_b = ws_->tensor(p + "attention.output.LayerNorm.bias", {H});
         L.ffn1 = ws_->linear(p + "intermediate.dense");
         L.ffn2 = ws_->linear(p + "output.dense");
-        L.ln2_g = ws_->tensor(p + "output.LayerNorm.weight");
-        L.ln2_b = ws_->tensor(p + "output.LayerNorm.bias");
+        L.ln2_g = ws_->tensor(p + "output.LayerNorm.weight", {H});
+        L.ln2_b = ws_->tensor(p + "output.LayerNorm.bias", {H});
+        ws_->expect(L.q, p + "query_proj", H, H, 1);
+        ws_->expect(L.k, p + "key_proj", H, H, 1);
+        ws_->expect(L.v, p + "value_proj", H, H, 1);
+        ws_->expect(L.o, p + "attention.output.dense", H, H, 1);
+        ws_->expect(L.ffn1, p + "intermediate.dense", cfg_.inter, H, 1);
+        ws_->expect(L.ffn2, p + "output.dense", H, cfg_.inter, 1);
         // share_att_key: positions go through the layer's own key/query projections (:292-299)
         std::vector<float> zero((size_t)H * rel.ld, 0.f);
         L.pos_k = rel;
@@ -149,7 +179,8 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     std::vector<unsigned char> am((size_t)total, 1);
     if (mask)
         for (int64_t e = 0; e < total; ++e) am[e] = mask[e] != 0;
-    layout_ = make_layout(L, 0, arena_, stream_, am.data());
+    // packed utterances are separated by >= conv_k / 2 zero columns when the ConvLayer is present: the gap is its zero padding
+    layout_ = make_layout(L, cfg_.conv_k / 2, arena_, stream_, am.data());
     const SegLayout& lay = layout_;
     const int N = lay.L;
     const int maxT = lay.max_len();
@@ -207,6 +238,8 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     Plane X = arena_.plane(H, N), QKV = arena_.plane(3 * H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
     Plane Q = QKV.rows(0, H), Kp = QKV.rows(H, H), Vp = QKV.rows(2 * H, H);
     Plane F = arena_.plane(cfg_.inter, N);
+    Plane E0{};   // the embedding output is ConvLayer's input (modeling_deberta_v2.py:664: self.conv(hidden_states, output_states, input_mask))
+    if (cfg_.conv_k > 0) E0 = arena_.plane(H, N);
     std::vector<AttnGroup> ag_s, ag_l;
     std::vector<GemmGroup> g_st, g_c2p, g_p2c, g_pv;
     int64_t s_off = 0, c_off = 0, p_off = 0;
@@ -279,6 +312,8 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         std::swap(X, A);
     }
 
+    if (cfg_.conv_k > 0) HIP_CHECK(hipMemcpyAsync(E0.p, X.p, sizeof(float) * (size_t)H * X.ld, hipMemcpyDeviceToDevice, stream_));
+
     auto grouped = [&](const float* Aop, int lda, const float* Bop, int ldb, float* Cop, int ldc, const GemmGroup* grp, int maxM, int maxN,
                        float alpha, double flops) {
         ConvParams p;
@@ -321,6 +356,13 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         conv_plain(Ly.ffn1, A, F, 1, 0, nullptr, 1, stream_, ACT_GELU);
         conv_plain(Ly.ffn2, F, X, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &A);
         layernorm_ch(X, X, Ly.ln2_g, Ly.ln2_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
+        if (li == 0 && cfg_.conv_k > 0) {
+            // ConvLayer (:461-470): out = act(conv(embeddings), zeroed where attention_mask == 0); x = LayerNorm(layer0 + out) * mask.
+            // act(0) == 0 for gelu / tanh / relu, so zeroing the sum's masked columns before the LayerNorm and again after it (lay.d_mask
+            // = attention mask) gives the same zeros the reference's output * input_mask produces.
+            conv_plain(conv_, E0, A, 1, cfg_.conv_k / 2, nullptr, 1, stream_, cfg_.conv_act, 1.0f, &X);
+            layernorm_ch(A, X, conv_g_, conv_b_, cfg_.eps, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
+        }
     }
     out_ = X;
 }

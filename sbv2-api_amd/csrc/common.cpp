@@ -93,9 +93,10 @@ const HostTensor& Blob::get(const std::string& name) const {
     return it->second;
 }
 
+// Every length / offset field comes from the (possibly user-uploaded) file: bounds are checked in subtraction form (a huge value
+// cannot wrap the sum), dims must be positive and < 2^31 (later code narrows them to int) and numel is computed with overflow checks.
 Blob parse_blob(const uint8_t* b, size_t n) {
-    SBV2_REQUIRE(b && n >= 24 && std::memcmp(b, "SBV2W001", 8) == 0,
-                 "model bytes are not an SBV2W001 weight container (ONNX import is not built yet)");
+    SBV2_REQUIRE(b && n >= 24 && std::memcmp(b, "SBV2W001", 8) == 0, "model bytes are not an SBV2W001 weight container");
     Blob out;
     uint32_t nt;
     uint64_t jl;
@@ -103,32 +104,36 @@ Blob parse_blob(const uint8_t* b, size_t n) {
     std::memcpy(&nt, b + 12, 4);
     std::memcpy(&jl, b + 16, 8);
     size_t pos = 24;
-    SBV2_REQUIRE(pos + jl <= n, "truncated weight container");
+    SBV2_REQUIRE(jl <= n - pos, "truncated weight container");
     out.config_json.assign(reinterpret_cast<const char*>(b + pos), jl);
     pos += jl;
     for (uint32_t i = 0; i < nt; ++i) {
-        SBV2_REQUIRE(pos + 2 <= n, "truncated weight container");
+        SBV2_REQUIRE(n - pos >= 2, "truncated weight container");
         uint16_t nl;
         std::memcpy(&nl, b + pos, 2);
         pos += 2;
-        SBV2_REQUIRE(pos + nl + 4 <= n, "truncated weight container");
+        SBV2_REQUIRE(n - pos >= (size_t)nl + 4, "truncated weight container");
         std::string name(reinterpret_cast<const char*>(b + pos), nl);
         pos += nl;
         uint32_t nd;
         std::memcpy(&nd, b + pos, 4);
         pos += 4;
-        SBV2_REQUIRE(nd <= 8 && pos + 8 * (size_t)nd + 8 <= n, "truncated weight container");
+        SBV2_REQUIRE(nd <= 8 && n - pos >= 8 * (size_t)nd + 8, "truncated weight container");
         HostTensor t;
+        uint64_t numel = 1;
         for (uint32_t d = 0; d < nd; ++d) {
             uint64_t v;
             std::memcpy(&v, b + pos, 8);
             pos += 8;
+            SBV2_REQUIRE(v >= 1 && v < (1ull << 31), "tensor '" + name + "': dimension out of range");
+            SBV2_REQUIRE(numel <= (1ull << 40) / v, "tensor '" + name + "': too many elements");
+            numel *= v;
             t.dims.push_back((int64_t)v);
         }
         uint64_t off;
         std::memcpy(&off, b + pos, 8);
         pos += 8;
-        SBV2_REQUIRE(off % 4 == 0 && off + (uint64_t)t.numel() * 4 <= n, "tensor data out of range");
+        SBV2_REQUIRE(off % 4 == 0 && off <= n && numel <= (n - off) / 4, "tensor '" + name + "': data out of range");
         t.data = reinterpret_cast<const float*>(b + off);
         out.tensors.emplace(std::move(name), std::move(t));
     }
@@ -142,6 +147,14 @@ static size_t find_key(const std::string& js, const std::string& key) {
     p = js.find(':', p + pat.size());
     SBV2_REQUIRE(p != std::string::npos, "malformed config json");
     return p + 1;
+}
+bool json_has(const std::string& js, const std::string& key) { return js.find("\"" + key + "\"") != std::string::npos; }
+std::string json_string(const std::string& js, const std::string& key) {
+    size_t p = js.find('"', find_key(js, key));
+    SBV2_REQUIRE(p != std::string::npos, "config value of '" + key + "' is not a string");
+    const size_t e = js.find('"', p + 1);
+    SBV2_REQUIRE(e != std::string::npos, "malformed config json");
+    return js.substr(p + 1, e - p - 1);
 }
 double json_number(const std::string& js, const std::string& key) { return std::strtod(js.c_str() + find_key(js, key), nullptr); }
 std::vector<int> json_int_array(const std::string& js, const std::string& key) {

@@ -107,6 +107,8 @@ struct Blob {
 
 Blob parse_blob(const uint8_t* bytes, size_t n);
 // minimal JSON helpers for the flat config object
+bool json_has(const std::string& js, const std::string& key);
+std::string json_string(const std::string& js, const std::string& key);
 double json_number(const std::string& js, const std::string& key);
 std::vector<int> json_int_array(const std::string& js, const std::string& key);
 std::vector<std::vector<int>> json_int_array2(const std::string& js, const std::string& key);
@@ -123,7 +125,7 @@ struct GemmGroup {
     int nb;  // valid B columns for this group: B[k][j] is read as 0 unless 0 <= j < nb
 };
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3 };
 enum BiasMode { BIAS_NONE = 0, BIAS_ROW = 1, BIAS_COL = 2 };
 
 struct ConvParams {

@@ -366,6 +366,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
                     float v = acc[i][j][r] + brow[r];
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    else if (p.act == ACT_TANH) v = tanhf(v);
                     v *= p.alpha;
                     if (p.R) v += rr[r][j];
                     v *= p.beta;

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
                             if (p.bias_mode == BIAS_COL) x += p.bias[min(n + e, N - 1)];
                             if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
                             else if (p.act == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                            else if (p.act == ACT_TANH) x = tanhf(x);
                             x *= p.alpha;
                             if (Rg) x += rr[e];
                             x *= p.beta;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
                 if (p.bias_mode == BIAS_COL) v += p.bias[n];
                 if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                else if (p.act == ACT_TANH) v = tanhf(v);
                 v *= p.alpha;
                 const int ocol = n * ostride + po;
                 if (Rg) v += Rg[(int64_t)orow * p.ldr + ocol];

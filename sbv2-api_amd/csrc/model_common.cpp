@@ -24,6 +24,28 @@ float* WeightStore::tensor(const std::string& name) {
     return upload(t.data, (size_t)t.numel());
 }
 
+float* WeightStore::tensor(const std::string& name, std::initializer_list<int64_t> dims) {
+    const HostTensor& t = blob_.get(name);
+    std::vector<int64_t> a, b;
+    for (int64_t d : t.dims)
+        if (d != 1) a.push_back(d);
+    for (int64_t d : dims)
+        if (d != 1) b.push_back(d);
+    if (a != b) {
+        std::string got, want;
+        for (int64_t d : t.dims) got += (got.empty() ? "" : ",") + std::to_string(d);
+        for (int64_t d : dims) want += (want.empty() ? "" : ",") + std::to_string(d);
+        throw Error("tensor '" + name + "' has shape [" + got + "], the model config implies [" + want + "]");
+    }
+    return upload(t.data, (size_t)t.numel());
+}
+
+void WeightStore::expect(const PackedConv& c, const std::string& prefix, int cout, int cin, int k) const {
+    if (c.cout != cout || c.cin != cin || c.k != k)
+        throw Error("weights '" + prefix + "' are [" + std::to_string(c.cout) + "," + std::to_string(c.cin) + "," + std::to_string(c.k) +
+                    "], the model config implies [" + std::to_string(cout) + "," + std::to_string(cin) + "," + std::to_string(k) + "]");
+}
+
 PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
     const HostTensor& t = blob_.get(prefix + ".weight");
     SBV2_REQUIRE(t.dims.size() == 3, "conv weight must be [Cout][Cin][k]: " + prefix);
@@ -38,7 +60,7 @@ PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
         for (int ci = 0; ci < pc.cin; ++ci)
             for (int j = 0; j < pc.k; ++j) h[((size_t)j * pc.cin + ci) * pc.lda + co] = t.data[((size_t)co * pc.cin + ci) * pc.k + j];
     pc.w = upload(h.data(), h.size());
-    if (bias && blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias");
+    if (bias && blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias", {pc.cout});
     if (cl_parts_) {
         pc.cl = pack_cl(*this, t.data, pc.cout, pc.cin, pc.k, cl_parts_, nullptr);
         pc.cl.bias = pc.bias;
@@ -70,6 +92,7 @@ PackedConv WeightStore::conv_cat(const std::vector<std::string>& prefixes) {
             for (int ci = 0; ci < pc.cin; ++ci) h[(size_t)ci * pc.lda + row0 + co] = t.data[(size_t)co * pc.cin + ci];
         if (blob_.has(prefixes[n] + ".bias")) {
             const HostTensor& bt = blob_.get(prefixes[n] + ".bias");
+            SBV2_REQUIRE(bt.numel() == co_n, "bias size mismatch: " + prefixes[n]);
             for (int co = 0; co < co_n; ++co) b[row0 + co] = bt.data[co];
         }
         row0 += co_n;
@@ -91,7 +114,7 @@ PackedConv WeightStore::linear(const std::string& prefix) {
     for (int co = 0; co < pc.cout; ++co)
         for (int ci = 0; ci < pc.cin; ++ci) h[(size_t)ci * pc.lda + co] = t.data[(size_t)co * pc.cin + ci];
     pc.w = upload(h.data(), h.size());
-    if (blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias");
+    if (blob_.has(prefix + ".bias")) pc.bias = tensor(prefix + ".bias", {pc.cout});
     if (cl_parts_) {
         pc.cl = pack_cl(*this, t.data, pc.cout, pc.cin, 1, cl_parts_, nullptr);
         pc.cl.bias = pc.bias;
@@ -146,7 +169,7 @@ PackedUpsample WeightStore::upsample(const std::string& prefix, int stride, int 
         g.w = upload(h.data(), h.size());
         u.groups.push_back(g);
     }
-    u.bias = tensor(prefix + ".bias");
+    u.bias = tensor(prefix + ".bias", {u.cout});
     return u;
 }
 

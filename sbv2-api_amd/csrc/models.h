@@ -67,6 +67,10 @@ class WeightStore {
     ~WeightStore();
     float* upload(const float* host, size_t n);
     float* tensor(const std::string& name);                      // raw copy
+    // raw copy of a tensor whose shape is fixed by the config: a container whose tensor has another shape is rejected here, before
+    // any kernel indexes the weights (trailing / leading 1-dims are ignored: [C] == [C, 1] == [1, C])
+    float* tensor(const std::string& name, std::initializer_list<int64_t> dims);
+    void expect(const PackedConv& c, const std::string& prefix, int cout, int cin, int k) const;
     PackedConv conv(const std::string& prefix, bool bias = true);  // <prefix>.weight [Cout][Cin][k] (+ .bias)
     PackedConv conv_cat(const std::vector<std::string>& prefixes);  // 1x1 convs of one input stacked along Cout
     PackedConv linear(const std::string& prefix);                // <prefix>.weight [Cout][Cin] + .bias
@@ -95,6 +99,8 @@ void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_
 struct BertConfig {
     int vocab, hidden, layers, heads, inter, buckets, max_rel;
     float eps;
+    int conv_k = 0;          // DebertaV2Encoder.conv (ConvLayer after layer 0) when conv_kernel_size > 0
+    int conv_act = ACT_TANH; // ConvLayer's default activation is tanh (modeling_deberta_v2.py:453)
 };
 
 class BertModel {
@@ -124,6 +130,8 @@ class BertModel {
     BertConfig cfg_;
     std::shared_ptr<WeightStore> ws_;
     float *emb_, *emb_g_, *emb_b_;
+    PackedConv conv_;                       // encoder.conv.conv (k = conv_k)
+    float *conv_g_ = nullptr, *conv_b_ = nullptr;   // encoder.conv.LayerNorm
     std::vector<Layer> layers_;
     Arena arena_;
     hipStream_t stream_ = nullptr;

@@ -4,6 +4,7 @@ Same names, argument order and meaning as the reference; numpy arrays stand in f
 pipeline entry points are the new capabilities (the reference is strictly batch 1).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -76,10 +77,18 @@ def predict_batch(session: Session, token_ids_list, attention_masks_list=None):
     return np.split(out, np.cumsum(lens)[:-1], axis=0)
 
 
+def fresh_noise_seed() -> int:
+    """A new 64-bit seed per call: the reference's graph draws fresh RandomNormalLike noise on every run (tts.rs:313-314 passes
+    noise_scale 0.677 / noise_scale_w 0.8), so an unseeded request must not be bit-reproducible here either."""
+    return int.from_bytes(os.urandom(8), "little")
+
+
 def synthesize(session: Session, bert_ori, x_tst, spk_ids, tones, lang_ids, style_vector, sdp_ratio, length_scale, noise_scale,
-               noise_scale_w, noise_seed: int = 0) -> np.ndarray:
-    """model.rs:53-111 `synthesize(...) -> Array3<f32> [1, 1, L]` (same argument order)."""
+               noise_scale_w, noise_seed: int | None = None) -> np.ndarray:
+    """model.rs:53-111 `synthesize(...) -> Array3<f32> [1, 1, L]` (same argument order).  noise_seed None = fresh noise per call."""
     l = _lib.lib()
+    if noise_seed is None:
+        noise_seed = fresh_noise_seed()
     b, pb = _f32(bert_ori)
     x, px = _i64(x_tst)
     t, pt = _i64(tones)
@@ -129,14 +138,36 @@ def synthesize_batch(session: Session, utts, sdp_ratio=0.0, length_scale=1.0, no
     if not fetch:
         return lens
     pcm = np.empty(int(lens.sum()), np.float32)
-    check(l.sbv2_vits_fetch_pcm(session.handle, pcm.ctypes.data_as(f32p)))
+    check(l.sbv2_vits_fetch_pcm(session.handle, pcm.ctypes.data_as(f32p), pcm.size))
     return np.split(pcm, np.cumsum(lens)[:-1])
+
+
+class PinnedArray:
+    """float32 numpy view of page-locked host memory from the library (sbv2_host_alloc): the destination of overlapped D2H copies."""
+
+    def __init__(self, n: int):
+        self.ptr = _lib.lib().sbv2_host_alloc(4 * max(n, 1))
+        if not self.ptr:
+            raise Sbv2Error(_lib.lib().sbv2_last_error().decode(errors="replace"))
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, f32p), shape=(n,))
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            _lib.lib().sbv2_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def fetch_durations(session: Session, total_t: int):
     d = np.zeros(total_t, np.int64)
     lw = np.zeros(total_t, np.float32)
-    check(_lib.lib().sbv2_vits_fetch_durations(session.handle, d.ctypes.data_as(i64p), lw.ctypes.data_as(f32p)))
+    check(_lib.lib().sbv2_vits_fetch_durations(session.handle, d.ctypes.data_as(i64p), lw.ctypes.data_as(f32p), total_t))
     return d, lw
 
 
@@ -180,20 +211,20 @@ class Pipeline:
     def wait(self, ticket: int):
         check(_lib.lib().sbv2_pipeline_wait(self.h, ticket))
 
-    def fetch_ticket_to_device(self, ticket: int, device_ptr: int):
-        check(_lib.lib().sbv2_pipeline_fetch_pcm_ticket(self.h, ticket, C.c_void_p(device_ptr), 1))
+    def fetch_ticket_to_device(self, ticket: int, device_ptr: int, capacity: int):
+        check(_lib.lib().sbv2_pipeline_fetch_pcm_ticket(self.h, ticket, C.c_void_p(device_ptr), capacity, 1))
 
     def sync(self):
         check(_lib.lib().sbv2_pipeline_sync(self.h))
 
-    def fetch(self, b):
-        pcm = np.empty(int(b.lens.sum()), np.float32)
-        check(_lib.lib().sbv2_pipeline_fetch_pcm(self.h, pcm.ctypes.data_as(C.c_void_p), 0))
-        return np.split(pcm, np.cumsum(b.lens)[:-1])
-
-    def fetch_to_device(self, device_ptr: int):
-        """Concatenated PCM of the last run -> caller-owned device memory (e.g. the RCCL gather's send buffer)."""
-        check(_lib.lib().sbv2_pipeline_fetch_pcm(self.h, C.c_void_p(device_ptr), 1))
+    def fetch(self, b, out=None):
+        """PCM of the run that `b` was last submitted as (by ticket: a later run of another batch does not change what this returns;
+        once the pipeline has reused that run's context the ticket is stale and the library raises).  `out`: optional preallocated
+        float32 array (e.g. a view of pinned memory from `pinned_array`) of at least sum(b.lens) samples."""
+        n = int(b.lens.sum())
+        pcm = np.empty(n, np.float32) if out is None else out
+        check(_lib.lib().sbv2_pipeline_fetch_pcm_ticket(self.h, b.ticket, pcm.ctypes.data_as(C.c_void_p), pcm.size, 0))
+        return np.split(pcm[:n], np.cumsum(b.lens)[:-1])
 
     def close(self):
         if self.h:

@@ -71,12 +71,14 @@ def array_to_wav(audio: np.ndarray) -> bytes:
     return b"RIFF" + struct.pack("<I", len(body)) + body
 
 
-def easy_synthesize(pipe: "model.Pipeline", sentences, style_vectors, style_id=0, speaker_id=0, options=None, noise_seed=0,
+def easy_synthesize(pipe: "model.Pipeline", sentences, style_vectors, style_id=0, speaker_id=0, options=None, noise_seed=None,
                     noise_scale=NOISE_SCALE, noise_scale_w=NOISE_SCALE_W) -> bytes:
     """tts.rs:280-349 for one request whose lines are already parsed: `sentences` is the list obtained from text.split('\\n'),
     each entry a dict {input_ids, word2ph, phones, tones, langs} (parse_text's products) or None / {} for an empty line.
     With options.split_sentences False the caller passes the single parsed text as a one-element list."""
     options = options or SynthesizeOptions()
+    if noise_seed is None:      # the reference draws fresh noise per request; tests pass an explicit seed
+        noise_seed = model.fresh_noise_seed()
     style = get_style_vector(style_vectors, style_id, options.style_weight)
     live = [(i, s) for i, s in enumerate(sentences) if s]
     if not live:

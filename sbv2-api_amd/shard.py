@@ -8,8 +8,10 @@ import numpy as np
 
 
 def deal(costs, world: int):
-    """Longest-first round-robin deal: returns, per rank, the list of utterance indices it synthesises.
-    Balanced to within one utterance's cost for sorted inputs; deterministic on every rank."""
+    """Longest-processing-time-first deal (utterances by descending cost, each to the least-loaded rank): returns, per rank, the list of
+    utterance indices it synthesises.  Loads differ by at most one utterance's cost; the NUMBER of utterances per rank is not bounded
+    by ceil(n / world) (one long utterance can balance many short ones).  Deterministic on every rank.  Same rule as the library's
+    sbv2_deal (csrc/node.cpp)."""
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
     shards = [[] for _ in range(world)]
     load = [0.0] * world
@@ -27,7 +29,11 @@ def gather_pcm(local_ids, local_pcm, n_total: int, dist, device="cpu", dst: int 
     n_total numpy arrays in the original utterance order, elsewhere None."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    k = max(1, -(-n_total // world))                       # max utterances per rank
+    # rows of the (index, length) table = the LARGEST shard of any rank: deal() balances cost, not count, so a rank can hold more than
+    # ceil(n_total / world) utterances (costs [512, 32, 32, 32, 32, 40] on two ranks deal 1 + 5)
+    kk = torch.tensor([len(local_ids)], dtype=torch.int64, device=device)
+    dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+    k = max(1, int(kk.item()))
     meta = torch.full((k, 2), -1, dtype=torch.int64, device=device)
     for j, (i, p) in enumerate(zip(local_ids, local_pcm)):
         meta[j, 0], meta[j, 1] = i, len(p)

@@ -104,6 +104,9 @@ def make_deberta_weights(cfg, seed=0x5B72):
     b.w["deberta.encoder.rel_embeddings.weight"] = _tensor(seed, "deberta.encoder.rel_embeddings.weight",
                                                            (2 * span, H), 1.0)
     b.ln("deberta.encoder.LayerNorm.weight", "deberta.encoder.LayerNorm.bias", H)
+    if cfg.get("conv_kernel_size", 0) > 0:     # DebertaV2Encoder.conv (ConvLayer after layer 0)
+        b.conv("deberta.encoder.conv.conv", H, H, cfg["conv_kernel_size"])
+        b.ln("deberta.encoder.conv.LayerNorm.weight", "deberta.encoder.conv.LayerNorm.bias", H)
     for i in range(cfg["layers"]):
         p = f"deberta.encoder.layer.{i}."
         for n in ("query_proj", "key_proj", "value_proj"):

@@ -30,7 +30,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 
 
-def deberta_case(name, cfg, S, seed, extra_layers=2):
+def deberta_case(name, cfg, S, seed, extra_layers=2, mask_tail=0):
     """hidden_states[-3][0] of a model with cfg['layers'] + 2 layers == state after layer cfg['layers']
     (convert_deberta.py:33-34)."""
     W = synth.make_deberta_weights(cfg, seed)
@@ -41,6 +41,7 @@ def deberta_case(name, cfg, S, seed, extra_layers=2):
         type_vocab_size=0, layer_norm_eps=cfg["ln_eps"], relative_attention=True, max_relative_positions=-1,
         position_buckets=cfg["position_buckets"], norm_rel_ebd="layer_norm", share_att_key=True,
         pos_att_type=["p2c", "c2p"], position_biased_input=False, pad_token_id=0,
+        **(dict(conv_kernel_size=cfg["conv_kernel_size"], conv_act=cfg.get("conv_act", "tanh")) if cfg.get("conv_kernel_size", 0) > 0 else {}),
     )
     m = DebertaV2Model(hc).eval()
     sd = m.state_dict()
@@ -51,12 +52,16 @@ def deberta_case(name, cfg, S, seed, extra_layers=2):
             sd[k].copy_(T(W[kk]))
             loaded += 1
     assert loaded == len(W), (loaded, len(W))
+    assert (m.encoder.conv is not None) == (cfg.get("conv_kernel_size", 0) > 0)
     u = synth.make_utterance(8, cfg, O.VITS_TINY, seed=seed, chars=S - 2)
     ids = u["input_ids"]
+    am = torch.ones(1, S, dtype=torch.long)
+    if mask_tail:
+        am[0, S - mask_tail:] = 0
     with torch.no_grad():
-        out = m(input_ids=T(ids)[None], attention_mask=torch.ones(1, S, dtype=torch.long), output_hidden_states=True)
+        out = m(input_ids=T(ids)[None], attention_mask=am, output_hidden_states=True)
     hs = out.hidden_states[-3][0].numpy()
-    np.savez_compressed(os.path.join(OUT, name), input_ids=ids, output=hs, seed=seed,
+    np.savez_compressed(os.path.join(OUT, name), input_ids=ids, attention_mask=am[0].numpy(), output=hs, seed=seed,
                         cfg=np.array(repr(cfg)))
     print(name, hs.shape, float(np.abs(hs).max()))
 
@@ -186,6 +191,179 @@ def vits_cases(name, cfg, seed, T_text, T_frames):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def path_case(name, cfg, seed, T_text):
+    """The duration -> ceil -> clamp_min -> monotonic path -> prior expansion block, executed by transformers' own
+    `VitsModel.forward` (modeling_vits.py:1349-1376; what commons.generate_path + the two matmuls do upstream).  The block is inline
+    in forward(), so a whole (tiny, randomly initialised) VitsModel is run and its in/outputs are captured with hooks: log-durations
+    (duration predictor output), prior means / log-variances (text encoder output) -> the flow's input.  `torch.randn_like` is patched
+    to ones with noise_scale 1, so the flow input is `m_f + exp(logs_f)` and both expansions are pinned."""
+    W = synth.make_vits_weights(cfg, seed)
+    hc = vits_cfg_hf(cfg)
+    hc.use_stochastic_duration_prediction = False
+    hc.num_hidden_layers = 1
+    torch.manual_seed(seed)
+    m = MV.VitsModel(hc).eval()
+    mp = {}
+    for c in ("conv_1", "conv_2", "proj", "cond"):
+        mp[f"{c}.weight"], mp[f"{c}.bias"] = f"dp.{c}.weight", f"dp.{c}.bias"
+    for n in ("norm_1", "norm_2"):
+        mp[f"{n}.weight"], mp[f"{n}.bias"] = f"dp.{n}.gamma", f"dp.{n}.beta"
+    assert not load(m.duration_predictor, mp, W)
+    # text-encoder output scaled so that log-durations / prior stats are O(1) whatever the random init gives
+    cap = {}
+    m.duration_predictor.register_forward_hook(lambda mod, a, o: cap.__setitem__("logw", o.detach().clone()))
+    m.text_encoder.register_forward_hook(lambda mod, a, o: cap.__setitem__("te", (o.prior_means.detach().clone(), o.prior_log_variances.detach().clone())))
+    m.flow.register_forward_pre_hook(lambda mod, a: cap.__setitem__("flow_in", a[0].detach().clone()))
+    ids = T(np.arange(T_text, dtype=np.int64) % cfg["n_vocab"])[None]
+    out = {}
+    real = torch.randn_like
+    try:
+        torch.randn_like = lambda t, **k: torch.ones_like(t)
+        m.noise_scale = 1.0
+        for i, rate in enumerate((1.0, 0.77, 1.9)):
+            with torch.no_grad():
+                r = m(input_ids=ids, speaker_id=1, speaking_rate=rate)
+            out[f"logw{i}"] = cap["logw"][0, 0].numpy()
+            out[f"m_p{i}"] = cap["te"][0][0].numpy().T.copy()        # [C, T]
+            out[f"logs_p{i}"] = cap["te"][1][0].numpy().T.copy()
+            out[f"length_scale{i}"] = np.float32(1.0 / rate)
+            out[f"flow_in{i}"] = cap["flow_in"][0].numpy()           # [C, T_frames] = m_f + exp(logs_f)
+            out[f"samples{i}"] = np.int64(r.sequence_lengths[0].item())
+    finally:
+        torch.randn_like = real
+    np.savez_compressed(os.path.join(OUT, name), seed=seed, cfg=np.array(repr(cfg)), **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def _hf_layers(cfg, W, prefix, n_layers, kernel):
+    hc = vits_cfg_hf(cfg)
+    hc.ffn_kernel_size = kernel
+    layers = []
+    for i in range(n_layers):
+        lay = MV.VitsEncoderLayer(hc).eval()
+        mp = {}
+        for hf, ours in (("q_proj", "conv_q"), ("k_proj", "conv_k"), ("v_proj", "conv_v"), ("out_proj", "conv_o")):
+            mp[f"attention.{hf}.weight"] = f"{prefix}attn_layers.{i}.{ours}.weight"
+            mp[f"attention.{hf}.bias"] = f"{prefix}attn_layers.{i}.{ours}.bias"
+        mp["attention.emb_rel_k"] = f"{prefix}attn_layers.{i}.emb_rel_k"
+        mp["attention.emb_rel_v"] = f"{prefix}attn_layers.{i}.emb_rel_v"
+        mp["layer_norm.weight"], mp["layer_norm.bias"] = f"{prefix}norm_layers_1.{i}.gamma", f"{prefix}norm_layers_1.{i}.beta"
+        mp["final_layer_norm.weight"], mp["final_layer_norm.bias"] = f"{prefix}norm_layers_2.{i}.gamma", f"{prefix}norm_layers_2.{i}.beta"
+        for c in ("conv_1", "conv_2"):
+            mp[f"feed_forward.{c}.weight"] = f"{prefix}ffn_layers.{i}.{c}.weight"
+            mp[f"feed_forward.{c}.bias"] = f"{prefix}ffn_layers.{i}.{c}.bias"
+        assert not load(lay, mp, W)
+        layers.append(lay)
+    return layers
+
+
+def _hf_encoder(cfg, W, prefix, n_layers, kernel, x, g):
+    """attentions.Encoder of style-bert-vits2 composed from transformers' VitsEncoderLayer modules (pinned blocks) in torch:
+    x [1, T, H]; the speaker vector spk_emb_linear(g) is added before layer cond_layer_idx (JP-Extra glue, restated)."""
+    import torch.nn.functional as F
+    ones = torch.ones(1, x.shape[1], 1)
+    for i, lay in enumerate(_hf_layers(cfg, W, prefix, n_layers, kernel)):
+        if i == cfg["cond_layer_idx"] and g is not None:
+            x = x + F.linear(g, T(W[prefix + "spk_emb_linear.weight"]), T(W[prefix + "spk_emb_linear.bias"]))[None, None, :]
+        x = lay(x, ones)[0]
+    return x
+
+
+def e2e_case(name, cfg, seed, n_phones, with_sdp_noise=False):
+    """One utterance through `SynthesizerTrn.infer` (convert_model.py:97-110) COMPOSED IN TORCH from transformers' modules:
+    VitsEncoderLayer stacks (text encoder, 4 coupling layers), VitsDurationPredictor, VitsStochasticDurationPredictor (reverse),
+    VitsHifiGan; the JP-Extra glue between them (embedding sum, speaker vector at layer 2, sdp/dp blend, ceil, repeat_interleave
+    expansion, flip + mean-only coupling) is written here with torch ops, independently of the numpy oracle and of the HIP code.
+    noise_scale = 0 (deterministic); sdp_ratio 0.0 and 0.25 (the second with injected duration noise)."""
+    import torch.nn.functional as F
+    W = synth.make_vits_weights(cfg, seed)
+    hc = vits_cfg_hf(cfg)
+    u = synth.make_utterance(n_phones, O.DEBERTA_TINY, cfg, seed=seed + 1)
+    Tt = u["T_text"]
+    bert = synth.hash_normal(seed + 2, cfg["bert_dim"] * Tt).reshape(cfg["bert_dim"], Tt)
+    H, I = cfg["hidden"], cfg["inter"]
+    sid = cfg["n_speakers"] - 1
+    with torch.no_grad():
+        g = T(W["emb_g.weight"])[sid]
+        x = F.embedding(T(u["phones"]), T(W["enc_p.emb.weight"])) + F.embedding(T(u["tones"]), T(W["enc_p.tone_emb.weight"])) \
+            + F.embedding(T(u["langs"]), T(W["enc_p.language_emb.weight"]))
+        x = x + F.conv1d(T(bert)[None], T(W["enc_p.bert_proj.weight"]), T(W["enc_p.bert_proj.bias"]))[0].T
+        x = x + F.linear(T(u["style"]), T(W["enc_p.style_proj.weight"]), T(W["enc_p.style_proj.bias"]))[None, :]
+        x = (x * float(np.float32(np.sqrt(np.float32(H)))))[None]
+        x = _hf_encoder(cfg, W, "enc_p.encoder.", cfg["enc_layers"], cfg["enc_kernel"], x, g)       # [1, T, H]
+        xc = x.transpose(1, 2)                                                                       # [1, H, T]
+        stats = F.conv1d(xc, T(W["enc_p.proj.weight"]), T(W["enc_p.proj.bias"]))[0]
+        m_p, logs_p = stats[:I], stats[I:]
+        ones = torch.ones(1, 1, Tt)
+        dp = MV.VitsDurationPredictor(hc).eval()
+        mp = {}
+        for c in ("conv_1", "conv_2", "proj", "cond"):
+            mp[f"{c}.weight"], mp[f"{c}.bias"] = f"dp.{c}.weight", f"dp.{c}.bias"
+        for n in ("norm_1", "norm_2"):
+            mp[f"{n}.weight"], mp[f"{n}.bias"] = f"dp.{n}.gamma", f"dp.{n}.beta"
+        assert not load(dp, mp, W)
+        logw_dp = dp(xc, ones, g[None, :, None])[0, 0]
+        sdp = MV.VitsStochasticDurationPredictor(hc).eval()
+        mp = {"conv_pre.weight": "sdp.pre.weight", "conv_pre.bias": "sdp.pre.bias", "conv_proj.weight": "sdp.proj.weight",
+              "conv_proj.bias": "sdp.proj.bias", "cond.weight": "sdp.cond.weight", "cond.bias": "sdp.cond.bias",
+              "flows.0.translate": "sdp.flows.0.m", "flows.0.log_scale": "sdp.flows.0.logs"}
+        mp.update(dds_map("conv_dds.", "sdp.convs.", cfg["sdp_dds_layers"]))
+        for i in range(2, cfg["sdp_flows"] + 1):
+            o = f"sdp.flows.{2 * i - 1}."
+            mp[f"flows.{i}.conv_pre.weight"], mp[f"flows.{i}.conv_pre.bias"] = o + "pre.weight", o + "pre.bias"
+            mp[f"flows.{i}.conv_proj.weight"], mp[f"flows.{i}.conv_proj.bias"] = o + "proj.weight", o + "proj.bias"
+            mp.update(dds_map(f"flows.{i}.conv_dds.", o + "convs.", cfg["sdp_dds_layers"]))
+        load(sdp, mp, W)
+        real_randn = torch.randn
+        out = {}
+        dec = MV.VitsHifiGan(hc).eval()
+        mp = {"conv_pre.weight": "dec.conv_pre.weight", "conv_pre.bias": "dec.conv_pre.bias",
+              "conv_post.weight": "dec.conv_post.weight", "cond.weight": "dec.cond.weight", "cond.bias": "dec.cond.bias"}
+        for i in range(len(cfg["up_rates"])):
+            mp[f"upsampler.{i}.weight"], mp[f"upsampler.{i}.bias"] = f"dec.ups.{i}.weight", f"dec.ups.{i}.bias"
+        for k in dec.state_dict():
+            if k.startswith("resblocks."):
+                mp[k] = "dec." + k
+        assert not load(dec, mp, W)
+        for tag, sdp_ratio, nscale, ls in (("a", 0.0, 0.0, 1.0), ("b", 0.25, 0.3, 1.25)):
+            for attempt in range(64):   # deterministic search for injected noise whose durations keep clear of the ceil() edge
+                nw = synth.hash_normal(seed + 3 + 1000 * attempt, 2 * Tt).reshape(2, Tt) * np.float32(nscale)
+                try:
+                    torch.randn = lambda *a, **k: T(nw)[None]
+                    logw_sdp = sdp(xc, ones, g[None, :, None], reverse=True, noise_scale=1.0)[0, 0]
+                finally:
+                    torch.randn = real_randn
+                logw = logw_sdp * np.float32(sdp_ratio) + logw_dp * np.float32(1.0 - sdp_ratio)
+                w = torch.exp(logw) * np.float32(ls)
+                if float(((w - torch.round(w)).abs() / torch.clamp_min(w, 1.0)).min()) > 3e-3:
+                    break
+            else:
+                raise SystemExit("no noise draw keeps the durations off the ceil edge")
+            dur = torch.ceil(w).long()
+            m_f = torch.repeat_interleave(m_p, dur, dim=1)
+            z = m_f.clone()                                              # noise_scale 0: z_p = m_p expanded
+            half = I // 2
+            Tf = z.shape[1]
+            for i in range(cfg["flow_n"] - 1, -1, -1):
+                z = torch.flip(z, [0])
+                p = f"flow.flows.{2 * i}."
+                x0, x1 = z[:half], z[half:]
+                h = F.conv1d(x0[None], T(W[p + "pre.weight"]), T(W[p + "pre.bias"]))
+                h = _hf_encoder(cfg, W, p + "enc.", cfg["flow_layers"], cfg["flow_kernel"], h.transpose(1, 2), g).transpose(1, 2)
+                mm = F.conv1d(h, T(W[p + "post.weight"]), T(W[p + "post.bias"]))[0]
+                z = torch.cat([x0, x1 - mm], 0)
+            pcm = dec(z[None], g[None, :, None])[0, 0]
+            out.update({f"sdp_ratio_{tag}": np.float32(sdp_ratio), f"length_scale_{tag}": np.float32(ls), f"noise_w_{tag}": nw,
+                        f"noise_key_{tag}": np.int64(seed + 3 + 1000 * attempt), f"noise_scale_w_{tag}": np.float32(nscale),
+                        f"logw_{tag}": logw.numpy(), f"w_{tag}": w.numpy(), f"dur_{tag}": dur.numpy(), f"z_p_{tag}": m_f.numpy(),
+                        f"z_{tag}": z.numpy(), f"pcm_{tag}": pcm.numpy()})
+        out.update(x=xc[0].numpy(), stats=stats.numpy(), logw_dp=logw_dp.numpy())
+    np.savez_compressed(os.path.join(OUT, name), seed=seed, cfg=np.array(repr(cfg)), sid=sid, bert=bert, style=u["style"],
+                        phones=u["phones"], tones=u["tones"], langs=u["langs"], **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+
 def spline_case():
     """Direct known-answer vectors for the rational-quadratic spline inverse incl. tails and edge bins
     (transformers modeling_vits.py:93-303, reverse=True)."""
@@ -220,8 +398,16 @@ if __name__ == "__main__":
     spline_case()
     deberta_case("deberta_tiny_S24.npz", O.DEBERTA_TINY, 24, seed=3)
     deberta_case("deberta_tiny_S5.npz", O.DEBERTA_TINY, 5, seed=4)
+    # DebertaV2Encoder.conv (ConvLayer after layer 0): gelu k = 3 (the recalled ku-nlp setting), tanh k = 5 (the class default
+    # activation), and a case with two masked tail tokens (ConvLayer zeroes masked positions and multiplies its output by the mask)
+    deberta_case("deberta_tiny_conv_S24.npz", O.DEBERTA_TINY_CONV, 24, seed=3)
+    deberta_case("deberta_tiny_conv_tanh_S9.npz", dict(O.DEBERTA_TINY, conv_kernel_size=5, conv_act="tanh"), 9, seed=6)
+    deberta_case("deberta_tiny_conv_masked_S12.npz", O.DEBERTA_TINY_CONV, 12, seed=7, mask_tail=2)
     vits_cases("vits_tiny_blocks.npz", O.VITS_TINY, seed=5, T_text=37, T_frames=23)
+    path_case("vits_tiny_path.npz", O.VITS_TINY, seed=8, T_text=29)
+    e2e_case("vits_tiny_e2e.npz", O.VITS_TINY, seed=9, n_phones=9)
     if "--full" in sys.argv or not os.path.exists(os.path.join(OUT, "deberta_full_S64.npz")):
+        e2e_case("vits_full_e2e.npz", O.VITS_FULL, seed=0x5B72, n_phones=7)
         deberta_case("deberta_full_S64.npz", O.DEBERTA_FULL, 64, seed=0x5B72)
         # full-shape VITS blocks on short sequences (weights reproducible from the seed; outputs are small)
         vits_cases("vits_full_blocks.npz", O.VITS_FULL, seed=0x5B72, T_text=41, T_frames=12)

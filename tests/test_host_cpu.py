@@ -61,11 +61,14 @@ def test_deal_is_balanced_and_complete():
         assert max(loads) - min(loads) <= max(costs)
 
 
-def _worker(rank, world, port, q):
+_SKEWED = [512, 32, 32, 32, 32, 40]     # deals 1 + 5 utterances on two ranks: more than ceil(6 / 2) on one of them
+
+
+def _worker(rank, world, port, q, lens=(5, 17, 1, 9, 12)):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lens = [5, 17, 1, 9, 12]
+    lens = list(lens)
     ids = shard.deal(lens, world)[rank]
     pcm = [np.arange(lens[i], dtype=np.float32) + 100 * i for i in ids]
     out = shard.gather_pcm(ids, pcm, len(lens), dist)
@@ -88,10 +91,25 @@ def test_gather_pcm_world2_gloo():
         assert got[i] == (np.arange(n, dtype=np.float32) + 100 * i).tolist()
 
 
+def test_gather_pcm_world2_gloo_skewed_costs():
+    """A deal whose largest shard exceeds ceil(n / world) utterances (the mixed 32..512 case of BASELINE configs[3])."""
+    import torch.multiprocessing as mp
+    assert sorted(len(s) for s in shard.deal(_SKEWED, 2)) == [1, 5]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, tuple(_SKEWED))) for r in range(2)]
+    [p.start() for p in ps]
+    got = q.get(timeout=120)
+    [p.join(60) for p in ps]
+    for i, n in enumerate(_SKEWED):
+        assert got[i] == (np.arange(n, dtype=np.float32) + 100 * i).tolist()
+
+
 def test_package_configs_match_oracle():
     import sbv2_oracle as O
     from sbv2_api_amd import configs
-    for name in ("DEBERTA_FULL", "DEBERTA_TINY", "VITS_FULL", "VITS_TINY", "SAMPLE_RATE"):
+    for name in ("DEBERTA_FULL", "DEBERTA_TINY", "DEBERTA_TINY_CONV", "VITS_FULL", "VITS_TINY", "SAMPLE_RATE"):
         assert getattr(configs, name) == getattr(O, name), name
 
 
