@@ -124,6 +124,40 @@ int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int64_t capacity, int 
 void* sbv2_host_alloc(size_t bytes);
 void sbv2_host_free(void* p);
 
+/* ---- new: multi-GPU.  The reference is one process, one device, batch 1; a batch of independent utterances is
+ * sharded over the GPUs of a node (sorted by cost, longest-processing-time-first deal, a full weight replica per GPU, no data-path
+ * collective) and the PCM is gathered to rank 0 over RCCL / xGMI (one all-gather of the sample counts + grouped send / recv).
+ * RCCL is dlopen'ed on first use: single-GPU callers never load it. ------------------------------------------------------------------ */
+/* rank_of[i] = rank that synthesises utterance i (host only, deterministic on every rank). */
+int sbv2_deal(int64_t n, const int64_t* costs, int world, int32_t* rank_of);
+
+/* (a) one process per GPU: rank 0 obtains a 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any side channel. */
+typedef struct sbv2_comm sbv2_comm;
+int sbv2_comm_unique_id(uint8_t* id128);
+int sbv2_comm_create(const uint8_t* id128, int rank, int world, int device, sbv2_comm** out);
+void sbv2_comm_destroy(sbv2_comm* c);
+int sbv2_comm_rank(const sbv2_comm* c);
+int sbv2_comm_world(const sbv2_comm* c);
+int sbv2_comm_barrier(sbv2_comm* c);
+int sbv2_comm_max_f64(sbv2_comm* c, double* v);   /* in place: max over ranks (also a barrier) */
+/* PCM of the run `ticket` of this rank's pipeline -> root: counts[world] = samples per rank (filled on every rank); on the root
+ * dst_host (capacity samples; may be sbv2_host_alloc memory) receives the ranks' PCM concatenated in rank order. */
+int sbv2_comm_gather_pcm(sbv2_comm* c, sbv2_pipeline* p, int64_t ticket, int root, float* dst_host, int64_t capacity, int64_t* counts);
+
+/* (b) one process, N devices: the batched multi-GPU entry SURVEY.md §8b calls `sbv2_synthesize_batch`.  devices[ndev] are HIP ordinals (the model bytes are
+ * the ones sbv2_bert_create / sbv2_vits_create take); one host thread + stream set per device, ncclCommInitAll when ndev > 1. */
+typedef struct sbv2_node sbv2_node;
+int sbv2_node_create(const uint8_t* bert_model, size_t bert_len, const uint8_t* vits_model, size_t vits_len, const int* devices, int ndev,
+                     sbv2_node** out);
+void sbv2_node_destroy(sbv2_node* nd);
+int sbv2_node_devices(const sbv2_node* nd);
+int sbv2_node_uses_rccl(const sbv2_node* nd);
+/* Same inputs as sbv2_pipeline_run.  Outputs: pcm_lens[n]; pcm_host = the batch's PCM concatenated in the CALLER's utterance order
+ * (capacity samples).  Utterance i's samples equal what a one-GPU call of the whole batch returns for it, bit for bit. */
+int sbv2_node_synthesize(sbv2_node* nd, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens, const int64_t* word2ph,
+                         int64_t* pcm_lens, float* pcm_host, int64_t capacity);
+int sbv2_node_last_deal(const sbv2_node* nd, int32_t* rank_of, int64_t n);   /* which device ran which utterance in the last call */
+
 /* ---- test hooks (no reference counterpart) ------------------------------------------------------------------------ */
 /* bucket(rel) for rel in [-(max_s-1), max_s-1] (transformers modeling_deberta_v2.py:57-69); host only, no GPU needed. */
 int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out);

@@ -58,6 +58,21 @@ SYMBOLS = {
     "sbv2_pipeline_wait": (C.c_int, [C.c_void_p, C.c_int64]),
     "sbv2_host_alloc": (C.c_void_p, [C.c_size_t]),
     "sbv2_host_free": (None, [C.c_void_p]),
+    "sbv2_deal": (C.c_int, [C.c_int64, i64p, C.c_int, C.POINTER(C.c_int32)]),
+    "sbv2_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "sbv2_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sbv2_comm_destroy": (None, [C.c_void_p]),
+    "sbv2_comm_rank": (C.c_int, [C.c_void_p]),
+    "sbv2_comm_world": (C.c_int, [C.c_void_p]),
+    "sbv2_comm_barrier": (C.c_int, [C.c_void_p]),
+    "sbv2_comm_max_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "sbv2_comm_gather_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, i64p]),
+    "sbv2_node_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "sbv2_node_destroy": (None, [C.c_void_p]),
+    "sbv2_node_devices": (C.c_int, [C.c_void_p]),
+    "sbv2_node_uses_rccl": (C.c_int, [C.c_void_p]),
+    "sbv2_node_synthesize": (C.c_int, [C.c_void_p, C.POINTER(Sbv2Batch), i64p, i64p, i64p, i64p, C.c_void_p, C.c_int64]),
+    "sbv2_node_last_deal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]),
     "sbv2_debug_bucket_table": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "sbv2_debug_conv1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
     "sbv2_debug_conv_transpose1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

@@ -3,52 +3,10 @@
 #include <cstring>
 #include <new>
 
-#include "../../include/sbv2_hip.h"
-#include "models.h"
 
-namespace sbv2 {
-const char* last_error_cstr();
-}
-using namespace sbv2;
+#include "api_internal.h"
 
-struct sbv2_bert {
-    std::unique_ptr<BertModel> m;
-};
-struct sbv2_vits {
-    std::unique_ptr<VitsModel> m;
-};
-struct sbv2_pipeline {
-    sbv2_bert* bert;
-    sbv2_vits* vits;
-    // execution contexts: context 0 is the caller's pair of handles, the others are clones (shared weights, own stream + arena)
-    std::vector<std::unique_ptr<BertModel>> bclones;
-    std::vector<std::unique_ptr<VitsModel>> vclones;
-    int64_t calls = 0;   // tickets are call numbers 1, 2, ...: ticket t ran on context (t - 1) % depth and is valid until that context is reused
-    BertModel& bm(int i) { return i == 0 ? *bert->m : *bclones[i - 1]; }
-    VitsModel& vm(int i) { return i == 0 ? *vits->m : *vclones[i - 1]; }
-    int contexts() const { return 1 + (int)vclones.size(); }
-    // context of a ticket; throws for tickets never issued or already overwritten by a later run on the same context
-    int ctx_of(int64_t ticket) const {
-        SBV2_REQUIRE(ticket >= 1 && ticket <= calls, "unknown pipeline ticket");
-        SBV2_REQUIRE(ticket > calls - contexts(), "stale pipeline ticket: its execution context has been reused by a later run");
-        return (int)((ticket - 1) % contexts());
-    }
-};
-
-#define API_BEGIN try {
-#define API_END                                   \
-    return 0;                                     \
-    }                                             \
-    catch (const std::exception& e) {             \
-        set_last_error(e.what());                 \
-        return 1;                                 \
-    }                                             \
-    catch (...) {                                 \
-        set_last_error("unknown error");          \
-        return 1;                                 \
-    }
-
-static VitsBatch to_batch(const sbv2_batch* b) {
+VitsBatch to_batch(const sbv2_batch* b) {
     SBV2_REQUIRE(b && b->n >= 1 && b->t_lens && b->x_tst && b->tones && b->lang_ids && b->sids && b->style_vectors,
                  "sbv2_batch has null fields");
     VitsBatch v;
@@ -281,9 +239,11 @@ int sbv2_pipeline_create(sbv2_bert* bert, sbv2_vits* vits, sbv2_pipeline** out) 
 }
 void sbv2_pipeline_destroy(sbv2_pipeline* p) { delete p; }
 
+}  // extern "C"
+
 // One micro-batch on one context: bert::predict -> word2ph repeat (tts_util.rs:129-154) -> model::synthesize
-static void pipeline_run_one(BertModel& bm, VitsModel& vm, VitsBatch v, const int64_t* token_ids, const int64_t* s_lens,
-                             const int64_t* word2ph) {
+void pipeline_run_one(BertModel& bm, VitsModel& vm, VitsBatch v, const int64_t* token_ids, const int64_t* s_lens,
+                      const int64_t* word2ph) {
     HIP_CHECK(hipStreamSynchronize(vm.stream()));  // this context's previous batch may still be reading the DeBERTa output plane
     bm.forward(v.n, token_ids, nullptr, s_lens);
     const SegLayout& bl = bm.layout();
@@ -306,6 +266,8 @@ static void pipeline_run_one(BertModel& bm, VitsModel& vm, VitsBatch v, const in
     v.after_stream = bm.stream();
     vm.forward(v);
 }
+
+extern "C" {
 
 // Batches are PIPELINED ACROSS CALLS: call n runs on execution context n % depth (own HIP stream + workspace, shared weights), so the
 // latency-bound part of batch n+1 (DeBERTa, text encoder, duration predictors, flow: ~1300 small launches, ~55 ms whatever the

@@ -168,7 +168,8 @@ struct VitsBatch {
     float sdp_ratio = 0.f, length_scale = 1.f, noise_scale = 0.f, noise_scale_w = 0.f;
     uint64_t seed = 0;
     const int64_t* forced_durations = nullptr;  // concatenated, optional
-    int utt0 = 0;                               // index of the first utterance in the caller's batch (noise stream keys)
+    int utt0 = 0;                               // index of the first utterance in the caller's batch (noise stream keys) ...
+    const int64_t* utt_ids = nullptr;           // ... or, for an arbitrary subset (a shard dealt to this GPU), every utterance's index
     hipStream_t after_stream = nullptr;         // when set, the forward's kernels wait for the work queued on this stream
 };
 

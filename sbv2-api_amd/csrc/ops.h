@@ -59,11 +59,12 @@ void affine_reverse(float* z0, float* z1, const float* m, const float* logs, con
                     hipStream_t s);
 void durations(const float* sdp, const float* dp, float ratio, float length_scale, const unsigned char* mask, int L,
                float* logw, int* dur, hipStream_t s);
-void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, int L,
+void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, const int* seg_utt, int L,
                 uint64_t seed, int stream_id, float scale, hipStream_t s);
 void expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame, const int* seg_of, const int* seg_start,
-                   const int* seg_len, uint64_t seed, float noise_scale, const float* noise_inj, int ld_inj, Plane out,
-                   hipStream_t s);
+                   const int* seg_len, const int* seg_utt, uint64_t seed, float noise_scale, Plane out, hipStream_t s);
+// dst[tab[3i + 1] + e] = src[tab[3i] + e] for e < tab[3i + 2], i < n (device table)
+void copy_segments(const float* src, float* dst, const int64_t* d_table, int n, hipStream_t s);
 void conv_post_tanh(Plane x, const float* w, int k, float slope, const int* seg_start, const int* seg_len,
                     const int64_t* pcm_off, int nseg, int up, int64_t max_samples, float* pcm, hipStream_t s);
 void transpose_out(Plane in, int col0, int T, float* out, hipStream_t s);  // out[t][c] = in[c][col0+t]

@@ -631,7 +631,9 @@ __device__ __forceinline__ uint64_t noise_key(uint64_t seed, int utt, int stream
     return seed + (uint64_t)(2 * utt + stream) * 0x9E3779B97F4A7C15ull;
 }
 
-__global__ void k_noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, int L,
+// seg_utt[sg] = index of segment sg's utterance in the CALLER's batch (the noise streams are keyed by it, so a shard of a batch that was
+// dealt to another GPU draws exactly the noise the whole batch would have drawn on one GPU)
+__global__ void k_noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, const int* seg_utt, int L,
                              uint64_t seed, int stream_id, float scale) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;
@@ -640,19 +642,19 @@ __global__ void k_noise_fill(float* out, int ld, int rows, const int* seg_of, co
     float v = 0.f;
     if (sg >= 0 && scale != 0.f) {
         const uint64_t e = (uint64_t)r * seg_len[sg] + (n - seg_start[sg]);
-        v = hash_normal(noise_key(seed, sg, stream_id), e) * scale;
+        v = hash_normal(noise_key(seed, seg_utt[sg], stream_id), e) * scale;
     }
     out[(size_t)r * ld + n] = v;
 }
-void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, int L, uint64_t seed,
-                int stream_id, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(k_noise_fill, dim3((L + 255) / 256, rows), dim3(256), 0, s, out, ld, rows, seg_of, seg_start, seg_len, L, seed,
+void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, const int* seg_utt, int L,
+                uint64_t seed, int stream_id, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_noise_fill, dim3((L + 255) / 256, rows), dim3(256), 0, s, out, ld, rows, seg_of, seg_start, seg_len, seg_utt, L, seed,
                        stream_id, scale);
 }
 
 // generate_path + the two matmuls + prior sampling: z_p[c][y] = m_p[c][tok(y)] + randn * exp(logs_p[c][tok(y)]) * noise_scale
 __global__ void k_expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame, const int* seg_of, const int* seg_start,
-                                const int* seg_len, uint64_t seed, float noise_scale, Plane out) {
+                                const int* seg_len, const int* seg_utt, uint64_t seed, float noise_scale, Plane out) {
     const int y = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
     if (y >= out.L) return;
@@ -663,15 +665,15 @@ __global__ void k_expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame
         if (noise_scale != 0.f) {
             const int sg = seg_of[y];
             const uint64_t e = (uint64_t)c * seg_len[sg] + (y - seg_start[sg]);
-            v += hash_normal(noise_key(seed, sg, 1), e) * noise_scale * expf(logs_p.p[(size_t)c * logs_p.ld + tok]);
+            v += hash_normal(noise_key(seed, seg_utt[sg], 1), e) * noise_scale * expf(logs_p.p[(size_t)c * logs_p.ld + tok]);
         }
     }
     out.p[(size_t)c * out.ld + y] = v;
 }
 void expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame, const int* seg_of, const int* seg_start, const int* seg_len,
-                   uint64_t seed, float noise_scale, const float* /*noise_inj*/, int /*ld_inj*/, Plane out, hipStream_t s) {
+                   const int* seg_utt, uint64_t seed, float noise_scale, Plane out, hipStream_t s) {
     hipLaunchKernelGGL(k_expand_frames, dim3((out.L + 255) / 256, out.C), dim3(256), 0, s, m_p, logs_p, tok_of_frame, seg_of,
-                       seg_start, seg_len, seed, noise_scale, out);
+                       seg_start, seg_len, seg_utt, seed, noise_scale, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -807,5 +809,23 @@ void conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, 
 }
 
 void fill_zero(void* p, size_t bytes, hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
+
+// ------------------------------------------------------------------------------------------------
+// Segment permutation: dst[tab[i].dst + e] = src[tab[i].src + e], e < tab[i].len  (PCM blocks received per device -> utterance order)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy_segments(const float* src, float* dst, const int64_t* tab) {
+    const int64_t so = tab[3 * blockIdx.y], dof = tab[3 * blockIdx.y + 1], len = tab[3 * blockIdx.y + 2];
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < len; e += (int64_t)gridDim.x * 1024) {
+        if (e + 4 <= len && ((so + e) & 3) == 0 && ((dof + e) & 3) == 0) {
+            *reinterpret_cast<float4*>(dst + dof + e) = *reinterpret_cast<const float4*>(src + so + e);
+        } else {
+            for (int64_t q = e; q < min(e + 4, len); ++q) dst[dof + q] = src[so + q];
+        }
+    }
+}
+void copy_segments(const float* src, float* dst, const int64_t* d_table, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_copy_segments, dim3(64, n), dim3(256), 0, s, src, dst, d_table);
+}
 
 }  // namespace sbv2

@@ -465,7 +465,7 @@ void VitsModel::forward(const VitsBatch& b) {
     }
     Arena& ar = arena_;
     const int n = b.n, H = cfg_.hidden, I = cfg_.inter;
-    const uint64_t seed = b.seed + (uint64_t)(2 * b.utt0) * 0x9E3779B97F4A7C15ull;   // noise_key(seed, utt0 + u, stream)
+    const uint64_t seed = b.seed;   // noise streams: noise_key(seed, index of the utterance in the caller's batch, stream)
     std::vector<int> T(n);
     int64_t total_t = 0;
     for (int u = 0; u < n; ++u) {
@@ -498,6 +498,12 @@ void VitsModel::forward(const VitsBatch& b) {
     int* d_tn = ar.array<int>(Lt);
     int* d_lg = ar.array<int>(Lt);
     int* d_sid = ar.array<int>(n);
+    int* d_uid = ar.array<int>(n);
+    {
+        std::vector<int> uid(n);
+        for (int u = 0; u < n; ++u) uid[u] = b.utt_ids ? (int)b.utt_ids[u] : b.utt0 + u;
+        ar.upload(d_uid, uid.data(), sizeof(int) * n, stream_);
+    }
     float* d_style = ar.array<float>((size_t)n * cfg_.style_dim);
     ar.upload(d_ph, ph.data(), sizeof(int) * Lt, stream_);
     ar.upload(d_tn, tn.data(), sizeof(int) * Lt, stream_);
@@ -576,7 +582,7 @@ void VitsModel::forward(const VitsBatch& b) {
     conv_plain(sdp_proj_, XSd, COND, 1, 0, tl.d_mask, 1, stream_);
     float* z0 = Z.p;
     float* z1 = Z.p + Z.ld;
-    noise_fill(Z.p, Z.ld, 2, tl.d_seg_of, tl.d_start, tl.d_len, Lt, seed, 0, b.noise_scale_w, stream_);
+    noise_fill(Z.p, Z.ld, 2, tl.d_seg_of, tl.d_start, tl.d_len, d_uid, Lt, seed, 0, b.noise_scale_w, stream_);
     const float inv_sqrt_f = 1.0f / std::sqrt((float)H);
     for (int i = (int)sdp_cf_.size() - 1; i >= 0; --i) {
         const ConvFlow& cf = sdp_cf_[i];
@@ -633,7 +639,7 @@ void VitsModel::forward(const VitsBatch& b) {
 
     // ---- alignment expansion + prior sample ---------------------------------------------------------------
     Plane ZA = ar.plane(I, Lf), ZB = ar.plane(I, Lf);
-    expand_frames(m_p, logs_p, d_tok, fl.d_seg_of, fl.d_start, fl.d_len, seed, b.noise_scale, nullptr, 0, ZA, stream_);
+    expand_frames(m_p, logs_p, d_tok, fl.d_seg_of, fl.d_start, fl.d_len, d_uid, seed, b.noise_scale, ZA, stream_);
     trace("z_p", ZA, fl);
 
     // ---- TransformerCouplingBlock, reverse ----------------------------------------------------------------

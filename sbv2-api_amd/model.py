@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import Sbv2Batch, Sbv2Error, check, f32p, i64p
 
-__all__ = ["Session", "load_model", "predict", "synthesize", "predict_batch", "synthesize_batch", "Pipeline", "Sbv2Error"]
+__all__ = ["Session", "load_model", "predict", "synthesize", "predict_batch", "synthesize_batch", "Pipeline", "Node", "Comm", "deal", "Sbv2Error"]
 
 
 def _i64(a):
@@ -229,4 +229,89 @@ class Pipeline:
     def close(self):
         if self.h:
             _lib.lib().sbv2_pipeline_destroy(self.h)
+            self.h = None
+
+
+def deal(costs, world: int) -> np.ndarray:
+    """rank_of[i] for every utterance: the library's longest-processing-time-first deal (csrc/node.cpp; host only)."""
+    c = np.ascontiguousarray(costs, np.int64)
+    out = np.zeros(len(c), np.int32)
+    check(_lib.lib().sbv2_deal(len(c), c.ctypes.data_as(i64p), world, out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
+
+
+class Node:
+    """One process, N devices: utterance-sharded synthesis with the PCM gathered to device 0 inside the library."""
+
+    def __init__(self, bert_bytes: bytes, vits_bytes: bytes, devices):
+        self.h = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices)
+        bb = (C.c_char * len(bert_bytes)).from_buffer_copy(bert_bytes)
+        vb = (C.c_char * len(vits_bytes)).from_buffer_copy(vits_bytes)
+        check(_lib.lib().sbv2_node_create(C.cast(bb, C.c_void_p), len(bert_bytes), C.cast(vb, C.c_void_p), len(vits_bytes), dv, len(devices),
+                                          C.byref(self.h)))
+
+    def prepare(self, utts, **kw):
+        return Pipeline.prepare(self, utts, **kw)
+
+    def synthesize(self, b, out=None):
+        """Runs the prepared batch; returns the list of PCM arrays in the caller's utterance order."""
+        l = _lib.lib()
+        hop_guess = None
+        if out is None:
+            # capacity: exact when durations are forced, generous otherwise
+            cap = int(b.forced.sum()) * 512 if b.forced is not None else int(b.t_lens.sum()) * 512 * 64
+            out = np.empty(max(cap, 1), np.float32)
+        check(l.sbv2_node_synthesize(self.h, C.byref(b.c), b.ids.ctypes.data_as(i64p), b.s_lens.ctypes.data_as(i64p), b.w2p.ctypes.data_as(i64p),
+                                     b.lens.ctypes.data_as(i64p), out.ctypes.data_as(C.c_void_p), out.size))
+        n = int(b.lens.sum())
+        return np.split(out[:n], np.cumsum(b.lens)[:-1])
+
+    def last_deal(self, n: int) -> np.ndarray:
+        r = np.zeros(n, np.int32)
+        check(_lib.lib().sbv2_node_last_deal(self.h, r.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return r
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(_lib.lib().sbv2_node_uses_rccl(self.h))
+
+    def close(self):
+        if self.h:
+            _lib.lib().sbv2_node_destroy(self.h)
+            self.h = None
+
+
+class Comm:
+    """One process per GPU: the RCCL communicator of the library (no torch).  Rank 0 creates the id, the launcher distributes it."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().sbv2_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int):
+        self.h = C.c_void_p()
+        self.rank, self.world = rank, world
+        check(_lib.lib().sbv2_comm_create(uid, rank, world, device, C.byref(self.h)))
+
+    def barrier(self):
+        check(_lib.lib().sbv2_comm_barrier(self.h))
+
+    def max(self, v: float) -> float:
+        d = C.c_double(v)
+        check(_lib.lib().sbv2_comm_max_f64(self.h, C.byref(d)))
+        return d.value
+
+    def gather_pcm(self, pipe: Pipeline, ticket: int, dst: np.ndarray | None, root: int = 0) -> np.ndarray:
+        """counts[world]; on the root `dst` (float32, possibly a PinnedArray view) receives the ranks' PCM in rank order."""
+        counts = np.zeros(self.world, np.int64)
+        check(_lib.lib().sbv2_comm_gather_pcm(self.h, pipe.h, ticket, root, dst.ctypes.data_as(C.c_void_p) if dst is not None else None,
+                                              dst.size if dst is not None else 0, counts.ctypes.data_as(i64p)))
+        return counts
+
+    def close(self):
+        if self.h:
+            _lib.lib().sbv2_comm_destroy(self.h)
             self.h = None

@@ -449,6 +449,102 @@ def test_config2_b32_u128_default_path():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_node_shards_equal_single_gpu_call():
+    """sbv2_node_synthesize with four shards on one GPU (the same ordinal four times: peers exchange by device-to-device copies) ==
+    one pipeline call of the whole batch, bit for bit, with predicted durations AND noise (streams are keyed by the caller's utterance
+    index, not by the position inside a shard); the deal is the library's LPT deal."""
+    bc, bw = weights("bert", "tiny", 3)
+    vc, vw = weights("vits", "tiny", 5)
+    bb, vb = blob("bert", "tiny", 3), blob("vits", "tiny", 5)
+    utts = make_utts([7, 15, 4, 22, 9, 3, 11, 6, 18], bc, vc, seed0=151, with_bert=False)
+    utts[3]["sid"] = 1
+    bs, vs = model.load_model(bb, True), model.load_model(vb, False)
+    pipe = model.Pipeline(bs, vs)
+    node = model.Node(bb, vb, [0, 0, 0, 0])
+    assert not node.uses_rccl
+    for kw in (dict(forced=True), dict(sdp_ratio=0.3, length_scale=1.1, noise_scale=0.667, noise_scale_w=0.8, noise_seed=123)):
+        b = pipe.prepare(utts, **kw)
+        pipe.run(b)
+        ref = pipe.fetch(b)
+        nb = node.prepare(utts, **kw)
+        cap = np.empty(sum(len(r) for r in ref) + 7, np.float32)
+        got = node.synthesize(nb, out=cap)
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g, r)
+        deal = node.last_deal(len(utts))
+        assert set(deal) == {0, 1, 2, 3}
+        if kw.get("forced"):
+            np.testing.assert_array_equal(deal, model.deal([int(u["forced_durations"].sum()) for u in utts], 4))
+        with pytest.raises(model.Sbv2Error, match="too small"):
+            node.synthesize(nb, out=np.empty(10, np.float32))
+    node.close(); pipe.close(); bs.close(); vs.close()
+
+
+def test_comm_world1_gather_through_rccl():
+    """The one-process-per-GPU communicator with world size 1 on the box's GPU: RCCL is dlopen'ed, ncclCommInitRank / all-reduce / all-gather
+    run for real, and the gather returns the run's PCM (by ticket) with the count table."""
+    bc, bw = weights("bert", "tiny", 3)
+    vc, vw = weights("vits", "tiny", 5)
+    bs, vs = model.load_model(blob("bert", "tiny", 3), True), model.load_model(blob("vits", "tiny", 5), False)
+    pipe = model.Pipeline(bs, vs)
+    comm = model.Comm(model.Comm.unique_id(), 0, 1, 0)
+    assert comm.max(3.5) == 3.5
+    comm.barrier()
+    utts = make_utts([7, 15, 4], bc, vc, seed0=161, with_bert=False)
+    b = pipe.prepare(utts, forced=True)
+    pipe.run(b)
+    ref = np.concatenate(pipe.fetch(b))
+    pin = model.PinnedArray(ref.size)
+    counts = comm.gather_pcm(pipe, b.ticket, pin.array)
+    assert counts.tolist() == [ref.size]
+    np.testing.assert_array_equal(pin.array, ref)
+    with pytest.raises(model.Sbv2Error, match="too small"):
+        comm.gather_pcm(pipe, b.ticket, np.empty(5, np.float32))
+    pin.close(); comm.close(); pipe.close(); bs.close(); vs.close()
+
+
+def test_config3_b256_mixed_lengths_sharded_8_ways():
+    """BASELINE configs[3]: batch 256 of mixed 32..512-phoneme utterances, utterance-sharded 8 ways.  One GPU is all a test box has, so the
+    eight shards run on eight execution contexts of that GPU (the library's deal, threads, gather and permutation are the ones an 8-GPU
+    node uses; only ncclSend / ncclRecv are replaced by device-to-device copies).  Every utterance: length and finiteness; 6 of them
+    bit-equal to a batch-1 call; 2 of them vs the oracle."""
+    bc, bw = weights("bert", "full")
+    vc, vw = weights("vits", "full")
+    bb, vb = blob("bert", "full"), blob("vits", "full")
+    rng = np.random.default_rng(256)
+    ns = [int(v) for v in rng.integers(32, 513, 256)]
+    ns[5], ns[77] = 32, 512
+    utts = [synth.make_utterance(n, bc, vc, seed=3000 + i, chars=min(98, max(1, n // 2 - 2))) for i, n in enumerate(ns)]
+    node = model.Node(bb, vb, [0] * 8)
+    b = node.prepare(utts, forced=True)
+    total = sum(512 * (7 * n + 1) for n in ns)
+    pin = model.PinnedArray(total)
+    got = node.synthesize(b, out=pin.array)
+    assert [len(g) for g in got] == [512 * (7 * n + 1) for n in ns]
+    deal = node.last_deal(256)
+    loads = [sum(7 * ns[i] + 1 for i in range(256) if deal[i] == r) for r in range(8)]
+    assert max(loads) - min(loads) <= 7 * 512 + 1
+    for g in got:
+        assert np.isfinite(g).all() and np.abs(g).max() < 1.0
+    bs, vs = model.load_model(bb, True), model.load_model(vb, False)
+    pipe = model.Pipeline(bs, vs)
+    for i in (0, 5, 77, 100, 200, 255):
+        b1 = pipe.prepare([utts[i]], forced=True)
+        pipe.run(b1)
+        np.testing.assert_array_equal(pipe.fetch(b1)[0], got[i])
+    O.set_conv_backend("torch")
+    try:
+        for i in (5, int(np.argmin(np.abs(np.array(ns) - 128)))):
+            ref = _oracle_pipeline(bw, bc, vw, vc, utts[i])
+            err = float(np.abs(got[i] - ref).max())
+            print(f"configs[3] utterance {i} ({ns[i]} phones): waveform max-abs error {err:.3e}")
+            assert err < 5e-5
+    finally:
+        O.set_conv_backend("numpy")
+    pin.close(); node.close(); pipe.close(); bs.close(); vs.close()
+
+
 def test_pipeline_tiny():
     """DeBERTa -> word2ph repeat -> VITS on the device equals predict + expand + synthesize through the host."""
     bc, bw = weights("bert", "tiny", 3)

@@ -61,6 +61,22 @@ def test_deal_is_balanced_and_complete():
         assert max(loads) - min(loads) <= max(costs)
 
 
+def test_library_deal_matches_host_deal():
+    """sbv2_deal (C ABI, csrc/node.cpp) == shard.deal: complete, deterministic, balanced to one utterance's cost, skewed counts allowed."""
+    from sbv2_api_amd import model
+    rng = np.random.default_rng(0)
+    cases = [[7 * n + 1 for n in rng.integers(32, 513, 256)], [512, 32, 32, 32, 32, 40], [5], [3, 3, 3, 3], []]
+    for costs in cases:
+        for world in (1, 2, 8):
+            r = model.deal(costs, world)
+            ref = shard.deal(costs, world)
+            got = [[i for i in range(len(costs)) if r[i] == q] for q in range(world)]
+            assert [sorted(s) for s in ref] == got
+            if costs:
+                loads = [sum(costs[i] for i in s) for s in got]
+                assert max(loads) - min(loads) <= max(costs)
+
+
 _SKEWED = [512, 32, 32, 32, 32, 40]     # deals 1 + 5 utterances on two ranks: more than ceil(6 / 2) on one of them
 
 
