@@ -10,7 +10,10 @@
  *     outputs are either caller-allocated or owned buffers released with sbv2_pcm_free (the reference returns owned
  *     arrays: model.rs:108, bert.rs:21).
  *   - a handle is used by one caller at a time (`&mut Session` in the reference: bert.rs:7, model.rs:54).
- *   - model bytes are a weight container ("SBV2W001", see sbv2-api_amd/synth.py); they need not outlive *_create.
+ *   - model bytes: what the reference hands to load_model, i.e. an ONNX ModelProto (deberta.onnx / model_<name>.onnx: the initializers are
+ *     read, the graph itself is replaced by the HIP path), or a whole `.sbv2` file (zstd(tar{model.onnx, style_vectors.json})) for the VITS
+ *     handle; also the synthetic weight container "SBV2W001" (sbv2-api_amd/synth.py) used by tests and bench.py.  The bytes need not
+ *     outlive *_create (the reference drops them unless max_loaded_models is set: tts.rs:171-175).
  */
 #ifndef SBV2_HIP_H
 #define SBV2_HIP_H
@@ -124,6 +127,16 @@ int sbv2_pipeline_fetch_pcm(sbv2_pipeline* p, float* dst, int64_t capacity, int 
 void* sbv2_host_alloc(size_t bytes);
 void sbv2_host_free(void* p);
 
+/* ---- sbv2file.rs:15-37 `parse_sbv2file(bytes) -> (style_vectors, vits2)`: a .sbv2 file is zstd(tar{version.txt, model.onnx,
+ * style_vectors.json}) (writer: scripts/convert/convert_model.py:156-175).  Both outputs are owned copies (sbv2_bytes_free).
+ * Errors: "model not found: style_vectors" / "model not found: vits2" (Error::ModelNotFoundError, sbv2file.rs:31-36). ------------------- */
+int sbv2_parse_sbv2file(const uint8_t* sbv2_bytes, size_t len, uint8_t** style_vectors, size_t* style_len, uint8_t** vits2, size_t* vits2_len);
+void sbv2_bytes_free(uint8_t* p);
+/* style.rs:11-17 `load_style`: {"shape": [n, dim], "data": [[..], ..]} -> owned f32 [n][dim] (release with sbv2_bytes_free) */
+int sbv2_style_load(const uint8_t* json, size_t len, float** data, int64_t* n, int64_t* dim);
+/* style.rs:19-28 `get_style_vector`: out[dim] = mean + (style_vectors[style_id] - mean) * weight, mean = row 0 */
+int sbv2_style_vector(const float* style_vectors, int64_t n, int64_t dim, int64_t style_id, float weight, float* out);
+
 /* ---- new: multi-GPU.  The reference is one process, one device, batch 1; a batch of independent utterances is
  * sharded over the GPUs of a node (sorted by cost, longest-processing-time-first deal, a full weight replica per GPU, no data-path
  * collective) and the PCM is gathered to rank 0 over RCCL / xGMI (one all-gather of the sample counts + grouped send / recv).
@@ -158,6 +171,20 @@ int sbv2_node_synthesize(sbv2_node* nd, const sbv2_batch* batch, const int64_t* 
                          int64_t* pcm_lens, float* pcm_host, int64_t capacity);
 int sbv2_node_last_deal(const sbv2_node* nd, int32_t* rank_of, int64_t n);   /* which device ran which utterance in the last call */
 
+/* ---- new: streaming long-form synthesis (BASELINE configs[4]).  The reference synthesises one sentence per session.run and only splits
+ * long text on '\n' (tts.rs:290-321).  Here DeBERTa / text encoder / durations / flow run whole-sequence (global attention) and the HiFi-GAN
+ * decoder runs on fixed windows of chunk_frames + 2 x 16 halo frames, ONE hipGraph captured per window shape and replayed per chunk;
+ * chunked output equals the whole-sequence output (the halo covers the generator's 13.4-frame receptive field per side). ------------- */
+typedef struct sbv2_stream sbv2_stream;
+/* batch->n must be 1; inputs as for sbv2_pipeline_run.  *total_samples = samples of the whole utterance.  The handles are busy until _end. */
+int sbv2_stream_begin(sbv2_bert* bert, sbv2_vits* vits, const sbv2_batch* batch, const int64_t* token_ids, const int64_t* s_lens,
+                      const int64_t* word2ph, int64_t chunk_frames, sbv2_stream** out, int64_t* total_samples);
+/* next chunk -> dst (host; capacity samples, chunk_frames * hop always suffices); *n = samples written, 0 at the end */
+int sbv2_stream_next(sbv2_stream* s, float* dst, int64_t capacity, int64_t* n);
+int sbv2_stream_uses_graph(const sbv2_stream* s);
+int64_t sbv2_stream_workspace_bytes(const sbv2_stream* s);
+void sbv2_stream_end(sbv2_stream* s);
+
 /* ---- test hooks (no reference counterpart) ------------------------------------------------------------------------ */
 /* bucket(rel) for rel in [-(max_s-1), max_s-1] (transformers modeling_deberta_v2.py:57-69); host only, no GPU needed. */
 int sbv2_debug_bucket_table(int64_t max_s, int64_t buckets, int64_t max_rel, int32_t* out);
@@ -178,6 +205,9 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
 int sbv2_debug_conv1d_ps(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k,
                          int64_t L, int64_t dilation, float pre_slope, float out_slope, int split, int residual, int64_t iters,
                          float* y, float* ya, float* ms);
+/* The named-tensor table an import of `model` (ONNX / .sbv2 / container; kind 1 = DeBERTa, 2 = VITS) produces, written back as an SBV2W001
+ * container (owned, sbv2_bytes_free): tests compare it with the container the same weights were packed into.  Host only. */
+int sbv2_debug_import_to_container(const uint8_t* model, size_t len, int kind, uint8_t** out, size_t* out_len);
 /* Per-launch HIP-event timing of the implicit-GEMM kernel family between begin and end; end writes a JSON array
  * [{"kernel", "launches", "ms", "flop"}] (one entry per tile configuration) into json[cap]. */
 int sbv2_prof_begin(void);

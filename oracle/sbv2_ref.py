@@ -11,6 +11,27 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# libgomp's default is to spin at barriers; on a box whose cgroup grants fewer CPUs than it shows that turns into a livelock
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: min(scheduler affinity, cgroup CPU quota).  (The GPU boxes of the pool show 256 hardware threads
+    but grant a container 16 CPUs of time through cgroup v2 cpu.max; 256 OpenMP threads on that are ~100x slower than 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
 _f32p, _i64p = C.POINTER(C.c_float), C.POINTER(C.c_int64)
 _libs = {}
 

@@ -73,6 +73,16 @@ SYMBOLS = {
     "sbv2_node_uses_rccl": (C.c_int, [C.c_void_p]),
     "sbv2_node_synthesize": (C.c_int, [C.c_void_p, C.POINTER(Sbv2Batch), i64p, i64p, i64p, i64p, C.c_void_p, C.c_int64]),
     "sbv2_node_last_deal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]),
+    "sbv2_stream_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Sbv2Batch), i64p, i64p, i64p, C.c_int64, C.POINTER(C.c_void_p), i64p]),
+    "sbv2_stream_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, i64p]),
+    "sbv2_stream_uses_graph": (C.c_int, [C.c_void_p]),
+    "sbv2_stream_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "sbv2_stream_end": (None, [C.c_void_p]),
+    "sbv2_parse_sbv2file": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "sbv2_bytes_free": (None, [C.c_void_p]),
+    "sbv2_style_load": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), i64p, i64p]),
+    "sbv2_style_vector": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
+    "sbv2_debug_import_to_container": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sbv2_debug_bucket_table": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "sbv2_debug_conv1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
     "sbv2_debug_conv_transpose1d": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

@@ -63,7 +63,7 @@ int sbv2_device_count(void) {
 int sbv2_bert_create(const uint8_t* model, size_t model_len, int device, sbv2_bert** out) {
     API_BEGIN
     SBV2_REQUIRE(out, "null output handle");
-    Blob blob = parse_blob(model, model_len);
+    Blob blob = load_model_bytes(model, model_len, 1);
     std::unique_ptr<sbv2_bert> h(new sbv2_bert);
     h->m.reset(new BertModel(blob, device));
     *out = h.release();
@@ -87,7 +87,7 @@ int sbv2_bert_predict(sbv2_bert* h, const int64_t* token_ids, const int64_t* att
 int sbv2_vits_create(const uint8_t* model, size_t model_len, int device, sbv2_vits** out) {
     API_BEGIN
     SBV2_REQUIRE(out, "null output handle");
-    Blob blob = parse_blob(model, model_len);
+    Blob blob = load_model_bytes(model, model_len, 2);
     std::unique_ptr<sbv2_vits> h(new sbv2_vits);
     h->m.reset(new VitsModel(blob, device));
     *out = h.release();

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -68,6 +69,11 @@ class Arena {
     // Host -> device copy that never blocks the host: the bytes are staged in pinned memory owned by the arena (valid until
     // the next reset()) and copied asynchronously on `stream`.
     void upload(void* dst, const void* src, size_t bytes, hipStream_t stream);
+    // recycles the pinned staging only (callers guarantee that every copy issued so far has completed)
+    void reset_pinned() {
+        for (auto& c : pinned_) c.off = 0;
+        pcur_ = 0;
+    }
     void release();
     size_t capacity() const;
 
@@ -101,11 +107,21 @@ struct Blob {
     uint32_t kind = 0;
     std::string config_json;
     std::map<std::string, HostTensor> tensors;
+    std::shared_ptr<void> owned;   // storage behind `tensors` when the blob was imported (ONNX / .sbv2) instead of viewing the caller's bytes
     const HostTensor& get(const std::string& name) const;
     bool has(const std::string& name) const { return tensors.count(name) != 0; }
 };
 
 Blob parse_blob(const uint8_t* bytes, size_t n);
+// import.cpp: whatever the reference's load_model may be handed (SBV2W001 container, .sbv2 = zstd(tar), bare tar, ONNX ModelProto)
+struct Span2 {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+};
+Blob load_model_bytes(const uint8_t* bytes, size_t n, uint32_t want_kind);   // 1 = DeBERTa, 2 = VITS
+Blob import_vits_onnx(const uint8_t* bytes, size_t n);
+Blob import_bert_onnx(const uint8_t* bytes, size_t n);
+void parse_sbv2file_bytes(const uint8_t* b, size_t n, std::vector<uint8_t>& storage, Span2& style, Span2& onnx);
 // minimal JSON helpers for the flat config object
 bool json_has(const std::string& js, const std::string& key);
 std::string json_string(const std::string& js, const std::string& key);

@@ -175,9 +175,8 @@ void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float*
     launch_conv_cl(p, stream_);
 }
 
-void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
+void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const float* cond_vec) {
     const int n = fl.n, Lf = fl.L, I = cfg_.inter;
-    Arena& ar = arena_;
     SBV2_REQUIRE(I % 16 == 0, "flow channels must be a multiple of 16 for the channels-last decoder");
     // z [inter][Lf] -> channels-last [Lf][inter]
     float* zc = ar.array<float>((size_t)Lf * I);
@@ -185,7 +184,7 @@ void VitsModel::run_decoder_cl(Plane z, const SegLayout& fl) {
     int C = cfg_.up_initial;
     float* cur = ar.array<float>((size_t)Lf * C);
     conv_cl(cl_pre_, zc, I, Lf, cur, C, Lf, 1, cl_pre_.k / 2, fl.d_mask, 1, 1.0f, nullptr, 0, 1.0f, 0);
-    add_segvec_cl(cur, Lf, C, dec_cond_vec_, C, fl.d_seg_of, fl.d_mask, stream_);
+    add_segvec_cl(cur, Lf, C, cond_vec, C, fl.d_seg_of, fl.d_mask, stream_);
     int U = 1;
     int64_t Lcur = Lf;
     const int nk = (int)cfg_.res_kernels.size();

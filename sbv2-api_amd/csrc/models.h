@@ -171,6 +171,7 @@ struct VitsBatch {
     int utt0 = 0;                               // index of the first utterance in the caller's batch (noise stream keys) ...
     const int64_t* utt_ids = nullptr;           // ... or, for an arbitrary subset (a shard dealt to this GPU), every utterance's index
     hipStream_t after_stream = nullptr;         // when set, the forward's kernels wait for the work queued on this stream
+    bool skip_decoder = false;                  // stop after the flow (streaming: the decoder then runs chunk by chunk, stream_*)
 };
 
 class VitsModel {
@@ -182,6 +183,16 @@ class VitsModel {
     int device() const { return device_; }
     const VitsConfig& cfg() const { return cfg_; }
     void forward(const VitsBatch& b);
+    // Streaming long-form decode (BASELINE configs[4]) of the utterance of the last forward(skip_decoder = true, n = 1): the HiFi-GAN
+    // decoder runs on windows of chunk_frames + 2 * kStreamHalo frames, ONE hipGraph captured for that fixed shape and replayed per
+    // chunk; the workspace is bounded by the window.  stream_begin returns the number of frames; stream_chunk decodes frames
+    // [f0, f0 + chunk_frames) into dst (host) and returns the number of samples written.
+    // halo frames per side = the generator's receptive field (from the config: 13.4 frames -> 16 for JP-Extra, SURVEY.md §5 "Long-context")
+    int stream_halo() const;
+    int64_t stream_begin(int chunk_frames);
+    int64_t stream_chunk(int64_t f0, float* dst_host, int64_t capacity);
+    bool stream_graph_captured() const { return chunk_ && chunk_->exec != nullptr; }
+    size_t stream_workspace_bytes() const { return chunk_ ? chunk_->ar.capacity() : 0; }
     // results of the last forward
     const std::vector<int64_t>& pcm_lens() const { return pcm_lens_; }
     const std::vector<int64_t>& pcm_offs() const { return pcm_offs_; }
@@ -245,7 +256,7 @@ class VitsModel {
     DDS load_dds(const std::string& prefix, int channels);
     void run_encoder(const Encoder& e, Plane x, const SegLayout& lay, const float* spk_vec, Arena& ar);
     void run_dds(const DDS& d, Plane x, const SegLayout& lay, Arena& ar);
-    void run_decoder(Plane z, const SegLayout& fl);
+    void run_decoder(Arena& ar, Plane z, const SegLayout& fl, const float* cond_vec);
     // channels-last bf16 / split-bf16 MFMA decoder (decoder_cl.cpp)
     struct ClUpGroup {
         ClConv c;
@@ -264,10 +275,29 @@ class VitsModel {
         int cin, ch, rate;
     };
     void load_decoder_cl(const Blob& blob);
-    void run_decoder_cl(Plane z, const SegLayout& fl);
+    void run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const float* cond_vec);
     void conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l, const unsigned char* mask,
                  int mask_div, float pre_slope, const float* R, int ldr, float beta, int accumulate);
     void trace(const std::string& name, Plane p, const SegLayout& lay, int div = 1);
+    // fixed-shape decoder of the streaming path: own arena (never reset while the plan lives), persistent input / conditioning buffers
+    // and the captured graph
+    struct ChunkPlan {
+        int chunk = 0, W = 0;
+        Arena ar;
+        SegLayout lay;
+        Plane zin;
+        float* cond = nullptr;
+        Arena::Mark mark{0, 0};
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        float* pcm = nullptr;       // window PCM (W * hop samples), valid after a replay
+        ~ChunkPlan() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+    };
+    std::shared_ptr<ChunkPlan> chunk_;
+    Plane z_{};              // flow output of the last forward (frame-rate plane, packed layout fl_)
 
     int device_;
     VitsConfig cfg_;

@@ -286,7 +286,7 @@ int sbv2_node_create(const uint8_t* bert_model, size_t bert_len, const uint8_t* 
     try {
         SBV2_REQUIRE(bert_model && vits_model && devices && ndev >= 1 && ndev <= 64 && out, "bad arguments");
         raw = new sbv2_node;
-        Blob bb = parse_blob(bert_model, bert_len), vb = parse_blob(vits_model, vits_len);
+        Blob bb = load_model_bytes(bert_model, bert_len, 1), vb = load_model_bytes(vits_model, vits_len, 2);
         raw->devs.resize(ndev);
         bool distinct = true;
         for (int i = 0; i < ndev; ++i)

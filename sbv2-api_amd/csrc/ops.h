@@ -63,6 +63,8 @@ void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_
                 uint64_t seed, int stream_id, float scale, hipStream_t s);
 void expand_frames(Plane m_p, Plane logs_p, const int* tok_of_frame, const int* seg_of, const int* seg_start,
                    const int* seg_len, const int* seg_utt, uint64_t seed, float noise_scale, Plane out, hipStream_t s);
+// out[c][j] = in[c][col0 + j] or 0 outside the plane; mask[j] = 1 where the column exists (the chunk window of the streaming decoder)
+void window_cols(Plane in, int col0, Plane out, unsigned char* mask, hipStream_t s);
 // dst[tab[3i + 1] + e] = src[tab[3i] + e] for e < tab[3i + 2], i < n (device table)
 void copy_segments(const float* src, float* dst, const int64_t* d_table, int n, hipStream_t s);
 void conv_post_tanh(Plane x, const float* w, int k, float slope, const int* seg_start, const int* seg_len,

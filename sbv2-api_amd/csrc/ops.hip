@@ -811,6 +811,22 @@ void conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, 
 void fill_zero(void* p, size_t bytes, hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming decode: out[c][j] = in[c][col0 + j] (0 outside [0, in.L)), mask[j] = column col0 + j exists; out.L columns
+// ------------------------------------------------------------------------------------------------
+__global__ void k_window_cols(Plane in, int col0, Plane out, unsigned char* mask) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (j >= out.L) return;
+    const int q = col0 + j;
+    const bool ok = q >= 0 && q < in.L;
+    out.p[(size_t)c * out.ld + j] = ok ? in.p[(size_t)c * in.ld + q] : 0.f;
+    if (c == 0 && mask) mask[j] = ok ? 1 : 0;
+}
+void window_cols(Plane in, int col0, Plane out, unsigned char* mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_window_cols, dim3((out.L + 255) / 256, out.C), dim3(256), 0, s, in, col0, out, mask);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Segment permutation: dst[tab[i].dst + e] = src[tab[i].src + e], e < tab[i].len  (PCM blocks received per device -> utterance order)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_copy_segments(const float* src, float* dst, const int64_t* tab) {

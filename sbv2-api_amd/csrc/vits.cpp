@@ -268,6 +268,8 @@ VitsModel* VitsModel::clone() const {
     c->pcm_lens_.clear();
     c->pcm_offs_.clear();
     c->traces_.clear();
+    c->chunk_.reset();
+    c->z_ = Plane{};
     c->trace_ = false;
     return c;
 }
@@ -370,13 +372,12 @@ void VitsModel::run_dds(const DDS& d, Plane x, const SegLayout& lay, Arena& ar) 
 }
 
 // models_jp_extra.Generator
-void VitsModel::run_decoder(Plane z, const SegLayout& fl) {
+void VitsModel::run_decoder(Arena& ar, Plane z, const SegLayout& fl, const float* cond_vec) {
     const int n = fl.n;
     const int Lf = fl.L;
-    Arena& ar = arena_;
     Plane cur = ar.plane(cfg_.up_initial, Lf);
     conv_plain(dec_pre_, z, cur, 1, dec_pre_.k / 2, fl.d_mask, 1, stream_);
-    add_segvec(cur, dec_cond_vec_, cfg_.up_initial, fl.d_seg_of, 1, fl.d_mask, stream_);
+    add_segvec(cur, cond_vec, cfg_.up_initial, fl.d_seg_of, 1, fl.d_mask, stream_);
     trace("dec_pre", cur, fl, 1);
     int U = 1;
     const int nk = (int)cfg_.res_kernels.size();
@@ -655,9 +656,122 @@ void VitsModel::forward(const VitsBatch& b) {
         conv_plain(c.post, Hf, x1, 1, 0, fl.d_mask, 1, stream_, ACT_NONE, 1.0f, &x1, -1.0f);  // x1 = (x1 - m) * mask
     }
     trace("z", ZA, fl);
+    z_ = ZA;
+    if (b.skip_decoder) {   // streaming: the caller decodes chunk by chunk (stream_begin / stream_chunk)
+        pcm_ = nullptr;
+        pcm_total_ = 0;
+        pcm_lens_.assign(n, 0);
+        pcm_offs_.assign(n, 0);
+        return;
+    }
+    if (dec_mode_) run_decoder_cl(ar, ZA, fl, dec_cond_vec_);
+    else run_decoder(ar, ZA, fl, dec_cond_vec_);
+}
 
-    if (dec_mode_) run_decoder_cl(ZA, fl);
-    else run_decoder(ZA, fl);
+// ---- streaming long-form decode ---------------------------------------------------------------------------------------------------
+// The generator is purely convolutional: frames [f0, f0 + chunk) depend on z[f0 - 13.4, f0 + chunk + 13.4) only, so a window with a
+// 16-frame halo on both sides reproduces the whole-sequence result on its centre.  The window's column mask marks which of its frames
+// exist (the sequence ends are zero padding at EVERY layer, exactly like the gaps of a packed batch), interior window edges only
+// contaminate the halo, which is discarded.  The window shape is fixed, so the ~90 launches of the decoder are captured once into a
+// hipGraph and replayed per chunk; all device pointers of the captured launches live in the plan's own arena.
+// Receptive field of the generator per side, in frames: conv_pre + per stage {transposed-conv taps at the input rate, the widest MRF branch
+// sum_d (d + 1)(k - 1) / 2 at the output rate} + conv_post; + 1 frame of margin, rounded up to a multiple of 4.
+int VitsModel::stream_halo() const {
+    double rf = (dec_pre_.k - 1) / 2.0;
+    double rate = 1.0;
+    for (size_t i = 0; i < stages_.size(); ++i) {
+        int tmax = 0;
+        for (const auto& g : stages_[i].up.groups)
+            for (int t = 0; t < g.ntaps; ++t) tmax = std::max(tmax, std::abs(g.shift[t]));
+        rf += tmax / rate;
+        rate *= stages_[i].rate;
+        int mrf = 0;
+        for (const auto& rb : stages_[i].branches) {
+            int h = 0;
+            for (int d : rb.dil) h += (d + 1) * (rb.k - 1) / 2;
+            mrf = std::max(mrf, h);
+        }
+        rf += mrf / rate;
+    }
+    rf += (dec_post_k_ - 1) / 2.0 / rate;
+    return round_up((int)std::ceil(rf) + 1, 4);
+}
+
+int64_t VitsModel::stream_begin(int chunk_frames) {
+    HIP_CHECK(hipSetDevice(device_));
+    SBV2_REQUIRE(fl_.n == 1 && z_.p, "stream_begin needs a preceding forward of ONE utterance with skip_decoder");
+    SBV2_REQUIRE(chunk_frames >= 16 && chunk_frames <= (1 << 20), "chunk_frames must be in [16, 2^20]");
+    static const bool no_graph = getenv("SBV2_STREAM_GRAPH") && atoi(getenv("SBV2_STREAM_GRAPH")) == 0;   // A/B knob
+    if (!chunk_ || chunk_->chunk != chunk_frames) {
+        chunk_.reset(new ChunkPlan);
+        ChunkPlan& c = *chunk_;
+        c.chunk = chunk_frames;
+        c.W = chunk_frames + 2 * stream_halo();
+        c.lay = make_layout(std::vector<int>{c.W}, kFrameGap, c.ar, stream_);
+        c.zin = c.ar.plane(cfg_.inter, c.lay.L);
+        fill_zero(c.zin.p, sizeof(float) * (size_t)c.zin.C * c.zin.ld, stream_);
+        c.cond = c.ar.array<float>((size_t)cfg_.up_initial);
+        c.mark = c.ar.mark();
+    }
+    ChunkPlan& c = *chunk_;
+    // the speaker conditioning vector of THIS utterance goes into the plan's persistent buffer (the captured launches read it there)
+    HIP_CHECK(hipMemcpyAsync(c.cond, dec_cond_vec_, sizeof(float) * (size_t)cfg_.up_initial, hipMemcpyDeviceToDevice, stream_));
+    if (!c.exec && !no_graph) {
+        // warm-up pass (sizes the arena: no hipMalloc may happen under capture), then the same launch sequence under capture
+        auto decode = [&]() {
+            c.ar.rewind(c.mark);
+            if (dec_mode_) run_decoder_cl(c.ar, c.zin, c.lay, c.cond);
+            else run_decoder(c.ar, c.zin, c.lay, c.cond);
+            c.pcm = pcm_;
+        };
+        const bool tr = trace_;
+        trace_ = false;
+        decode();
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        try {
+            decode();
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(stream_, &g);
+            if (g) (void)hipGraphDestroy(g);
+            trace_ = tr;
+            throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(stream_, &c.graph));
+        HIP_CHECK(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
+        trace_ = tr;
+    }
+    if (!c.exec) HIP_CHECK(hipStreamSynchronize(stream_));   // eager path: the plan's pinned staging is recycled per chunk
+    return fl_.len[0];
+}
+
+int64_t VitsModel::stream_chunk(int64_t f0, float* dst_host, int64_t capacity) {
+    HIP_CHECK(hipSetDevice(device_));
+    SBV2_REQUIRE(chunk_ && z_.p && fl_.n == 1, "stream_chunk without stream_begin");
+    ChunkPlan& c = *chunk_;
+    const int64_t Tf = fl_.len[0];
+    SBV2_REQUIRE(f0 >= 0 && f0 < Tf, "chunk start out of range");
+    const int hop = cfg_.hop();
+    const int64_t nframes = std::min<int64_t>(c.chunk, Tf - f0), nsamp = nframes * hop;
+    SBV2_REQUIRE(capacity >= nsamp, "PCM buffer too small for the chunk");
+    // window = frames [f0 - halo, f0 - halo + W) of this utterance (fl_.start[0] is its first column in the packed plane)
+    Plane zu = z_;
+    zu.p = z_.p + fl_.start[0];
+    zu.L = (int)Tf;
+    window_cols(zu, (int)(f0 - stream_halo()), Plane{c.zin.p, c.zin.C, c.W, c.zin.ld}, c.lay.d_mask, stream_);
+    if (c.exec) {
+        HIP_CHECK(hipGraphLaunch(c.exec, stream_));
+    } else {
+        c.ar.rewind(c.mark);
+        c.ar.reset_pinned();   // every earlier copy has completed (stream_chunk ends with a stream sync)
+        if (dec_mode_) run_decoder_cl(c.ar, c.zin, c.lay, c.cond);
+        else run_decoder(c.ar, c.zin, c.lay, c.cond);
+        c.pcm = pcm_;
+    }
+    HIP_CHECK(hipMemcpyAsync(dst_host, c.pcm + (size_t)stream_halo() * hop, sizeof(float) * (size_t)nsamp, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return nsamp;
 }
 
 void VitsModel::copy_pcm(float* host) {

@@ -232,6 +232,45 @@ class Pipeline:
             self.h = None
 
 
+def stream_synthesize(bert: Session, vits: Session, utt, chunk_frames=256, **kw):
+    """Generator over the PCM chunks of ONE long utterance (BASELINE configs[4]): whole-sequence DeBERTa / text / flow, then the HiFi-GAN
+    decoder chunk by chunk through a captured hipGraph.  Yields float32 arrays; `.info` of the generator's first item is not needed:
+    use stream_open for the handle-level interface."""
+    st = StreamHandle(bert, vits, utt, chunk_frames, **kw)
+    try:
+        while True:
+            c = st.next()
+            if c is None:
+                return
+            yield c
+    finally:
+        st.close()
+
+
+class StreamHandle:
+    def __init__(self, bert: Session, vits: Session, utt, chunk_frames=256, **kw):
+        l = _lib.lib()
+        self.b = Pipeline.prepare(None, [utt], **kw)
+        self.h = C.c_void_p()
+        tot = C.c_int64()
+        check(l.sbv2_stream_begin(bert.handle, vits.handle, C.byref(self.b.c), self.b.ids.ctypes.data_as(i64p), self.b.s_lens.ctypes.data_as(i64p),
+                                  self.b.w2p.ctypes.data_as(i64p), chunk_frames, C.byref(self.h), C.byref(tot)))
+        self.total_samples = tot.value
+        self.buf = np.empty(chunk_frames * l.sbv2_vits_hop(vits.handle), np.float32)
+        self.uses_graph = bool(l.sbv2_stream_uses_graph(self.h))
+        self.workspace_bytes = l.sbv2_stream_workspace_bytes(self.h)
+
+    def next(self):
+        n = C.c_int64()
+        check(_lib.lib().sbv2_stream_next(self.h, self.buf.ctypes.data_as(C.c_void_p), self.buf.size, C.byref(n)))
+        return None if n.value == 0 else self.buf[:n.value].copy()
+
+    def close(self):
+        if self.h:
+            _lib.lib().sbv2_stream_end(self.h)
+            self.h = None
+
+
 def deal(costs, world: int) -> np.ndarray:
     """rank_of[i] for every utterance: the library's longest-processing-time-first deal (csrc/node.cpp; host only)."""
     c = np.ascontiguousarray(costs, np.int64)

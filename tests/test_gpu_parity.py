@@ -545,6 +545,72 @@ def test_config3_b256_mixed_lengths_sharded_8_ways():
     pin.close(); node.close(); pipe.close(); bs.close(); vs.close()
 
 
+def _stream_all(bs, vs, u, chunk, **kw):
+    st = model.StreamHandle(bs, vs, u, chunk, **kw)
+    parts = []
+    while True:
+        c = st.next()
+        if c is None:
+            break
+        parts.append(c)
+    info = (st.total_samples, st.uses_graph, st.workspace_bytes)
+    st.close()
+    return np.concatenate(parts), info, [len(p) for p in parts]
+
+
+def test_streaming_tiny_chunked_equals_whole():
+    """Streaming decode (fixed window + halo, one captured hipGraph replayed per chunk) == whole-sequence decode, bit for bit, for chunk
+    sizes that do and do not divide the utterance, with predicted durations and noise; a second utterance reuses the captured graph."""
+    bc, bw = weights("bert", "tiny", 3)
+    vc, vw = weights("vits", "tiny", 5)
+    bs, vs = model.load_model(blob("bert", "tiny", 3), True), model.load_model(blob("vits", "tiny", 5), False)
+    pipe = model.Pipeline(bs, vs)
+    for n, kw in ((40, dict(forced=True)), (23, dict(sdp_ratio=0.2, noise_scale=0.667, noise_scale_w=0.8, noise_seed=5))):
+        u = make_utts([n], bc, vc, seed0=171 + n, with_bert=False)[0]
+        b = pipe.prepare([u], **kw)
+        pipe.run(b)
+        whole = pipe.fetch(b)[0]
+        for chunk in (16, 50, 64):
+            got, (total, graph, ws), sizes = _stream_all(bs, vs, u, chunk, **kw)
+            assert graph and total == whole.size == got.size and ws > 0
+            assert all(s == chunk * O.hop_length(vc) for s in sizes[:-1])
+            np.testing.assert_array_equal(got, whole)
+    pipe.close(); bs.close(); vs.close()
+
+
+def test_config4_streaming_long_form_full_shapes():
+    """BASELINE configs[4]: >= 2000 phonemes (T_text 4001, 14001 frames, 162.6 s of audio) streamed in 256-frame chunks through the
+    captured decoder graph == the whole-sequence decode within 1e-5 (same arithmetic, same summation order: expected bit-equal);
+    a 600-symbol utterance streamed vs the oracle within north_star's 1e-3; the chunk decoder's workspace does not grow with the utterance."""
+    bc, bw = weights("bert", "full")
+    vc, vw = weights("vits", "full")
+    bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
+    pipe = model.Pipeline(bs, vs)
+    u = synth.make_utterance(2000, bc, vc, seed=991, chars=98)
+    b = pipe.prepare([u], forced=True)
+    pipe.run(b)
+    whole = pipe.fetch(b)[0]
+    assert whole.shape == (512 * 14001,)
+    got, (total, graph, ws_long), sizes = _stream_all(bs, vs, u, 256, forced=True)
+    assert graph and total == whole.size and len(sizes) == 55
+    err = float(np.abs(got - whole).max())
+    print(f"configs[4]: 2000 phonemes, 55 chunks of 256 frames, chunked vs whole-sequence max-abs {err:.3e}, chunk workspace {ws_long / 2**20:.0f} MiB")
+    assert err <= 1e-5
+    u6 = synth.make_utterance(600, bc, vc, seed=990, chars=98)
+    got6, (_, graph6, ws_short), _ = _stream_all(bs, vs, u6, 256, forced=True)
+    assert graph6 and ws_short == ws_long          # bounded by the window, not by the utterance
+    O.set_conv_backend("torch")
+    try:
+        ref = _oracle_pipeline(bw, bc, vw, vc, u6)
+    finally:
+        O.set_conv_backend("numpy")
+    assert got6.shape == ref.shape
+    e6 = float(np.abs(got6 - ref).max())
+    print(f"configs[4]: 600 symbols streamed vs oracle max-abs {e6:.3e}")
+    assert e6 < 1e-3 and e6 < 5e-5
+    pipe.close(); bs.close(); vs.close()
+
+
 def test_pipeline_tiny():
     """DeBERTa -> word2ph repeat -> VITS on the device equals predict + expand + synthesize through the host."""
     bc, bw = weights("bert", "tiny", 3)
