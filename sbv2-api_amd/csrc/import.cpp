@@ -629,9 +629,9 @@ void parse_sbv2file_bytes(const uint8_t* b, size_t n, std::vector<uint8_t>& stor
 
 // Whatever `load_model` may be handed -> named tensors.  want_kind: 1 = DeBERTa, 2 = VITS.
 Blob load_model_bytes(const uint8_t* b, size_t n, uint32_t want_kind) {
-    SBV2_REQUIRE(b && n >= 8, "model bytes are empty");
-    if (std::memcmp(b, "SBV2W001", 8) == 0) return parse_blob(b, n);
-    const bool zst = b[0] == 0x28 && b[1] == 0xB5 && b[2] == 0x2F && b[3] == 0xFD;
+    SBV2_REQUIRE(b && n >= 1, "model bytes are empty");
+    if (n >= 8 && std::memcmp(b, "SBV2W001", 8) == 0) return parse_blob(b, n);
+    const bool zst = n >= 4 && b[0] == 0x28 && b[1] == 0xB5 && b[2] == 0x2F && b[3] == 0xFD;
     if (zst || looks_like_tar(b, n)) {
         SBV2_REQUIRE(want_kind == 2, "a .sbv2 container holds a VITS model, not DeBERTa");
         std::vector<uint8_t> storage;
@@ -640,7 +640,7 @@ Blob load_model_bytes(const uint8_t* b, size_t n, uint32_t want_kind) {
         return import_vits_onnx(onnx.p, onnx.n);
     }
     // ONNX ModelProto: field 1 (ir_version, varint) comes first in every exporter's output
-    if (b[0] == 0x08) return want_kind == 1 ? import_bert_onnx(b, n) : import_vits_onnx(b, n);
+    if (n >= 16 && b[0] == 0x08) return want_kind == 1 ? import_bert_onnx(b, n) : import_vits_onnx(b, n);
     throw Error("model bytes are neither an SBV2W001 weight container, a .sbv2 (zstd + tar) file nor an ONNX ModelProto");
 }
 
