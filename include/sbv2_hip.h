@@ -199,12 +199,6 @@ int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, cons
  * when iters > 0 also returns the mean time of `iters` further launches in *ms. */
 int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k,
                          int64_t L, int64_t dilation, float pre_slope, int mode, int64_t iters, float* y, float* ms);
-/* Same convolution through the pre-split-operand kernel (conv_ps.hip): x is converted to an "A tensor" (leaky-ReLU pre_slope,
- * bf16 hi/lo split when split != 0) on the device, y is the raw result (+ x when residual != 0) and ya[Cout][L] the decoded
- * A tensor of lrelu(y, out_slope) that the kernel emits for the next convolution. */
-int sbv2_debug_conv1d_ps(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k,
-                         int64_t L, int64_t dilation, float pre_slope, float out_slope, int split, int residual, int64_t iters,
-                         float* y, float* ya, float* ms);
 /* The named-tensor table an import of `model` (ONNX / .sbv2 / container; kind 1 = DeBERTa, 2 = VITS) produces, written back as an SBV2W001
  * container (owned, sbv2_bytes_free): tests compare it with the container the same weights were packed into.  Host only. */
 int sbv2_debug_import_to_container(const uint8_t* model, size_t len, int kind, uint8_t** out, size_t* out_len);

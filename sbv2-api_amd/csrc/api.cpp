@@ -457,96 +457,6 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
     API_END
 }
 
-int sbv2_debug_conv1d_ps(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k, int64_t L,
-                         int64_t dilation, float pre_slope, float out_slope, int split, int residual, int64_t iters, float* y, float* ya,
-                         float* ms) {
-    API_BEGIN
-    HIP_CHECK(hipSetDevice(device));
-    SBV2_REQUIRE(!residual || cin == cout, "residual needs cin == cout");
-    const int parts = split ? 2 : 1;
-    Blob b = one_conv_blob(w, bias, {cout, cin, k}, cout);
-    WeightStore ws(b);
-    ClConv c = pack_cl(ws, w, (int)cout, (int)cin, (int)k, parts, bias);
-    std::vector<float> xt((size_t)L * cin), yt((size_t)L * cout);
-    for (int64_t ci = 0; ci < cin; ++ci)
-        for (int64_t n = 0; n < L; ++n) xt[(size_t)n * cin + ci] = x[(size_t)ci * L + n];
-    DevBuf dx(xt.size()), dy(yt.size());
-    HIP_CHECK(hipMemcpy(dx.p, xt.data(), sizeof(float) * xt.size(), hipMemcpyHostToDevice));
-    const size_t xa_bytes = PsTensor::bytes((int)cin, parts, L), ya_bytes = PsTensor::bytes((int)cout, parts, L);
-    DevBuf dxa(xa_bytes / 4), dya(ya_bytes / 4);
-    const int64_t plane = (int64_t)(PsTensor::kFront + L + PsTensor::kBack) * 32;
-    HIP_CHECK(hipMemset(dxa.p, 0xff, xa_bytes));   // poison: halos must be zeroed by ps_zero_halo, rows written by split_cl
-    HIP_CHECK(hipMemset(dya.p, 0xff, ya_bytes));
-    ps_zero_halo(dxa.p, (int)(cin / 16) * parts, plane, PsTensor::kFront, L, PsTensor::kBack, nullptr);
-    split_cl(dx.p, (int)cin, L, (int)cin, pre_slope, split, dxa.p, plane, PsTensor::kFront, nullptr);
-    ConvClParams p;
-    p.XA = dxa.p;
-    p.xa_plane = plane;
-    p.xa_front = PsTensor::kFront;
-    p.xa_back = PsTensor::kBack;
-    p.NB = (int)L;
-    p.W = c.w;
-    p.nmt = c.nmt;
-    p.tm = c.tm;
-    p.split = split;
-    p.M = (int)cout;
-    p.N = (int)L;
-    p.K = (int)cin;
-    p.ntaps = (int)k;
-    for (int j = 0; j < k; ++j) p.shift[j] = (int)(j * dilation - dilation * (k - 1) / 2);
-    p.Y = dy.p;
-    p.ldy = (int)cout;
-    p.bias = c.bias;
-    if (residual) {
-        p.R = dx.p;
-        p.ldr = (int)cin;
-    }
-    p.YA = dya.p;
-    p.ya_plane = plane;
-    p.ya_front = PsTensor::kFront;
-    p.out_slope = out_slope;
-    launch_conv_ps(p, nullptr);
-    HIP_CHECK(hipDeviceSynchronize());
-    if (iters > 0 && ms) {
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) launch_conv_ps(p, nullptr);
-        HIP_CHECK(hipEventRecord(e1, nullptr));
-        HIP_CHECK(hipEventSynchronize(e1));
-        float t = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
-        *ms = t / (float)iters;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-    }
-    HIP_CHECK(hipMemcpy(yt.data(), dy.p, sizeof(float) * yt.size(), hipMemcpyDeviceToHost));
-    for (int64_t co = 0; co < cout; ++co)
-        for (int64_t n = 0; n < L; ++n) y[(size_t)co * L + n] = yt[(size_t)n * cout + co];
-    if (ya) {
-        // decode the A tensor (undo the half swizzle, hi + lo) into ya[Cout][L]
-        std::vector<uint16_t> h(ya_bytes / 2);
-        HIP_CHECK(hipMemcpy(h.data(), dya.p, ya_bytes, hipMemcpyDeviceToHost));
-        auto bf = [](uint16_t v) {
-            uint32_t u = (uint32_t)v << 16;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
-        for (int64_t co = 0; co < cout; ++co)
-            for (int64_t n = 0; n < L; ++n) {
-                const int64_t prow = PsTensor::kFront + n;
-                const int half = (int)(((co >> 3) ^ (prow >> 3)) & 1);
-                const size_t e = (size_t)(co >> 4) * parts * (plane / 2) + (size_t)prow * 16 + half * 8 + (co & 7);
-                float v = bf(h[e]);
-                if (split) v += bf(h[e + plane / 2]);
-                ya[(size_t)co * L + n] = v;
-            }
-    }
-    API_END
-}
-
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters, float* ms) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));

@@ -165,6 +165,7 @@ BertModel::~BertModel() {
 void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens) {
     HIP_CHECK(hipSetDevice(device_));
     SBV2_REQUIRE(n >= 1, "empty batch");
+    TraceRange tr("deberta");
     HIP_CHECK(hipStreamSynchronize(stream_));  // pinned staging of the previous call must be drained before reuse
     arena_.reset();
     const int H = cfg_.hidden, nh = cfg_.heads, d = H / nh;

@@ -1,6 +1,8 @@
 // Arena, weight-blob parser, error plumbing (host only).
 #include "common.h"
 
+#include <dlfcn.h>
+
 #include <cstring>
 
 namespace sbv2 {
@@ -8,6 +10,41 @@ namespace sbv2 {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool enabled = false;
+    Roctx() {
+        const char* e = getenv("SBV2_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void* h = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        enabled = push && pop;
+    }
+};
+Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+TraceRange::TraceRange(const char* name) : on(roctx().enabled) {
+    if (on) roctx().push(name);
+}
+TraceRange::~TraceRange() {
+    if (on) roctx().pop();
+}
+void log_line(const std::string& msg) {
+    static const bool on = getenv("SBV2_LOG") && atoi(getenv("SBV2_LOG")) != 0;
+    if (on) fprintf(stderr, "[sbv2_hip] %s\n", msg.c_str());
+}
 
 size_t Arena::capacity() const {
     size_t t = 0;

@@ -31,6 +31,18 @@ struct Error : std::runtime_error {
         if (!(cond)) throw ::sbv2::Error(std::string(msg) + " [" #cond "]");             \
     } while (0)
 
+// rocTX ranges around the stages of a forward pass (tracing).  librocprofiler-sdk-roctx.so.1 is dlopen'ed on first use when
+// SBV2_ROCTX=1 (rocprofv3 --marker-trace then shows deberta / text_encoder / durations / flow / decoder / gather); otherwise a no-op.
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+    bool on;
+};
+// stderr logging behind SBV2_LOG=1 (the reference logs through env_logger / RUST_LOG: sbv2_api/src/main.rs:84,131-179)
+void log_line(const std::string& msg);
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -206,30 +218,8 @@ struct ConvClParams {
     int in_km = 0, out_km = 0;  // operand / result layout: 0 = channels-last [pos][C], 1 = k-major plane [C][ld]
     int act = ACT_NONE;         // k-major output only
     float alpha = 1.0f;         // k-major output only
-    // conv_ps.hip only: pre-split ("A tensor") operand and result, see PsTensor
-    const void* XA = nullptr;
-    int64_t xa_plane = 0;       // bytes per (chunk, part) plane
-    int xa_front = 0, xa_back = 0;
-    void* YA = nullptr;
-    int64_t ya_plane = 0;
-    int ya_front = 0;
-    float out_slope = 1.0f;     // leaky-ReLU applied to the result before it is split into YA
 };
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
-
-// A tensor of a channels-last plane x[rows][C] (conv_ps.hip): [C / 16][parts][front + rows + back][16 bf16] = activated, bf16 hi
-// (+ lo) split operand rows of 32 bytes with the ds_read_b128 bank swizzle applied and zero halo rows.  4 bytes per element.
-struct PsTensor {
-    void* p = nullptr;
-    int C = 0, parts = 2;
-    int64_t rows = 0;
-    int64_t plane = 0;   // bytes per (chunk, part) plane
-    static constexpr int kFront = 64, kBack = 448;
-    static size_t bytes(int C, int parts, int64_t rows) { return (size_t)(C / 16) * parts * (size_t)(kFront + rows + kBack) * 32; }
-};
-void launch_conv_ps(const ConvClParams& p, hipStream_t stream);
-void split_cl(const float* X, int ldx, int64_t N, int C, float slope, int split, void* A, int64_t plane, int front, hipStream_t stream);
-void ps_zero_halo(void* A, int nplanes, int64_t plane, int front, int64_t rows, int back, hipStream_t stream);
 
 // One fused ResBlock1 step y' = beta * (conv2(lrelu(conv1(lrelu(y), dil) + b1)) + b2 + y) on a channels-last plane (respair_cl.hip)
 struct ResPairParams {

@@ -218,6 +218,7 @@ int sbv2_comm_gather_pcm(sbv2_comm* c, sbv2_pipeline* p, int64_t ticket, int roo
     SBV2_REQUIRE(c->rank != root || dst_host, "the root needs a destination buffer");
     VitsModel& vm = p->vm(p->ctx_of(ticket));
     SBV2_REQUIRE(vm.device() == c->device, "pipeline and communicator live on different devices");
+    TraceRange tr("gather_pcm");
     HIP_CHECK(hipSetDevice(c->device));
     Rccl& R = rccl();
     // the gather stream waits for the run's kernels (event, not a host wait)

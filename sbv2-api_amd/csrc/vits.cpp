@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 
 #include "models.h"
 
@@ -551,6 +552,7 @@ void VitsModel::forward(const VitsBatch& b) {
     for (auto& c : flows_) v_flow.push_back(gvec(c.enc.spk_w, c.enc.spk_b, H));
 
     // ---- TextEncoder ----------------------------------------------------------------------------------
+    std::unique_ptr<TraceRange> tr(new TraceRange("text_encoder"));
     Plane BP = ar.plane(H, Lt);
     conv_plain(bert_proj_, bert, BP, 1, 0, nullptr, 1, stream_);
     Plane X = ar.plane(H, Lt);
@@ -564,6 +566,8 @@ void VitsModel::forward(const VitsBatch& b) {
     trace("stats", ST, tl);
 
     // ---- DurationPredictor -----------------------------------------------------------------------------
+    tr.reset();
+    tr.reset(new TraceRange("durations"));
     Plane XD = ar.plane(H, Lt);
     HIP_CHECK(hipMemcpyAsync(XD.p, X.p, sizeof(float) * (size_t)H * X.ld, hipMemcpyDeviceToDevice, stream_));
     add_segvec(XD, v_dp, H, tl.d_seg_of, 1, tl.d_mask, stream_);
@@ -639,6 +643,8 @@ void VitsModel::forward(const VitsBatch& b) {
     ar.upload(d_tok, tok.data(), sizeof(int) * Lf, stream_);
 
     // ---- alignment expansion + prior sample ---------------------------------------------------------------
+    tr.reset();
+    tr.reset(new TraceRange("flow"));
     Plane ZA = ar.plane(I, Lf), ZB = ar.plane(I, Lf);
     expand_frames(m_p, logs_p, d_tok, fl.d_seg_of, fl.d_start, fl.d_len, d_uid, seed, b.noise_scale, ZA, stream_);
     trace("z_p", ZA, fl);
@@ -656,6 +662,7 @@ void VitsModel::forward(const VitsBatch& b) {
         conv_plain(c.post, Hf, x1, 1, 0, fl.d_mask, 1, stream_, ACT_NONE, 1.0f, &x1, -1.0f);  // x1 = (x1 - m) * mask
     }
     trace("z", ZA, fl);
+    tr.reset();
     z_ = ZA;
     if (b.skip_decoder) {   // streaming: the caller decodes chunk by chunk (stream_begin / stream_chunk)
         pcm_ = nullptr;
@@ -664,8 +671,10 @@ void VitsModel::forward(const VitsBatch& b) {
         pcm_offs_.assign(n, 0);
         return;
     }
+    TraceRange td("decoder");
     if (dec_mode_) run_decoder_cl(ar, ZA, fl, dec_cond_vec_);
     else run_decoder(ar, ZA, fl, dec_cond_vec_);
+    log_line("vits forward: " + std::to_string(n) + " utterance(s), " + std::to_string(Lt) + " text columns, " + std::to_string(Lf) + " frame columns");
 }
 
 // ---- streaming long-form decode ---------------------------------------------------------------------------------------------------

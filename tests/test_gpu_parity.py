@@ -84,29 +84,6 @@ def test_conv1d_cl_kernel(cin, cout, k, dil, L):
     np.testing.assert_allclose(got, ref, atol=4e-3, rtol=0)
 
 
-@pytest.mark.parametrize("cin,cout,k,dil,L,res", [(64, 64, 3, 1, 777, 1), (128, 128, 11, 1, 1030, 0), (256, 256, 7, 5, 515, 1),
-                                                  (64, 128, 7, 3, 2100, 0), (512, 64, 1, 1, 300, 0), (128, 128, 11, 5, 9, 1),
-                                                  (64, 64, 5, 1, 256, 1)])
-def test_conv1d_ps_kernel(cin, cout, k, dil, L, res):
-    """Pre-split-operand kernel (LDS-DMA staging): raw result f32-grade in split mode and bit-identical to conv_cl (same products
-    in the same order); the emitted A tensor decodes to lrelu(result) within the hi+lo representation (2^-16 relative)."""
-    rng = np.random.default_rng(cin * 1000 + cout + k)
-    x = rng.standard_normal((cin, L)).astype(np.float32)
-    w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
-    b = rng.standard_normal(cout).astype(np.float32)
-    ref = O.conv1d_same(O.leaky_relu(x, 0.1), w, b, dil) + (x if res else 0.0)
-    P = lambda a: a.ctypes.data_as(f32p)
-    for split, atol, ya_rtol in ((1, 5e-5, 2.0 ** -15), (0, 3e-2, 2.0 ** -7)):
-        y = np.empty((cout, L), np.float32)
-        ya = np.empty((cout, L), np.float32)
-        ms = np.zeros(1, np.float32)
-        _lib.check(_lib.lib().sbv2_debug_conv1d_ps(0, P(x), P(w), P(b), cin, cout, k, L, dil, 0.1, 0.1, split, res, 0, P(y), P(ya), P(ms)))
-        np.testing.assert_allclose(y, ref, atol=atol, rtol=1e-5)
-        np.testing.assert_allclose(ya, O.leaky_relu(y, 0.1), atol=1e-30, rtol=ya_rtol)
-        if not res:
-            np.testing.assert_array_equal(y, _conv_cl_dev(x, w, b, dil, 0.1, 1 if split else 2))
-
-
 def _golden(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name))
     return z, ast.literal_eval(str(z["cfg"]))
