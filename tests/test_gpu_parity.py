@@ -460,25 +460,14 @@ def test_node_shards_equal_single_gpu_call():
 
 def test_comm_world1_gather_through_rccl():
     """The one-process-per-GPU communicator with world size 1 on the box's GPU: RCCL is dlopen'ed, ncclCommInitRank / all-reduce / all-gather
-    run for real, and the gather returns the run's PCM (by ticket) with the count table."""
-    bc, bw = weights("bert", "tiny", 3)
-    vc, vw = weights("vits", "tiny", 5)
-    bs, vs = model.load_model(blob("bert", "tiny", 3), True), model.load_model(blob("vits", "tiny", 5), False)
-    pipe = model.Pipeline(bs, vs)
-    comm = model.Comm(model.Comm.unique_id(), 0, 1, 0)
-    assert comm.max(3.5) == 3.5
-    comm.barrier()
-    utts = make_utts([7, 15, 4], bc, vc, seed0=161, with_bert=False)
-    b = pipe.prepare(utts, forced=True)
-    pipe.run(b)
-    ref = np.concatenate(pipe.fetch(b))
-    pin = model.PinnedArray(ref.size)
-    counts = comm.gather_pcm(pipe, b.ticket, pin.array)
-    assert counts.tolist() == [ref.size]
-    np.testing.assert_array_equal(pin.array, ref)
-    with pytest.raises(model.Sbv2Error, match="too small"):
-        comm.gather_pcm(pipe, b.ticket, np.empty(5, np.float32))
-    pin.close(); comm.close(); pipe.close(); bs.close(); vs.close()
+    run for real, and the gather returns the run's PCM (by ticket) with the count table.  Runs in a FRESH interpreter (tests/rccl_world1_check.py):
+    this pytest process has usually imported torch by now (the oracle's conv backend), whose bundled ROCm runtime libraries make the system
+    RCCL fail to find the GPU when it is loaded afterwards; the product (bench.py, a server) never has torch in the process."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "rccl_world1_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_config3_b256_mixed_lengths_sharded_8_ways():
