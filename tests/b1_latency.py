@@ -1,0 +1,20 @@
+"""Builder tool (GPU box): batch-1 latency of one 128-phoneme utterance (BASELINE configs[1] shape), un-pipelined: wall per call."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from sbv2_api_amd import _lib, configs, model, synth
+bc, vc = configs.DEBERTA_FULL, configs.VITS_FULL
+bs = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, synth.make_deberta_weights(bc)), True)
+vs = model.load_model(synth.pack_blob(synth.KIND_VITS, vc, synth.make_vits_weights(vc)), False)
+u = synth.make_utterance(128, bc, vc, seed=1)
+pipe = model.Pipeline(bs, vs)
+b = pipe.prepare([u], forced=True)
+pin = model.PinnedArray(897 * 512)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+for _ in range(5):
+    pipe.run(b); pipe.fetch(b, out=pin.array)
+ts = []
+for _ in range(n):
+    a = time.perf_counter(); pipe.run(b); pipe.fetch(b, out=pin.array); ts.append(time.perf_counter() - a)
+print(f"B=1 U128: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms per call (10.414 s audio)", flush=True)
