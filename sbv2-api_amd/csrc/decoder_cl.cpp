@@ -234,8 +234,9 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                 const int d = rb.dil[q];
                 const bool last = q + 1 == nd;
                 float* yn = last ? XS : ((y == YA) ? YB : YA);
-                if (fuse_pairs_ && C <= 32 && (U & (U - 1)) == 0) {
-                    // narrow stages are HBM bound: conv1 -> conv2 fused, the intermediate stays in LDS (respair_cl.hip)
+                static const int fuse_max_c = getenv("SBV2_FUSE_PAIRS_MAXC") ? atoi(getenv("SBV2_FUSE_PAIRS_MAXC")) : 64;   // A/B knob
+                if (fuse_pairs_ && C <= fuse_max_c && C <= 64 && (U & (U - 1)) == 0) {
+                    // stages of <= 64 channels are HBM bound: conv1 -> conv2 fused, the intermediate stays in LDS (respair_cl.hip)
                     ResPairParams rp;
                     rp.X = y;
                     rp.Y = yn;

@@ -388,7 +388,7 @@ const char* kCfgNames[] = {"conv_gemm<16,1,4,1,4,16>", "conv_gemm<32,1,2,1,4,16>
                            "conv_gemm<32,2,2,2,2,16>", "conv_gemm<32,2,2,1,4,16>", "conv_gemm<32,1,2,2,2,16>", "conv_gemm<32,1,1,2,2,16>",
                            "conv_cl<2,split-bf16>",    "conv_cl<1,split-bf16>",    "conv_cl<2,bf16>",          "conv_cl<1,bf16>",
                            "conv_cl_km<2,split-bf16>", "conv_cl_km<1,split-bf16>", "conv_cl_km<2,bf16>",       "conv_cl_km<1,bf16>",
-                           "respair_cl",               "conv_ps<split-bf16>",      "conv_ps<bf16>",
+                           "respair_cl<C<=32>",        "respair_cl<C=64>",         "resblock_cl",
                            "conv_cl<2,f16>",           "conv_cl<1,f16>",           "conv_cl_km<2,f16>",        "conv_cl_km<1,f16>"};
 constexpr int kNumCfg = 23;
 constexpr int cfg_id(int MF, int TM, int TN, int WM) {

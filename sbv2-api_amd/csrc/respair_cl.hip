@@ -1,4 +1,4 @@
-// One HiFi-GAN ResBlock1 step fused into one launch for the narrow decoder stages (C <= 32 channels, channels-last planes):
+// One HiFi-GAN ResBlock1 step fused into one launch for the decoder stages with C <= 64 channels (channels-last planes):
 //
 //     y' = beta * ( conv2( lrelu( conv1( lrelu(y), dilation d ) + b1 ) ) + b2 + y )  [+ previous contents]  (then column mask)
 //
@@ -37,22 +37,25 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
     }
 }
 
-template <int PREC, bool PERSIST>
-__global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERSIST ? 1 : 3))) void respair_cl_kernel(const ResPairParams p) {
+// WM = 32-row tiles of the output channels, one group of four waves each: 1 for C = 16 / 32 (256 threads), 2 for C = 64 (512 threads: the
+// 134 KB of LDS at k = 11 allow one workgroup per CU, so the second wave per SIMD has to come from inside the workgroup)
+template <int PREC, bool PERSIST, int WM>
+__global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu(PERSIST ? 1 : (WM > 1 ? 2 : 3)))) void respair_cl_kernel(const ResPairParams p) {
+    constexpr int T = kRpThreads * WM;
     constexpr bool SPLIT = PREC == PREC_BF16X3;
     using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
     using ex8 = std::conditional_t<PREC == PREC_F16, f16x8, bf16x8>;
     using ex4 = std::conditional_t<PREC == PREC_F16, f16x4, bf16x4>;
     constexpr int PARTS = SPLIT ? 2 : 1;
     constexpr int TN = 2;
-    constexpr int MAXW = (kMaxTaps * PARTS * 64 + kRpThreads - 1) / kRpThreads;
-    constexpr int NX = ((kRpNT + 64) * 4 + kRpThreads - 1) / kRpThreads;
+    constexpr int MAXW = (kMaxTaps * WM * PARTS * 64 + T - 1) / T;
+    constexpr int NX = ((kRpNT + 64) * 4 + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntaps = p.k, C = p.C, nchunks = C >> 4;
-    const int lc = C == 32 ? 5 : 4;   // C is 16 or 32: row addressing by shift (a 64-bit multiply is a quarter-rate VALU op)
+    const int lc = C == 64 ? 6 : (C == 32 ? 5 : 4);   // C is 16, 32 or 64: row addressing by shift (a 64-bit multiply is a quarter-rate VALU op)
     const int h2 = (p.k - 1) / 2, h1 = p.dil * (p.k - 1) / 2;
     const int rows1 = kRpNT + 2 * h1;
-    const int wbytes = ntaps * PARTS * 1024;
+    const int wbytes = ntaps * WM * PARTS * 1024;
     char* wsm = smem;
     char* x1_hi = smem + wbytes;
     char* x1_lo = x1_hi + rows1 * 32;
@@ -62,19 +65,20 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
     // global round trips (~0.7-1 us each on a ~12 us workgroup in the clock-stamp timeline).  Placed behind everything the epilogue's
     // transpose tiles overlay.
     const int main_bytes = wbytes + rows1 * 32 * PARTS + nchunks * kRpWin2Rows * 32 * PARTS;
-    float* bias_s = reinterpret_cast<float*>(smem + max(main_bytes, 4 * 64 * 36 * 4));   // [0, 32): b1, [32, 64): b2
-    unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 64);                  // [kRpWin2Rows + 16]: rows of the intermediate
+    float* bias_s = reinterpret_cast<float*>(smem + max(main_bytes, WM * 4 * 64 * 36 * 4));   // [0, 64): b1, [64, 128): b2
+    unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 128);                      // [kRpWin2Rows + 16]: rows of the intermediate
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lh = lane >> 5;
-    const int wn0 = wave * 64;
+    const int wm = WM > 1 ? wave >> 2 : 0;     // this wave's 32-row tile of the output channels
+    const int wn0 = (wave & 3) * 64;           // ... and its 64 positions
     const int nto = kRpNT - 2 * h2;                 // outputs per workgroup
     const int ntiles = (p.N + nto - 1) / nto;
     int n0 = blockIdx.x * nto;                      // first output position (persistent: tile += gridDim.x)
     int t0 = n0 - h2;                               // first position of the intermediate
     int wstart = t0 - h1;                           // first row of the conv1 window
     const int NB = p.N;
-    const int nwf4 = ntaps * PARTS * 64;
+    const int nwf4 = ntaps * WM * PARTS * 64;
     const int nxf4 = rows1 * 4;
 
     f32x16 acc[TN];
@@ -89,26 +93,26 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
     f32x4v rw[MAXW];
     f32x4v rx[NX], rx1[NX];
     auto load_w = [&](const void* W, int chunk) {
-        const f32x4v* src = reinterpret_cast<const f32x4v*>(W) + (int64_t)chunk * ntaps * PARTS * 64;   // nmt == 1
+        const f32x4v* src = reinterpret_cast<const f32x4v*>(W) + (int64_t)chunk * ntaps * WM * PARTS * 64;   // nmt == WM
         rp_static_for<0, MAXW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            rw[i] = src[min(tid + i * kRpThreads, nwf4 - 1)];
+            rw[i] = src[min(tid + i * T, nwf4 - 1)];
         });
     };
     auto store_w = [&]() {
         rp_static_for<0, MAXW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const int idx = tid + i * kRpThreads;
+            const int idx = tid + i * T;
             if (idx < nwf4) reinterpret_cast<f32x4v*>(wsm)[idx] = rw[i];
         });
     };
-    // both 16-channel chunks of the conv1 window are requested at once (one 128-byte line per position when C == 32)
-    auto load_x = [&]() {
+    // both 16-channel chunks of a 32-channel group of the conv1 window are requested at once (one 128-byte line per position)
+    auto load_x = [&](int pair) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = min(tid + i * kRpThreads, nxf4 - 1);
+            const int idx = min(tid + i * T, nxf4 - 1);
             const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
-            const float* src = p.X + ((int64_t)pos << lc) + (idx & 3) * 4;
+            const float* src = p.X + ((int64_t)pos << lc) + (WM == 1 ? 0 : pair * 32) + (idx & 3) * 4;
             rx[i] = *reinterpret_cast<const f32x4v*>(src);
             rx1[i] = *reinterpret_cast<const f32x4v*>(nchunks > 1 ? src + 16 : src);
         }
@@ -116,11 +120,11 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
     auto store_x = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * kRpThreads;
+            const int idx = tid + i * T;
             if (idx < nxf4) {
                 const int row = idx >> 2, q = idx & 3;
                 const int pos = wstart + row;
-                f32x4v v = chunk ? rx1[i] : rx[i];
+                f32x4v v = (chunk & 1) ? rx1[i] : rx[i];
                 if (pos < 0 || pos >= NB) v = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.slope);   // leaky ReLU for 0 <= slope <= 1
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
                 f.bh[j] = *reinterpret_cast<const ex8*>(bhi + off);
                 if (SPLIT) f.bl[j] = *reinterpret_cast<const ex8*>(blo + off);
             }
-            const char* blk = wsm + (tap * PARTS) * 1024 + lane * 16;
+            const char* blk = wsm + ((wm * ntaps + tap) * PARTS) * 1024 + lane * 16;
             f.ah = *reinterpret_cast<const ex8*>(blk);
             if (SPLIT) f.al = *reinterpret_cast<const ex8*>(blk + 1024);
         };
@@ -180,27 +184,30 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
 
     // ---- phase 1: t = lrelu(conv1(lrelu(y)) + b1) on positions [t0, t0 + 256) -> LDS ----------------------------------------
     load_w(p.W1, 0);
-    load_x();
+    load_x(0);
   for (int tile = blockIdx.x;; tile += gridDim.x) {
     const bool next_tile = PERSIST && tile + (int)gridDim.x < ntiles;
     {
-        const float bval = tid < 64 ? (tid < 32 ? p.b1[min(tid, C - 1)] : p.b2[min(tid - 32, C - 1)]) : 0.f;
-        unsigned char mval[2];
+        const float bval = tid < 128 ? (tid < 64 ? p.b1[min(tid, C - 1)] : p.b2[min(tid - 64, C - 1)]) : 0.f;
+        constexpr int NMV = (kRpWin2Rows + 16 + T - 1) / T;
+        unsigned char mval[NMV];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int pos = min(max(t0 + tid + h * kRpThreads, 0), NB - 1);
+        for (int h = 0; h < NMV; ++h) {
+            const int pos = min(max(t0 + tid + h * T, 0), NB - 1);
             mval[h] = p.mask ? p.mask[pos >> p.mask_shift] : (unsigned char)1;
         }
         store_w();
         store_x(0);
-        if (tid < 64) bias_s[tid] = bval;
-        mask_s[tid] = mval[0];
-        if (tid < kRpWin2Rows + 16 - kRpThreads) mask_s[tid + kRpThreads] = mval[1];
+        if (tid < 128) bias_s[tid] = bval;
+#pragma unroll
+        for (int h = 0; h < NMV; ++h)
+            if (tid + h * T < kRpWin2Rows + 16) mask_s[tid + h * T] = mval[h];
     }
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
         load_w(more ? p.W1 : p.W2, more ? chunk + 1 : 0);   // the next weights: conv1's next chunk, then conv2's first
+        if (WM > 1 && (chunk & 1) && more) load_x((chunk + 1) >> 1);   // C = 64: the second 32-channel group (its registers are free now)
         mfma_chunk(x1_hi, x1_lo, p.dil);
         __syncthreads();
         if (more) {
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int co = 8 * q + 4 * lh;
+            const int co = wm * 32 + 8 * q + 4 * lh;
             if (co >= C) continue;
             const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bias_s + co);
 #pragma unroll
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
         n0 += gridDim.x * nto;
         t0 = n0 - h2;
         wstart = t0 - h1;
-        load_x();
+        load_x(0);
     }
     __syncthreads();
 
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
     // for the conv1 window a moment ago, so these are L2 hits, but still a dependent ~1 us round trip if left to the epilogue
     f32x4v rres[8];
     {
-        const int c4r = min((lane & 7) * 4, C - 4);
+        const int c4r = min(wm * 32 + (lane & 7) * 4, C - 4);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int64_t posr = min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
@@ -292,8 +299,8 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
             f32x4v v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
             *reinterpret_cast<f32x4v*>(ttile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
         }
-    const int c4 = (lane & 7) * 4;
-    const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bias_s + 32 + c4);   // (channels >= C are discarded below)
+    const int c4 = wm * 32 + (lane & 7) * 4;
+    const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bias_s + 64 + c4);   // (channels >= C are discarded below)
     // accumulate: all eight rows' previous contents are requested back to back (read inside the row loop, each load waited behind the
     // previous row's store: 8-9 us of epilogue instead of 3 in the clock-stamp timeline of this kernel)
     f32x4v rold[8];
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
         const int row = it * 8 + (lane >> 3);
         const int o = wn0 + row;          // output index inside the workgroup's range
         const int pos = n0_cur + o;                 // < 2^31 (checked by the caller)
-        const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * 36 + c4);
+        const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * 36 + (lane & 7) * 4);
         if (o >= nto || pos >= NB || c4 >= C) continue;
         const f32x4v r = rres[it];
         f32x4v v;
@@ -330,17 +337,18 @@ __global__ __launch_bounds__(kRpThreads) __attribute__((amdgpu_waves_per_eu(PERS
   }
 }
 
-template <int PREC, bool PERSIST>
+template <int PREC, bool PERSIST, int WM>
 static void launch_rp(const ResPairParams& p, hipStream_t stream) {
+    constexpr int T = kRpThreads * WM;
     constexpr int PARTS = PREC == PREC_BF16X3 ? 2 : 1;
     const int h1 = p.dil * (p.k - 1) / 2, h2 = (p.k - 1) / 2;
     const int rows1 = kRpNT + 2 * h1;
-    size_t lds = (size_t)p.k * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
-    lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));
-    lds += 64 * sizeof(float) + kRpWin2Rows + 16;   // biases + mask bytes (kernel: bias_s, mask_s)
+    size_t lds = (size_t)p.k * WM * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
+    lds = std::max<size_t>(lds, (size_t)WM * 4 * 64 * 36 * sizeof(float));
+    lds += 128 * sizeof(float) + kRpWin2Rows + 16;   // biases + mask bytes (kernel: bias_s, mask_s)
     lds = (lds + 15) / 16 * 16;
     SBV2_REQUIRE(lds <= 160 * 1024, "respair: LDS budget exceeded");
-    auto kern = respair_cl_kernel<PREC, PERSIST>;
+    auto kern = respair_cl_kernel<PREC, PERSIST, WM>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -348,7 +356,7 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     }
     const int nto = kRpNT - 2 * h2;
     int per_cu = 1;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kRpThreads, lds));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), T, lds));
     per_cu = std::max(1, std::min(per_cu, 4));
     const int ntiles = (p.N + nto - 1) / nto;
     dim3 grid(PERSIST ? std::min(ntiles, 256 * per_cu) : ntiles);
@@ -359,11 +367,11 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(kern, grid, dim3(kRpThreads), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(T), lds, stream, p);
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(16, 2.0 * 2.0 * p.C * (double)p.N * p.C * p.k, e0, e1);
+        conv_prof_add(WM > 1 ? 17 : 16, 2.0 * 2.0 * p.C * (double)p.N * p.C * p.k, e0, e1);
     }
 }
 
@@ -374,19 +382,23 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(!p.mask || (p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0), "respair: mask_div must be a power of two");
     p.mask_shift = 0;
     while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
-    SBV2_REQUIRE(p.C == 16 || p.C == 32, "respair: only the 16- and 32-channel stages are fused");
+    SBV2_REQUIRE(p.C == 16 || p.C == 32 || p.C == 64, "respair: only the 16-, 32- and 64-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
     if (p.N <= 0) return;
     static const int persist = getenv("SBV2_RESPAIR_PERSIST") ? atoi(getenv("SBV2_RESPAIR_PERSIST")) : 0;
     SBV2_REQUIRE(!(p.split && p.f16), "respair: split and f16 are exclusive");
-    if (p.split) {
-        if (persist) launch_rp<PREC_BF16X3, true>(p, stream);
-        else launch_rp<PREC_BF16X3, false>(p, stream);
+    if (p.C == 64) {
+        if (p.split) launch_rp<PREC_BF16X3, false, 2>(p, stream);
+        else if (p.f16) launch_rp<PREC_F16, false, 2>(p, stream);
+        else launch_rp<PREC_BF16, false, 2>(p, stream);
+    } else if (p.split) {
+        if (persist) launch_rp<PREC_BF16X3, true, 1>(p, stream);
+        else launch_rp<PREC_BF16X3, false, 1>(p, stream);
     } else if (p.f16) {
-        launch_rp<PREC_F16, false>(p, stream);
+        launch_rp<PREC_F16, false, 1>(p, stream);
     } else {
-        launch_rp<PREC_BF16, false>(p, stream);
+        launch_rp<PREC_BF16, false, 1>(p, stream);
     }
 }
 
