@@ -175,3 +175,92 @@ def test_cpp_host_mirror_builds_and_reports_errors(tmp_path):
         subprocess.run(["make", "-C", os.path.join(ROOT, "sbv2-api_amd", "csrc")], check=True, capture_output=True)
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "cannot open" in r.stderr, (r.returncode, r.stderr)
+
+
+class _FakeSession:
+    live = 0
+
+    def __init__(self, data, is_bert):
+        self.data, self.is_bert, self.closed = data, is_bert, False
+        _FakeSession.live += 0 if is_bert else 1
+
+    def close(self):
+        if not self.closed and not self.is_bert:
+            _FakeSession.live -= 1
+        self.closed = True
+
+
+class _FakePipe:
+    def __init__(self, bert, vits):
+        self.vits = vits
+
+    def close(self):
+        pass
+
+
+def _holder(max_loaded):
+    from sbv2_api_amd import holder
+    _FakeSession.live = 0
+    return holder.TTSModelHolder(b"bert", max_loaded_models=max_loaded, load_session=_FakeSession, make_pipeline=_FakePipe)
+
+
+def _style(n=2, dim=4):
+    import json
+    return json.dumps({"shape": [n, dim], "data": [[float(i + j) for j in range(dim)] for i in range(n)]}).encode()
+
+
+def test_model_holder_cache_semantics():
+    """tts.rs:149-258 mirrored: duplicate idents ignored, sessions created only below max_loaded_models, raw bytes kept iff the limit is set,
+    unload removes the entry, a non-resident model is rebuilt on demand and, when the cache is full, the FIRST entry of the list is dropped
+    from the holder (the reference's behaviour, not an LRU).  'Resident' here = weights in HBM (fake sessions count themselves)."""
+    from sbv2_api_amd import holder
+    h = _holder(None)
+    h.load("a", _style(), b"A"); h.load("b", _style(), b"B"); h.load("a", _style(), b"A2")
+    assert h.models() == ["a", "b"] and _FakeSession.live == 2 and all(m.bytes is None for m in h.models_)
+    assert h.unload("a") and not h.unload("a") and h.models() == ["b"] and _FakeSession.live == 1
+    with pytest.raises(holder.ModelNotFoundError):
+        h.find_and_load_model("zzz")
+    h = _holder(2)
+    for k in "abc":
+        h.load(k, _style(), k.encode())
+    assert h.models() == ["a", "b", "c"] and [m.vits2 is not None for m in h.models_] == [True, True, False] and _FakeSession.live == 2
+    assert all(m.bytes is not None for m in h.models_)
+    assert h.find_and_load_model("a") and h.models() == ["a", "b", "c"]          # already resident: nothing moves
+    assert h.find_and_load_model("c")
+    # c was rebuilt from its kept bytes; the cache was full, so the first entry ("a") left the holder altogether
+    assert h.models() == ["b", "c"] and _FakeSession.live == 2 and h._find("c").vits2.data == b"c"
+    np.testing.assert_array_equal(h.get_style_vector("b", 1, 0.5), np.array([0.5, 1.5, 2.5, 3.5], np.float32))
+    h.close()
+    assert _FakeSession.live == 0
+
+
+def test_rest_contract():
+    """main.rs:24-100,192-196 + error.rs:10-18: routes, JSON defaults, audio/wav, 'Something went wrong: ...' with status 500."""
+    from fastapi.testclient import TestClient
+    from sbv2_api_amd import orchestrator, rest
+
+    class H:
+        def __init__(self):
+            self.calls = []
+
+        def models(self):
+            return ["tsukuyomi"]
+
+        def easy_synthesize(self, ident, text, style_id, speaker_id, options):
+            if ident != "tsukuyomi":
+                raise RuntimeError(f"model not found: {ident}")
+            self.calls.append((text, style_id, speaker_id, options.sdp_ratio, options.length_scale))
+            return orchestrator.array_to_wav(np.zeros((1, 1, 10), np.float32))
+
+    h = H()
+    c = TestClient(rest.make_app(h), raise_server_exceptions=False)
+    assert c.get("/").text == "Hello, World!"
+    assert c.get("/models").json() == ["tsukuyomi"]
+    r = c.post("/synthesize", json={"text": "こんにちは", "ident": "tsukuyomi"})
+    assert r.status_code == 200 and r.headers["content-type"] == "audio/wav" and r.content[:4] == b"RIFF" and len(r.content) == 68 + 40
+    assert h.calls[-1] == ("こんにちは", 0, 0, 0.0, 1.0)                              # the reference's serde defaults
+    c.post("/synthesize", json={"text": "a\nb", "ident": "tsukuyomi", "sdp_ratio": 0.4, "length_scale": 1.2, "style_id": 3, "speaker_id": 1})
+    assert h.calls[-1] == ("a\nb", 3, 1, 0.4, 1.2)
+    r = c.post("/synthesize", json={"text": "x", "ident": "nope"})
+    assert r.status_code == 500 and r.text == "Something went wrong: model not found: nope"
+    assert c.post("/synthesize", json={"ident": "tsukuyomi"}).status_code == 422        # missing field (axum answers 422 as well)

@@ -127,3 +127,60 @@ def test_imported_models_synthesise_identically():
         pipe.close(); bs.close(); vs.close()
     for a, b2 in zip(*outs):
         np.testing.assert_array_equal(a, b2)
+
+
+@pytest.mark.gpu
+def test_model_holder_on_gpu_with_sbv2_files_and_eviction():
+    """TTSModelHolder (tts.rs:40-349 mirror) over real GPU sessions: two synthetic .sbv2 voices, max_loaded_models = 1: a request for the
+    non-resident voice rebuilds it from the kept bytes and evicts per the reference's rule; the WAV equals the direct pipeline call's."""
+    import io
+    from scipy.io import wavfile
+    from sbv2_api_amd import holder, orchestrator
+    bc, vc = dict(O.DEBERTA_TINY_CONV, heads=1), O.VITS_TINY
+    bw = synth.make_deberta_weights(bc, 3)
+    sv = np.random.default_rng(2).standard_normal((2, vc["style_dim"])).astype(np.float32) * 0.1
+    voices = {name: (OW.sbv2_file(OW.vits_onnx(synth.make_vits_weights(vc, seed), vc, folded=True), OW.style_json(sv)), seed)
+              for name, seed in (("a", 5), ("b", 6), ("c", 7))}
+    h = holder.TTSModelHolder(OW.deberta_onnx(bw, bc), max_loaded_models=1)
+    for name, (f, _) in voices.items():
+        h.load_sbv2file(name, f)
+    assert h.models() == ["a", "b", "c"] and [m.vits2 is not None for m in h.models_] == [True, False, False]
+    u = synth.make_utterance(7, bc, vc, seed=3)
+    sent = {k: u[k] for k in ("input_ids", "word2ph", "phones", "tones", "langs")}
+    opts = orchestrator.SynthesizeOptions()
+    wav_b = h.easy_synthesize("b", [sent], 1, 0, opts, noise_seed=4)
+    assert h.models() == ["b", "c"]                      # "a" (the first entry) was dropped to make room, as in the reference
+    wav_c = h.easy_synthesize("c", [sent], 1, 0, opts, noise_seed=4)
+    assert h.models() == ["c"]
+    # reference result for voice c through plain sessions
+    bs = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, bw), True)
+    vs = model.load_model(synth.pack_blob(synth.KIND_VITS, vc, synth.make_vits_weights(vc, 7)), False)
+    pipe = model.Pipeline(bs, vs)
+    want = orchestrator.easy_synthesize(pipe, [sent], sv, 1, 0, opts, noise_seed=4)
+    assert wav_c == want and wav_b != wav_c
+    assert wavfile.read(io.BytesIO(wav_c))[0] == 44100
+    with pytest.raises(holder.ModelNotFoundError):
+        h.easy_synthesize("a", [sent])
+    pipe.close(); bs.close(); vs.close(); h.close()
+
+
+def test_host_parsers_under_asan_ubsan(tmp_path):
+    """the host code that parses untrusted bytes (SBV2W001 container, ONNX protobuf, tar, zstd, style JSON) built with
+    g++ -fsanitize=address,undefined (`make -C sbv2-api_amd/csrc asan`; CPU only, no device code) and driven over the valid files plus
+    ~800 mutations of each (truncations, bit flips, overwritten length fields, splices): every input is either parsed or rejected with
+    an Error, never a sanitizer report."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "sbv2-api_amd", "csrc"), "asan"], check=True, capture_output=True)
+    cfg, bc = O.VITS_TINY, O.DEBERTA_TINY_CONV
+    W, BW = synth.make_vits_weights(cfg, 5), synth.make_deberta_weights(bc, 3)
+    sv = np.random.default_rng(1).standard_normal((3, cfg["style_dim"])).astype(np.float32)
+    onnx = OW.vits_onnx(W, cfg, folded=False)
+    files = {"container.bin": synth.pack_blob(synth.KIND_VITS, cfg, W), "vits.onnx": OW.vits_onnx(W, cfg, folded=True),
+             "bert.onnx": OW.deberta_onnx(BW, bc), "model.sbv2": OW.sbv2_file(onnx, OW.style_json(sv)), "style.json": OW.style_json(sv)}
+    for name, data in files.items():
+        open(os.path.join(tmp_path, name), "wb").write(data)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "host_asan"), str(tmp_path), "800"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "HOST_ASAN_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
