@@ -169,9 +169,15 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     }
     ws_.reset(new WeightStore(blob, gemm_parts));
     WeightStore& w = *ws_;
-    // The text side decides the INTEGER durations (ceil(exp(logw) * length_scale)): text encoder and both duration predictors always
-    // run on the exact-f32 kernels, whatever SBV2_GEMM says; a 1e-5 relative error there flips ~1 duration per 10^4 symbols.
-    w.set_cl_parts(0);
+    // The text side decides the INTEGER durations (ceil(exp(logw) * length_scale)): text encoder and both duration predictors run on
+    // the exact-f32 kernels whatever SBV2_GEMM says.  SBV2_TEXT_GEMM=bf16x3 puts their k = 3 convolutions on the split-bf16 matrix cores:
+    // an EXPERIMENT knob (tests/flip_rate.py measures how many integer durations that flips; the result is in DESIGN.md §5).
+    int text_parts = 0;
+    if (const char* m = getenv("SBV2_TEXT_GEMM")) {
+        SBV2_REQUIRE(std::string(m) == "bf16x3" || std::string(m) == "f32" || !*m, "SBV2_TEXT_GEMM must be f32 or bf16x3");
+        if (std::string(m) == "bf16x3") text_parts = 2;
+    }
+    w.set_cl_parts(text_parts);
     emb_g_ = w.tensor("emb_g.weight");
     emb_ = w.tensor("enc_p.emb.weight");
     tone_emb_ = w.tensor("enc_p.tone_emb.weight");

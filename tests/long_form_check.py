@@ -1,14 +1,15 @@
-"""BASELINE config 5 (long-form >= 2000 phonemes) as an ad-hoc parity run (too slow for the default suite: the CPU oracle needs
-minutes).  usage: python tests/long_form_check.py [n_phones]"""
-import os, sys, time
+"""BASELINE configs[4] (streaming long-form, >= 2000 phonemes) measurement: whole-sequence synthesis vs the chunked decoder replaying its
+captured hipGraph; prints one JSON line (kept under profiles/ as r02_longform*.json).
+usage: python tests/long_form_check.py [n_phones] [chunk_frames]         env SBV2_STREAM_GRAPH=0 -> eager chunk decode (A/B)"""
+import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import sbv2_oracle as O
 from helpers import blob, weights
 from sbv2_api_amd import model, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 bc, bw = weights("bert", "full")
 vc, vw = weights("vits", "full")
 bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
@@ -16,14 +17,36 @@ pipe = model.Pipeline(bs, vs)
 u = synth.make_utterance(n, bc, vc, seed=4242, chars=98)
 b = pipe.prepare([u], forced=True)
 pipe.run(b); pipe.sync()
-t = time.perf_counter(); pipe.run(b); pipe.sync(); dt = time.perf_counter() - t
-got = pipe.fetch(b)[0]
-audio = got.shape[0] / O.SAMPLE_RATE
-print(f"{n} phones -> T_text {u['T_text']}, {got.shape[0] // 512} frames, {audio:.1f} s audio in {dt * 1e3:.1f} ms (RTF {dt / audio:.5f}); finite={np.isfinite(got).all()}")
-if os.environ.get("SBV2_LONG_ORACLE", "1") == "1":
-    O.set_conv_backend("torch")
-    t = time.perf_counter()
-    h = O.deberta_forward(bw, bc, u["input_ids"])
-    ref = O.vits_forward(vw, vc, O.expand_bert_features(h, u["word2ph"]), u["phones"], u["tones"], u["langs"], 0, u["style"],
-                         forced_durations=u["forced_durations"])
-    print(f"oracle {time.perf_counter() - t:.1f} s; max-abs error {np.abs(got - ref).max():.3e}")
+t = time.perf_counter(); pipe.run(b); whole = pipe.fetch(b)[0]; t_whole = time.perf_counter() - t
+audio = whole.shape[0] / 44100.0
+ws_whole = model._lib.lib().sbv2_vits_workspace_bytes(vs.handle)
+
+
+def stream():
+    t0 = time.perf_counter()
+    st = model.StreamHandle(bs, vs, u, chunk, forced=True)
+    t_begin = time.perf_counter() - t0
+    parts, t_first = [], None
+    while True:
+        c = st.next()
+        if c is None:
+            break
+        if t_first is None:
+            t_first = time.perf_counter() - t0
+        parts.append(c)
+    t_all = time.perf_counter() - t0
+    info = (st.uses_graph, st.workspace_bytes)
+    st.close()
+    return np.concatenate(parts), t_begin, t_first, t_all, info, len(parts)
+
+
+stream()                                  # first use of this chunk size: warm-up pass + graph capture
+got, t_begin, t_first, t_all, (graph, ws), nchunks = stream()
+out = {"phones": n, "T_text": int(u["T_text"]), "frames": whole.shape[0] // 512, "audio_s": round(audio, 2), "chunk_frames": chunk, "chunks": nchunks,
+       "whole_sequence_ms": round(t_whole * 1e3, 1), "whole_sequence_rtf": round(t_whole / audio, 6),
+       "stream_text_and_flow_ms": round(t_begin * 1e3, 1), "stream_time_to_first_chunk_ms": round(t_first * 1e3, 1),
+       "stream_total_ms": round(t_all * 1e3, 1), "stream_rtf": round(t_all / audio, 6),
+       "stream_ms_per_chunk": round((t_all - t_begin) / nchunks * 1e3, 3), "chunk_audio_s": round(chunk * 512 / 44100.0, 3),
+       "decoder_graph_replay": bool(graph), "chunk_decoder_workspace_MiB": round(ws / 2**20, 1), "whole_sequence_workspace_MiB": round(ws_whole / 2**20, 1),
+       "chunked_vs_whole_max_abs": float(np.abs(got - whole).max())}
+print(json.dumps(out))

@@ -149,7 +149,7 @@ def test_model_holder_on_gpu_with_sbv2_files_and_eviction():
     sent = {k: u[k] for k in ("input_ids", "word2ph", "phones", "tones", "langs")}
     opts = orchestrator.SynthesizeOptions()
     wav_b = h.easy_synthesize("b", [sent], 1, 0, opts, noise_seed=4)
-    assert h.models() == ["b", "c"]                      # "a" (the first entry) was dropped to make room, as in the reference
+    assert h.models() == ["c", "b"]                      # b re-appended after reload; "a" (then the first entry) dropped to make room, as in the reference
     wav_c = h.easy_synthesize("c", [sent], 1, 0, opts, noise_seed=4)
     assert h.models() == ["c"]
     # reference result for voice c through plain sessions
