@@ -291,11 +291,20 @@ class VitsModel {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         float* pcm = nullptr;       // window PCM (W * hop samples), valid after a replay
+        // chunk c + 1 is enqueued before the host waits for chunk c: two pinned host slots + events
+        float* host[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        int64_t slot_f0[2] = {-1, -1}, slot_n[2] = {0, 0};
         ~ChunkPlan() {
             if (exec) (void)hipGraphExecDestroy(exec);
             if (graph) (void)hipGraphDestroy(graph);
+            for (int i = 0; i < 2; ++i) {
+                if (host[i]) (void)hipHostFree(host[i]);
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            }
         }
     };
+    void stream_enqueue(int64_t f0, int slot);
     std::shared_ptr<ChunkPlan> chunk_;
     Plane z_{};              // flow output of the last forward (frame-rate plane, packed layout fl_)
 

@@ -727,6 +727,10 @@ int64_t VitsModel::stream_begin(int chunk_frames) {
         fill_zero(c.zin.p, sizeof(float) * (size_t)c.zin.C * c.zin.ld, stream_);
         c.cond = c.ar.array<float>((size_t)cfg_.up_initial);
         c.mark = c.ar.mark();
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.host[i]), sizeof(float) * (size_t)chunk_frames * cfg_.hop(), hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming));
+        }
     }
     ChunkPlan& c = *chunk_;
     // the speaker conditioning vector of THIS utterance goes into the plan's persistent buffer (the captured launches read it there)
@@ -757,8 +761,38 @@ int64_t VitsModel::stream_begin(int chunk_frames) {
         HIP_CHECK(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
         trace_ = tr;
     }
-    if (!c.exec) HIP_CHECK(hipStreamSynchronize(stream_));   // eager path: the plan's pinned staging is recycled per chunk
+    if (!c.exec) {   // eager path: the plan's pinned staging is recycled once per stream
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        c.ar.reset_pinned();
+    }
+    c.slot_f0[0] = c.slot_f0[1] = -1;
+    stream_enqueue(0, 0);   // the first chunk starts right behind the flow
     return fl_.len[0];
+}
+
+// window + decoder (graph replay) + device -> pinned-host copy of the window's centre, all asynchronous on the model's stream
+void VitsModel::stream_enqueue(int64_t f0, int slot) {
+    ChunkPlan& c = *chunk_;
+    const int64_t Tf = fl_.len[0];
+    const int hop = cfg_.hop(), halo = stream_halo();
+    const int64_t nsamp = std::min<int64_t>(c.chunk, Tf - f0) * hop;
+    // window = frames [f0 - halo, f0 - halo + W) of this utterance (fl_.start[0] is its first column in the packed plane)
+    Plane zu = z_;
+    zu.p = z_.p + fl_.start[0];
+    zu.L = (int)Tf;
+    window_cols(zu, (int)(f0 - halo), Plane{c.zin.p, c.zin.C, c.W, c.zin.ld}, c.lay.d_mask, stream_);
+    if (c.exec) {
+        HIP_CHECK(hipGraphLaunch(c.exec, stream_));
+    } else {
+        c.ar.rewind(c.mark);
+        if (dec_mode_) run_decoder_cl(c.ar, c.zin, c.lay, c.cond);
+        else run_decoder(c.ar, c.zin, c.lay, c.cond);
+        c.pcm = pcm_;
+    }
+    HIP_CHECK(hipMemcpyAsync(c.host[slot], c.pcm + (size_t)halo * hop, sizeof(float) * (size_t)nsamp, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipEventRecord(c.ev[slot], stream_));
+    c.slot_f0[slot] = f0;
+    c.slot_n[slot] = nsamp;
 }
 
 int64_t VitsModel::stream_chunk(int64_t f0, float* dst_host, int64_t capacity) {
@@ -766,26 +800,15 @@ int64_t VitsModel::stream_chunk(int64_t f0, float* dst_host, int64_t capacity) {
     SBV2_REQUIRE(chunk_ && z_.p && fl_.n == 1, "stream_chunk without stream_begin");
     ChunkPlan& c = *chunk_;
     const int64_t Tf = fl_.len[0];
-    SBV2_REQUIRE(f0 >= 0 && f0 < Tf, "chunk start out of range");
-    const int hop = cfg_.hop();
-    const int64_t nframes = std::min<int64_t>(c.chunk, Tf - f0), nsamp = nframes * hop;
+    SBV2_REQUIRE(f0 >= 0 && f0 < Tf && f0 % c.chunk == 0, "chunk start out of range");
+    const int slot = (int)((f0 / c.chunk) & 1);
+    const int64_t nsamp = std::min<int64_t>(c.chunk, Tf - f0) * cfg_.hop();
     SBV2_REQUIRE(capacity >= nsamp, "PCM buffer too small for the chunk");
-    // window = frames [f0 - halo, f0 - halo + W) of this utterance (fl_.start[0] is its first column in the packed plane)
-    Plane zu = z_;
-    zu.p = z_.p + fl_.start[0];
-    zu.L = (int)Tf;
-    window_cols(zu, (int)(f0 - stream_halo()), Plane{c.zin.p, c.zin.C, c.W, c.zin.ld}, c.lay.d_mask, stream_);
-    if (c.exec) {
-        HIP_CHECK(hipGraphLaunch(c.exec, stream_));
-    } else {
-        c.ar.rewind(c.mark);
-        c.ar.reset_pinned();   // every earlier copy has completed (stream_chunk ends with a stream sync)
-        if (dec_mode_) run_decoder_cl(c.ar, c.zin, c.lay, c.cond);
-        else run_decoder(c.ar, c.zin, c.lay, c.cond);
-        c.pcm = pcm_;
-    }
-    HIP_CHECK(hipMemcpyAsync(dst_host, c.pcm + (size_t)stream_halo() * hop, sizeof(float) * (size_t)nsamp, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (c.slot_f0[slot] != f0) stream_enqueue(f0, slot);                                  // (random access: not the streaming order)
+    if (f0 + c.chunk < Tf && c.slot_f0[slot ^ 1] != f0 + c.chunk) stream_enqueue(f0 + c.chunk, slot ^ 1);   // next chunk runs while this one is delivered
+    HIP_CHECK(hipEventSynchronize(c.ev[slot]));
+    std::memcpy(dst_host, c.host[slot], sizeof(float) * (size_t)nsamp);
+    c.slot_f0[slot] = -1;
     return nsamp;
 }
 
