@@ -554,14 +554,18 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         kp.mask_shift = s;
     }
     SBV2_REQUIRE(!(p.split && p.f16), "conv_cl: split and f16 are exclusive");
+    // small grids (single-utterance calls: the flow's FFN convs at 897 frames are 12 / 48 workgroups of 64 rows): 32-row tiles double the
+    // workgroup count; the weights are packed per 32-row tile either way (nmt is a multiple of the packed tm)
+    int tm = p.tm;
+    if (tm == 2 && (int64_t)((p.N + kClNT - 1) / kClNT) * (p.nmt / 2) < 128) tm = 1;
     if (p.split) {
-        if (p.tm == 2) launch_cl_layout<2, PREC_BF16X3>(kp, stream);
+        if (tm == 2) launch_cl_layout<2, PREC_BF16X3>(kp, stream);
         else launch_cl_layout<1, PREC_BF16X3>(kp, stream);
     } else if (p.f16) {
-        if (p.tm == 2) launch_cl_layout<2, PREC_F16>(kp, stream);
+        if (tm == 2) launch_cl_layout<2, PREC_F16>(kp, stream);
         else launch_cl_layout<1, PREC_F16>(kp, stream);
     } else {
-        if (p.tm == 2) launch_cl_layout<2, PREC_BF16>(kp, stream);
+        if (tm == 2) launch_cl_layout<2, PREC_BF16>(kp, stream);
         else launch_cl_layout<1, PREC_BF16>(kp, stream);
     }
 }
