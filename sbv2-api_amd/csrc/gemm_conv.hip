@@ -521,7 +521,9 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         // single-utterance calls (DeBERTa at 64 tokens: 16-64 workgroups of 64 rows on 256 CUs, 47 us per launch whatever the size):
         // 32-row tiles double the workgroup count; the per-element summation order does not depend on the tile, so batch rows stay
         // bit-identical to single calls
-        if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 16>(kp, Mx, Nx, stream);
+        // ... and 64-channel chunks: a workgroup of a small grid is alone on its CU, its K loop is a chain of global round trips
+        // (two chunks in flight: ~0.7 us per 16-channel chunk whatever the MFMA work), so it asks for four times as much per trip
+        if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 64>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
     }
     if (blocks(64, 256) >= 512) return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
