@@ -91,8 +91,9 @@ void grouped_gemm(const float* A, int lda, const float* B, int ldb, float* C, in
 
 VitsModel::Encoder VitsModel::load_encoder(const std::string& p, int n_layers) {
     Encoder e;
-    e.spk_w = ws_->tensor(p + "spk_emb_linear.weight");
-    e.spk_b = ws_->tensor(p + "spk_emb_linear.bias");
+    const int Hh = cfg_.hidden, dkk = cfg_.hidden / cfg_.heads, nwin = 2 * cfg_.window + 1;
+    e.spk_w = ws_->tensor(p + "spk_emb_linear.weight", {Hh, cfg_.gin});
+    e.spk_b = ws_->tensor(p + "spk_emb_linear.bias", {Hh});
     e.layers.resize(n_layers);
     for (int i = 0; i < n_layers; ++i) {
         EncLayer& L = e.layers[i];
@@ -102,14 +103,17 @@ VitsModel::Encoder VitsModel::load_encoder(const std::string& p, int n_layers) {
         L.attn.v = ws_->conv(a + "conv_v");
         L.attn.o = ws_->conv(a + "conv_o");
         L.attn.qkv = ws_->conv_cat({a + "conv_q", a + "conv_k", a + "conv_v"});
-        L.attn.erk = ws_->tensor(a + "emb_rel_k");
-        L.attn.erv = ws_->tensor(a + "emb_rel_v");
-        L.n1g = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".gamma");
-        L.n1b = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".beta");
-        L.n2g = ws_->tensor(p + "norm_layers_2." + std::to_string(i) + ".gamma");
-        L.n2b = ws_->tensor(p + "norm_layers_2." + std::to_string(i) + ".beta");
+        L.attn.erk = ws_->tensor(a + "emb_rel_k", {nwin, dkk});     // [1][2w+1][dk]: shared by the heads
+        L.attn.erv = ws_->tensor(a + "emb_rel_v", {nwin, dkk});
+        L.n1g = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".gamma", {Hh});
+        L.n1b = ws_->tensor(p + "norm_layers_1." + std::to_string(i) + ".beta", {Hh});
+        L.n2g = ws_->tensor(p + "norm_layers_2." + std::to_string(i) + ".gamma", {Hh});
+        L.n2b = ws_->tensor(p + "norm_layers_2." + std::to_string(i) + ".beta", {Hh});
         L.ffn1 = ws_->conv(p + "ffn_layers." + std::to_string(i) + ".conv_1");
         L.ffn2 = ws_->conv(p + "ffn_layers." + std::to_string(i) + ".conv_2");
+        for (const PackedConv* c : {&L.attn.q, &L.attn.k, &L.attn.v, &L.attn.o}) ws_->expect(*c, a + "conv_*", Hh, Hh, 1);
+        ws_->expect(L.ffn1, p + "ffn_layers.conv_1", cfg_.filter, Hh, L.ffn1.k);
+        ws_->expect(L.ffn2, p + "ffn_layers.conv_2", Hh, cfg_.filter, L.ffn1.k);
     }
     return e;
 }
@@ -120,13 +124,15 @@ VitsModel::DDS VitsModel::load_dds(const std::string& p, int) {
         const std::string s = std::to_string(i);
         const HostTensor& w = ws_->blob().get(p + "convs_sep." + s + ".weight");
         SBV2_REQUIRE(w.dims.size() == 3 && w.dims[2] == 3, "DDSConv depthwise kernel must be 3");
-        d.sep_w.push_back(ws_->tensor(p + "convs_sep." + s + ".weight"));
-        d.sep_b.push_back(ws_->tensor(p + "convs_sep." + s + ".bias"));
+        const int Hd = cfg_.hidden;
+        d.sep_w.push_back(ws_->tensor(p + "convs_sep." + s + ".weight", {Hd, 3}));
+        d.sep_b.push_back(ws_->tensor(p + "convs_sep." + s + ".bias", {Hd}));
         d.pw.push_back(ws_->conv(p + "convs_1x1." + s));
-        d.n1g.push_back(ws_->tensor(p + "norms_1." + s + ".gamma"));
-        d.n1b.push_back(ws_->tensor(p + "norms_1." + s + ".beta"));
-        d.n2g.push_back(ws_->tensor(p + "norms_2." + s + ".gamma"));
-        d.n2b.push_back(ws_->tensor(p + "norms_2." + s + ".beta"));
+        ws_->expect(d.pw.back(), p + "convs_1x1." + s, Hd, Hd, 1);
+        d.n1g.push_back(ws_->tensor(p + "norms_1." + s + ".gamma", {Hd}));
+        d.n1b.push_back(ws_->tensor(p + "norms_1." + s + ".beta", {Hd}));
+        d.n2g.push_back(ws_->tensor(p + "norms_2." + s + ".gamma", {Hd}));
+        d.n2b.push_back(ws_->tensor(p + "norms_2." + s + ".beta", {Hd}));
     }
     return d;
 }
@@ -178,31 +184,44 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         if (std::string(m) == "bf16x3") text_parts = 2;
     }
     w.set_cl_parts(text_parts);
-    emb_g_ = w.tensor("emb_g.weight");
-    emb_ = w.tensor("enc_p.emb.weight");
-    tone_emb_ = w.tensor("enc_p.tone_emb.weight");
-    lang_emb_ = w.tensor("enc_p.language_emb.weight");
+    // every tensor's shape is checked against the config before a kernel indexes it (a container / imported ONNX whose config and
+    // weights disagree is refused here)
+    const int Hc = cfg_.hidden, Gc = cfg_.gin, Ic = cfg_.inter, Fd = cfg_.dp_filter;
+    SBV2_REQUIRE(cfg_.n_vocab >= 1 && cfg_.n_tones >= 1 && cfg_.n_langs >= 1 && cfg_.n_speakers >= 1 && Hc >= 4 && Gc >= 1 && Ic >= 2 && Fd >= 1 &&
+                     cfg_.enc_layers >= 1 && cfg_.flow_n >= 1 && cfg_.flow_layers >= 1 && cfg_.sdp_bins >= 2 && cfg_.sdp_bins <= 16 && cfg_.window >= 0,
+                 "bad VITS config");
+    emb_g_ = w.tensor("emb_g.weight", {cfg_.n_speakers, Gc});
+    emb_ = w.tensor("enc_p.emb.weight", {cfg_.n_vocab, Hc});
+    tone_emb_ = w.tensor("enc_p.tone_emb.weight", {cfg_.n_tones, Hc});
+    lang_emb_ = w.tensor("enc_p.language_emb.weight", {cfg_.n_langs, Hc});
     bert_proj_ = w.conv("enc_p.bert_proj");
-    style_w_ = w.tensor("enc_p.style_proj.weight");
-    style_b_ = w.tensor("enc_p.style_proj.bias");
+    w.expect(bert_proj_, "enc_p.bert_proj", Hc, cfg_.bert_dim, 1);
+    style_w_ = w.tensor("enc_p.style_proj.weight", {Hc, cfg_.style_dim});
+    style_b_ = w.tensor("enc_p.style_proj.bias", {Hc});
     enc_p_ = load_encoder("enc_p.encoder.", cfg_.enc_layers);
     enc_proj_ = w.conv("enc_p.proj");
+    w.expect(enc_proj_, "enc_p.proj", 2 * Ic, Hc, 1);
     dp_c1_ = w.conv("dp.conv_1");
     dp_c2_ = w.conv("dp.conv_2");
     dp_proj_ = w.conv("dp.proj");
-    dp_n1g_ = w.tensor("dp.norm_1.gamma"); dp_n1b_ = w.tensor("dp.norm_1.beta");
-    dp_n2g_ = w.tensor("dp.norm_2.gamma"); dp_n2b_ = w.tensor("dp.norm_2.beta");
-    dp_cond_w_ = w.tensor("dp.cond.weight"); dp_cond_b_ = w.tensor("dp.cond.bias");
+    w.expect(dp_c1_, "dp.conv_1", Fd, Hc, cfg_.dp_kernel);
+    w.expect(dp_c2_, "dp.conv_2", Fd, Fd, cfg_.dp_kernel);
+    w.expect(dp_proj_, "dp.proj", 1, Fd, 1);
+    dp_n1g_ = w.tensor("dp.norm_1.gamma", {Fd}); dp_n1b_ = w.tensor("dp.norm_1.beta", {Fd});
+    dp_n2g_ = w.tensor("dp.norm_2.gamma", {Fd}); dp_n2b_ = w.tensor("dp.norm_2.beta", {Fd});
+    dp_cond_w_ = w.tensor("dp.cond.weight", {Hc, Gc}); dp_cond_b_ = w.tensor("dp.cond.bias", {Hc});
     sdp_pre_ = w.conv("sdp.pre");
     sdp_proj_ = w.conv("sdp.proj");
-    sdp_cond_w_ = w.tensor("sdp.cond.weight"); sdp_cond_b_ = w.tensor("sdp.cond.bias");
-    sdp_ea_m_ = w.tensor("sdp.flows.0.m"); sdp_ea_logs_ = w.tensor("sdp.flows.0.logs");
+    w.expect(sdp_pre_, "sdp.pre", Hc, Hc, 1);
+    w.expect(sdp_proj_, "sdp.proj", Hc, Hc, 1);
+    sdp_cond_w_ = w.tensor("sdp.cond.weight", {Hc, Gc}); sdp_cond_b_ = w.tensor("sdp.cond.bias", {Hc});
+    sdp_ea_m_ = w.tensor("sdp.flows.0.m", {2}); sdp_ea_logs_ = w.tensor("sdp.flows.0.logs", {2});
     sdp_dds_ = load_dds("sdp.convs.", cfg_.hidden);
     for (int i = 2; i <= cfg_.sdp_flows; ++i) {  // ConvFlow 1 is the "useless vflow" dropped in reverse mode
         const std::string p = "sdp.flows." + std::to_string(2 * i - 1) + ".";
         ConvFlow cf;
-        cf.pre_w = w.tensor(p + "pre.weight");
-        cf.pre_b = w.tensor(p + "pre.bias");
+        cf.pre_w = w.tensor(p + "pre.weight", {Hc});
+        cf.pre_b = w.tensor(p + "pre.bias", {Hc});
         cf.dds = load_dds(p + "convs.", cfg_.hidden);
         cf.proj = w.conv(p + "proj");
         SBV2_REQUIRE(cf.proj.cout == 3 * cfg_.sdp_bins - 1, "ConvFlow projection size");
@@ -214,22 +233,33 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         Coupling c;
         c.pre = w.conv(p + "pre");
         c.post = w.conv(p + "post");
+        w.expect(c.pre, p + "pre", Hc, Ic / 2, 1);
+        w.expect(c.post, p + "post", Ic / 2, Hc, 1);
         c.enc = load_encoder(p + "enc.", cfg_.flow_layers);
         flows_.push_back(c);
     }
     // the k-major decoder weights stay exact f32 (SBV2_DECODER=f32 is the exact reference path); the bf16 decoder has its own packing
     w.set_cl_parts(0);
     dec_pre_ = w.conv("dec.conv_pre");
-    dec_cond_w_ = w.tensor("dec.cond.weight");
-    dec_cond_b_ = w.tensor("dec.cond.bias");
-    dec_post_w_ = w.tensor("dec.conv_post.weight");
-    dec_post_k_ = (int)blob.get("dec.conv_post.weight").dims[2];
+    w.expect(dec_pre_, "dec.conv_pre", cfg_.up_initial, Ic, dec_pre_.k);
+    dec_cond_w_ = w.tensor("dec.cond.weight", {cfg_.up_initial, Gc});
+    dec_cond_b_ = w.tensor("dec.cond.bias", {cfg_.up_initial});
+    {
+        const HostTensor& pw = blob.get("dec.conv_post.weight");
+        SBV2_REQUIRE(pw.dims.size() == 3 && pw.dims[0] == 1 && pw.dims[2] >= 1 && pw.dims[2] <= 15 && (pw.dims[2] & 1), "dec.conv_post.weight must be [1][C][odd k]");
+        int cl = cfg_.up_initial;
+        for (size_t i = 0; i < cfg_.up_rates.size(); ++i) cl /= 2;
+        dec_post_w_ = w.tensor("dec.conv_post.weight", {cl, pw.dims[2]});
+        dec_post_k_ = (int)pw.dims[2];
+    }
+    SBV2_REQUIRE(cfg_.up_rates.size() == cfg_.up_kernels.size() && !cfg_.up_rates.empty(), "upsampling config mismatch");
     int C = cfg_.up_initial;
     const int nk = (int)cfg_.res_kernels.size();
     for (size_t i = 0; i < cfg_.up_rates.size(); ++i) {
         Stage st;
         st.rate = cfg_.up_rates[i];
         st.up = w.upsample("dec.ups." + std::to_string(i), st.rate, (cfg_.up_kernels[i] - st.rate) / 2);
+        SBV2_REQUIRE(st.up.cin == C && st.up.cout == C / 2, "dec.ups." + std::to_string(i) + ": channel counts do not follow up_initial / 2^i");
         C /= 2;
         st.ch = C;
         for (int j = 0; j < nk; ++j) {
@@ -240,6 +270,8 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
             for (size_t n = 0; n < rb.dil.size(); ++n) {
                 rb.c1.push_back(w.conv(p + "convs1." + std::to_string(n)));
                 rb.c2.push_back(w.conv(p + "convs2." + std::to_string(n)));
+                w.expect(rb.c1.back(), p + "convs1", C, C, rb.k);
+                w.expect(rb.c2.back(), p + "convs2", C, C, rb.k);
             }
             st.branches.push_back(rb);
         }

@@ -713,3 +713,11 @@ def test_error_paths(vits_tiny):
         model.synthesize(vits_tiny, u["bert"], bad, [0], u["tones"], u["langs"], u["style"], 0.0, 1.0, 0.0, 0.0)
     with pytest.raises(model.Sbv2Error):
         model.load_model(b"not a model", False)
+    # a container whose tensors do not have the shapes its config implies is refused at load time, before any kernel indexes them
+    W = dict(weights("vits", "tiny", 5)[1])
+    for name, bad_shape in (("dp.norm_1.gamma", (cfg["dp_filter"] + 1,)), ("enc_p.emb.weight", (cfg["n_vocab"], cfg["hidden"] - 4)),
+                            ("dec.resblocks.0.convs1.0.weight", (cfg["up_initial"] // 2, cfg["up_initial"] // 2 + 16, cfg["res_kernels"][0]))):
+        Wb = dict(W)
+        Wb[name] = np.zeros(bad_shape, np.float32)
+        with pytest.raises(model.Sbv2Error, match="config implies"):
+            model.load_model(synth.pack_blob(synth.KIND_VITS, cfg, Wb), False)
