@@ -167,7 +167,199 @@ __global__ __launch_bounds__(256) void k_deberta_attn(const AttnGroup* groups, c
         }
     }
 }
+
+// ---- the same attention for 65 .. 128 tokens (the reference's TensorRT profile allows 100: crates/sbv2_core/src/model.rs:15) -----------
+// 4 x 4 score tiles on 8 waves (two key tiles of one query tile per wave).  The relative-position products of a whole (utterance, head)
+// no longer fit LDS (c2p^T alone is 256 x 128 floats), but a 32 x 32 score tile only needs the 63 bucket indices its (i - j) range
+// reaches (the bucket function is monotone with slope <= 1), so every wave computes, per score tile, a 64 x 32 piece of c2p^T and a 32 x 64
+// piece of p2c into its private 8.4 KB scratch, gathers the bias terms from there and moves on.  P ([128][129] floats) and the scratch
+// fill 135 KB of LDS; V is staged over the scratch once the scores are done.  Arithmetic per element as in k_deberta_attn.
+constexpr int kDbT = 128;
+constexpr int kDbPp = kDbT + 1;          // pitch of P / V rows
+constexpr int kDbScr = 64 * 33;          // floats of per-wave scratch (c2p piece [64][33]; p2c piece [32][65] = 2080 fits)
+
+__global__ __launch_bounds__(512) void k_deberta_attn128(const AttnGroup* groups, const float* Q, const float* K, int ld, const float* V,
+                                                         const float* posk, const float* posq, int ldp, int win_lo, int wlen, const int* tab,
+                                                         int tab_center, int span, float inv_scale, const unsigned char* tok_mask, int dh,
+                                                         float* ctx, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) float db_smem[];
+    float* p_s = db_smem;                                   // P[j][i]
+    float* scr = p_s + kDbT * kDbPp;                        // [8 waves][kDbScr]; V[dd][j] after the scores
+    float (*redm)[kDbT] = reinterpret_cast<float (*)[kDbT]>(scr + 8 * kDbScr);
+    float (*reds)[kDbT] = redm + 4;
+    int* tab_s = reinterpret_cast<int*>(reds + 4);          // [2 * kDbT]
+    const AttnGroup g = groups[blockIdx.x];
+    const int T = g.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int64_t hoff = (int64_t)g.head * dh;
+    const float* Qg = Q + hoff * ld + g.col0;
+    const float* Kg = K + hoff * ld + g.col0;
+    const float* Pk = posk + hoff * ldp + win_lo;
+    const float* Pq = posq + hoff * ldp + win_lo;
+    const float* Vg = V + hoff * ld + g.col0;
+    const int ns = dh >> 1;
+    const int hi = 2 * span - 1;
+
+    if (tid < 2 * T - 1) tab_s[tid] = tab[tab_center - (T - 1) + tid];   // tab_s[(i - j) + T - 1] = bucket(i - j)
+    for (int e = tid; e < 4 * kDbT; e += 512) (&redm[0][0])[e] = -FLT_MAX;
+    __syncthreads();
+
+    auto tile_product = [&](const float* Abase, int lda_, int arow, int amax, const float* Bbase, int ldb_, int bcol, int bmax) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int ar = arow + col, bc = bcol + col;
+        const bool aok = ar >= 0 && ar < amax, bok = bc >= 0 && bc < bmax;
+        const float* ap = Abase + min(max(ar, 0), amax - 1);
+        const float* bp = Bbase + min(max(bc, 0), bmax - 1);
+        // operands eight k-steps at a time (the 64-token kernel preloads all 32: with two score tiles per wave that spills)
+#pragma unroll 1
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int dd = min(2 * (s0 + s) + kh, dh - 1);
+                av[s] = ap[(int64_t)dd * lda_];
+                bv[s] = bp[(int64_t)dd * ldb_];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s0 + s < ns) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aok ? av[s] : 0.f, bok ? bv[s] : 0.f, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto widx = [&](int rel, bool neg) {   // window index of bucket(rel) (c2p) or of -bucket(-rel) (p2c)
+        const int b = neg ? -tab_s[-rel + T - 1] : tab_s[rel + T - 1];
+        return min(max(b + span, 0), hi) - win_lo;
+    };
+
+    // ---- scores: wave -> query tile it, key tiles jt0 and jt0 + 1 --------------------------------------------------------------------
+    const int it = wave & 3, jt0 = 2 * (wave >> 2);
+    const int i = it * 32 + col;
+    const bool iok = i < T;
+    const int ic = min(i, T - 1);
+    const bool mi = tok_mask[g.col0 + ic] != 0;
+    float* my = scr + wave * kDbScr;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int jt = jt0 + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][r] = -FLT_MAX;
+        if (it * 32 >= T || jt * 32 >= T) continue;   // (wave-uniform)
+        f32x16 a = tile_product(Kg, ld, jt * 32, T, Qg, ld, it * 32, T);
+        // relative positions of this tile pair: i - j in [rlo, rhi]; the bucket index is monotone in it
+        const int rlo = max(it * 32 - min(jt * 32 + 31, T - 1), -(T - 1)), rhi = min(min(it * 32 + 31, T - 1) - jt * 32, T - 1);
+        const int wb1 = widx(rlo, false), wb2 = widx(rlo, true);
+        (void)rhi;
+        // c2p^T piece: [w - wb1][i] = sum_d posk[d][w] q[d][i]
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt) {
+            const f32x16 c = tile_product(Pk, ldp, wb1 + wt * 32, wlen, Qg, ld, it * 32, T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[(wt * 32 + acc_row(r, kh)) * 33 + col] = c[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jc = min(jt * 32 + acc_row(r, kh), T - 1);
+            const int d1 = min(max(widx(ic - jc, false) - wb1, 0), 63);
+            a[r] = a[r] * inv_scale + my[d1 * 33 + col] * inv_scale;
+        }
+        // p2c piece: [j][w - wb2] = sum_d k[d][j] posq[d][w]
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt) {
+            const f32x16 c = tile_product(Kg, ld, jt * 32, T, Pq, ldp, wb2 + wt * 32, wlen);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[acc_row(r, kh) * 65 + wt * 32 + col] = c[r];
+        }
+        float mloc = -FLT_MAX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jr = acc_row(r, kh), j = jt * 32 + jr;
+            const int jc = min(j, T - 1);
+            // the p2c piece is indexed [key row of this tile][window]: this lane needs row jr at the window index of ITS query column,
+            // which another lane computed: read it from the scratch (same wave: LDS operations execute in order)
+            const int d2 = min(max(widx(ic - jc, true) - wb2, 0), 63);
+            float v = a[r] + my[jr * 65 + d2] * inv_scale;
+            if (!(mi && tok_mask[g.col0 + jc])) v = -FLT_MAX;
+            if (j >= T) v = -FLT_MAX;
+            sacc[t][r] = v;
+            if (j < T) mloc = fmaxf(mloc, v);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        if (kh == 0) redm[jt][i] = mloc;
+    }
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(redm[0][i], redm[1][i]), fmaxf(redm[2][i], redm[3][i]));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int jt = jt0 + t;
+        float sloc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jt * 32 + acc_row(r, kh);
+            const float e = (j < T && it * 32 < T) ? expf(sacc[t][r] - mx) : 0.f;
+            sacc[t][r] = e;
+            sloc += e;
+        }
+        const float other = __shfl_xor(sloc, 32);
+        sloc = kh ? other + sloc : sloc + other;
+        if (kh == 0) reds[jt][i] = sloc;
+    }
+    __syncthreads();
+    const float sum = (reds[0][i] + reds[1][i]) + (reds[2][i] + reds[3][i]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p_s[((jt0 + t) * 32 + acc_row(r, kh)) * kDbPp + i] = sum > 0.f ? sacc[t][r] / sum : 0.f;
+    // ---- V -> LDS over the scratch (coalesced along j), then ctx[dd][i] = sum_j v[dd][j] p[j][i]: wave -> (channel tile, query tile) -----
+    float* v_s = scr;   // [dd][j], pitch kDbPp
+    __syncthreads();    // every wave is done with its scratch; P is complete
+    for (int idx = tid; idx < 64 * kDbT; idx += 512) {
+        const int dd = idx >> 7, j = idx & 127;
+        v_s[dd * kDbPp + j] = (dd < dh && j < T) ? Vg[(int64_t)dd * ld + j] : 0.f;
+    }
+    __syncthreads();
+    const int ddt = wave >> 2;
+    if (ddt * 32 < dh && it * 32 < T) {
+        f32x16 cacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+        const float* vrow = v_s + (ddt * 32 + col) * kDbPp;
+#pragma unroll 8
+        for (int s = 0; s < 64; ++s) {
+            const int j = 2 * s + kh;
+            if (2 * s < T) cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[j], p_s[j * kDbPp + i], cacc, 0, 0, 0);
+        }
+        float* Cg = ctx + hoff * ldc + g.col0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d2 = ddt * 32 + acc_row(r, kh);
+            if (d2 < dh && iok) Cg[(int64_t)d2 * ldc + i] = cacc[r];
+        }
+    }
+}
 }  // namespace
+
+// 65 .. 128 tokens: the tiled variant (any window length: pieces are cut per score tile)
+bool deberta_attention128_fits(int T, int dh) { return T > kDaT && T <= kDbT && dh <= 64 && (dh & 1) == 0; }
+
+void deberta_attention128(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* V, const float* posk,
+                          const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span, float inv_scale,
+                          const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s) {
+    if (ngroups <= 0) return;
+    constexpr size_t lds = sizeof(float) * (kDbT * kDbPp + 8 * kDbScr + 8 * kDbT + 2 * kDbT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_deberta_attn128), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_deberta_attn128, dim3(ngroups), dim3(512), lds, s, groups, Q, K, ld, V, posk, posq, ldp, win_lo, wlen, tab,
+                       tab_center, span, inv_scale, tok_mask, dh, ctx, ldc);
+    HIP_CHECK(hipGetLastError());
+}
 
 bool deberta_attention_fits(int maxT, int wlen, int dh) { return maxT >= 1 && maxT <= kDaT && wlen <= kDaW && dh <= 64 && (dh & 1) == 0; }
 

@@ -219,8 +219,9 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     int* d_tab = arena_.array<int>(tab.size());
     arena_.upload(d_tab, tab.data(), sizeof(int) * tab.size(), stream_);
 
-    // attention problem descriptors.  Utterances of <= 64 tokens (the usual sentence) take the fused kernel of attn_deberta.hip, longer
-    // ones the grouped-GEMM + softmax path; a batch may hold both.  SBV2_BERT_ATTN=unfused sends everything down the second path.
+    // attention problem descriptors.  Utterances of <= 64 tokens (the usual sentence) take the fused kernel of attn_deberta.hip, 65 .. 128
+    // tokens its tiled variant (the reference's TensorRT profile allows 100 tokens: model.rs:15), longer ones the grouped-GEMM + softmax
+    // path; a batch may hold all three.  SBV2_BERT_ATTN=unfused sends everything down the second path.
     static const bool want_fused = !(getenv("SBV2_BERT_ATTN") && std::string(getenv("SBV2_BERT_ATTN")) == "unfused");
     // bucket window reachable by a short utterance (|i - j| <= 63)
     int win_lo_s = 0, wlen_s = 1;
@@ -235,13 +236,26 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         win_lo_s = lo / 4 * 4;
         wlen_s = hi2 - win_lo_s + 1;
     }
+    // ... and by a sequence of up to 128 tokens (|i - j| <= 127): the tiled fused kernel
+    int win_lo_m = 0, wlen_m = 1;
+    {
+        int lo = 2 * span, hi2 = 0;
+        const int c = maxT - 1, r = std::min(maxT - 1, 127);
+        for (int dlt = -r; dlt <= r; ++dlt) {
+            const int v = tab[c + dlt];
+            lo = std::min(lo, std::min(clampi(v + span), clampi(-v + span)));
+            hi2 = std::max(hi2, std::max(clampi(v + span), clampi(-v + span)));
+        }
+        win_lo_m = lo / 4 * 4;
+        wlen_m = hi2 - win_lo_m + 1;
+    }
     const int lds = round_up(maxT, 4);
     Plane X = arena_.plane(H, N), QKV = arena_.plane(3 * H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
     Plane Q = QKV.rows(0, H), Kp = QKV.rows(H, H), Vp = QKV.rows(2 * H, H);
     Plane F = arena_.plane(cfg_.inter, N);
     Plane E0{};   // the embedding output is ConvLayer's input (modeling_deberta_v2.py:664: self.conv(hidden_states, output_states, input_mask))
     if (cfg_.conv_k > 0) E0 = arena_.plane(H, N);
-    std::vector<AttnGroup> ag_s, ag_l;
+    std::vector<AttnGroup> ag_s, ag_m, ag_l;
     std::vector<GemmGroup> g_st, g_c2p, g_p2c, g_pv;
     int64_t s_off = 0, c_off = 0, p_off = 0;
     int maxTL = 0;
@@ -249,7 +263,8 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     for (int u = 0; u < n; ++u) {
         const int T = L[u];
         const bool is_short = want_fused && deberta_attention_fits(T, wlen_s, d);
-        if (!is_short) maxTL = std::max(maxTL, T);
+        const bool is_mid = want_fused && !is_short && deberta_attention128_fits(T, d);
+        if (!is_short && !is_mid) maxTL = std::max(maxTL, T);
         for (int h = 0; h < nh; ++h) {
             AttnGroup a;
             a.qk_off = (int64_t)h * d * X.ld + lay.start[u];
@@ -264,6 +279,10 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
                 ag_s.push_back(a);
                 continue;
             }
+            if (is_mid) {
+                ag_m.push_back(a);
+                continue;
+            }
             ag_l.push_back(a);
             g_st.push_back(GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, d, T});                                   // S^T = K^T Q
             g_c2p.push_back(GemmGroup{(int64_t)h * d * ldp + win_lo, a.qk_off, c_off, 0, wlen, T, d, T});          // posK^T Q
@@ -274,9 +293,13 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
             p_off += (int64_t)T * win_ld;
         }
     }
-    const int ngS = (int)ag_s.size(), ngL = (int)ag_l.size();
+    const int ngS = (int)ag_s.size(), ngM = (int)ag_m.size(), ngL = (int)ag_l.size();
     float *S = nullptr, *C2P = nullptr, *P2C = nullptr, *VT = nullptr;
-    AttnGroup *d_agS = nullptr, *d_agL = nullptr;
+    AttnGroup *d_agS = nullptr, *d_agM = nullptr, *d_agL = nullptr;
+    if (ngM) {
+        d_agM = arena_.array<AttnGroup>(ngM);
+        arena_.upload(d_agM, ag_m.data(), sizeof(AttnGroup) * ngM, stream_);
+    }
     GemmGroup* d_g = nullptr;
     if (ngS) {
         d_agS = arena_.array<AttnGroup>(ngS);
@@ -344,6 +367,9 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         if (ngS)
             deberta_attention(d_agS, ngS, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo_s, wlen_s, d_tab, maxT - 1, span, inv_scale,
                               lay.d_mask, d, ctx.p, ctx.ld, stream_);
+        if (ngM)
+            deberta_attention128(d_agM, ngM, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo_m, wlen_m, d_tab, maxT - 1, span, inv_scale,
+                                 lay.d_mask, d, ctx.p, ctx.ld, stream_);
         if (ngL) {
             linear_tokmajor(Ly.v, X, VT, H, stream_);   // the grouped V P^T product wants V token-major
             grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxTL, maxTL, inv_scale, fl_tt);

@@ -134,14 +134,29 @@ def test_deberta_conv_layer_batch_and_guard():
 def test_deberta_batch_equals_single(bert_tiny):
     cfg, W = weights("bert", "tiny", 3)
     rng = np.random.default_rng(0)
-    # 72 and 130 tokens: longer than the fused attention kernel's 64 -> the batch mixes the fused and the grouped-GEMM attention paths
-    seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (1, 7, 30, 70, 18, 3, 62, 128)]
+    # 72 / 100 / 128 tokens take the tiled fused kernel (65 .. 128), 130 and 200 the grouped-GEMM path: the batch mixes all three
+    seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (1, 7, 30, 70, 18, 3, 62, 128, 98, 126, 63, 198)]
     batch = model.predict_batch(bert_tiny, seqs)
     for ids, got in zip(seqs, batch):
         single = model.predict(bert_tiny, ids, np.ones_like(ids))
         ref = O.deberta_forward(W, cfg, ids)
         np.testing.assert_allclose(single, ref, atol=5e-5, rtol=0)
         np.testing.assert_array_equal(got, single)   # packing must not change a single bit
+
+
+def test_deberta_full_shape_mid_lengths_vs_oracle():
+    """Full ku-nlp-large shape (16 heads x 64, 256 log buckets, ConvLayer) at 65 .. 128 tokens: the tiled fused attention (the reference's
+    TensorRT profile allows 100 tokens, model.rs:15) against the oracle, alone and inside a batch with short and long neighbours."""
+    cfg, W = weights("bert", "full")
+    s = model.load_model(blob("bert", "full"), True)
+    rng = np.random.default_rng(7)
+    seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (98, 20, 126, 63, 150)]
+    batch = model.predict_batch(s, seqs)
+    for k in (0, 2):
+        ref = O.deberta_forward(W, cfg, seqs[k])
+        np.testing.assert_allclose(batch[k], ref, atol=2e-4, rtol=0)
+        np.testing.assert_array_equal(model.predict(s, seqs[k], np.ones_like(seqs[k])), batch[k])
+    s.close()
 
 
 def test_deberta_attention_mask(bert_tiny):
@@ -151,6 +166,13 @@ def test_deberta_attention_mask(bert_tiny):
     got = model.predict(bert_tiny, ids, mask)
     ref = O.deberta_forward(W, cfg, ids, mask)
     np.testing.assert_allclose(got[:6], ref[:6], atol=5e-5, rtol=0)
+    # the same through the tiled kernel (90 tokens, the last 7 masked)
+    rng = np.random.default_rng(3)
+    ids = np.concatenate([[1], rng.integers(3, cfg["vocab_size"], 88), [2]])
+    mask = np.ones_like(ids); mask[-7:] = 0
+    got = model.predict(bert_tiny, ids, mask)
+    ref = O.deberta_forward(W, cfg, ids, mask)
+    np.testing.assert_allclose(got[:-7], ref[:-7], atol=5e-5, rtol=0)
 
 
 @pytest.mark.parametrize("name", ["deberta_full_S64.npz", "deberta_full_S64_noconv.npz"])
