@@ -18,6 +18,8 @@
 // that chunk are copied into LDS in fragment order (1 KB blocks, lane-linear -> conflict-free ds_read_b128), so the tap loop
 // contains no global memory operation and no barrier: B fragments are plain shifted rows of the window.  Global loads for chunk
 // c+1 are issued before the MFMA loop of chunk c and written to LDS after it (two barriers per chunk).
+// Channels-last to channels-last launches whose row tiles pair up (Cout >= 128) run 8 waves = 128 rows x 256 positions per workgroup
+// (template WM = 2): both 64-row wave groups read the one staged window (measured: -4.5 ms of a 112 ms step, SBV2_CL_WM=1 is the A/B).
 #include <type_traits>
 
 #include "common.h"
@@ -63,16 +65,19 @@ struct ClKernelParams {
     int mask_nshift;  // mask index of position n * out_stride + phase offset == n >> mask_nshift (power-of-two strides)
 };
 
-template <int TM, int PREC, bool IN_KM, bool OUT_KM>
-__global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParams kp) {
+// WM = 2: eight waves; waves 0-3 and 4-7 compute two DIFFERENT row groups (TM * 32 rows each) over the SAME 256 positions, so the activation
+// window of a position tile is fetched, converted and written to LDS once for 2 * TM * 32 output rows instead of once per TM * 32.
+template <int TM, int PREC, bool IN_KM, bool OUT_KM, int WM>
+__global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernelParams kp) {
+    constexpr int kT = kClThreads * WM;
     constexpr bool SPLIT = PREC == PREC_BF16X3;
     using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
     using ex8 = std::conditional_t<PREC == PREC_F16, f16x8, bf16x8>;
     using ex4 = std::conditional_t<PREC == PREC_F16, f16x4, bf16x4>;
     constexpr int PARTS = SPLIT ? 2 : 1;
     constexpr int TN = 2;
-    constexpr int MAXW = (kMaxTaps * TM * PARTS * 64 + kClThreads - 1) / kClThreads;  // float4 per thread for one chunk's weights
-    constexpr int NX = ((kClNT + kClMaxSpan) * 4 + kClThreads - 1) / kClThreads;
+    constexpr int MAXW = (kMaxTaps * TM * WM * PARTS * 64 + kT - 1) / kT;  // float4 per thread for one chunk's weights
+    constexpr int NX = ((kClNT + kClMaxSpan) * 4 + kT - 1) / kT;
     const ConvClParams& p = kp.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wsm = smem;
@@ -80,22 +85,23 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     char* xs_lo = xs_hi + kp.xrows * 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn0 = wave * 64;
+    const int wn0 = (wave & 3) * 64;
+    const int wm = wave >> 2;   // row group of this wave (0 when WM == 1)
     // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2.  The gy row tiles
     // of one position tile read the SAME activation window, so they are given ids that differ by 8 (same XCD, back to back) and
     // consecutive position tiles of an XCD are neighbours (shared halo).  Speed only: any placement is correct.
-    const int gy = kp.nmt / TM;
+    const int gy = kp.nmt / (TM * WM);
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int by = slot % gy;
     const int bx = (slot / gy) * 8 + xcd;
-    const int m0 = by * (TM * 32);
+    const int m0 = (by * WM + wm) * (TM * 32);   // first output row of this WAVE's tile
     const int n0 = bx * kClNT;
     if (n0 >= p.N) return;
     const int M = p.M, N = p.N, NB = p.NB, ntaps = p.ntaps;
     const int nchunks = (p.K + 15) >> 4;
     const int wstart = n0 + kp.wshift0;
-    const int nwf4 = ntaps * TM * PARTS * 64;   // float4 of one chunk's weight region
+    const int nwf4 = ntaps * TM * WM * PARTS * 64;   // float4 of one chunk's weight region
     const int nxf4 = kp.xrows * 4;
     const float slope = p.pre_slope;
 
@@ -112,16 +118,16 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     f32x4v rx1[NX];   // rx1 = the following odd chunk)
     // branch-free loads (clamped, always-valid addresses); see gemm_conv.hip for why
     auto load_w = [&](int chunk) {
-        const f32x4v* src = reinterpret_cast<const f32x4v*>(p.W) + ((int64_t)chunk * kp.nmt + by * TM) * ntaps * PARTS * 64;
+        const f32x4v* src = reinterpret_cast<const f32x4v*>(p.W) + ((int64_t)chunk * kp.nmt + by * TM * WM) * ntaps * PARTS * 64;
         static_for<0, MAXW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            rw[i] = src[min(tid + i * kClThreads, nwf4 - 1)];
+            rw[i] = src[min(tid + i * kT, nwf4 - 1)];
         });
     };
     auto store_w = [&]() {
         static_for<0, MAXW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const int idx = tid + i * kClThreads;
+            const int idx = tid + i * kT;
             if (idx < nwf4) reinterpret_cast<f32x4v*>(wsm)[idx] = rw[i];
         });
     };
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     auto load_x = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = min(tid + i * kClThreads, nxf4 - 1);
+            const int idx = min(tid + i * kT, nxf4 - 1);
             if (IN_KM) {
                 // handled by load_xk below (4 x 4 blocks)
             } else {
@@ -146,13 +152,13 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     };
     // k-major input: one thread owns a 4-channel x 4-position block (4 float4 loads along the position axis), transposes it in
     // registers and writes 4 channels per position with one 8-byte LDS store (instead of sixteen 2-byte stores)
-    constexpr int NBK = ((kClNT + kClMaxSpan) + kClThreads - 1) / kClThreads;   // blocks per thread: 4 * xrows / 4 / 256
+    constexpr int NBK = ((kClNT + kClMaxSpan) + kT - 1) / kT;   // blocks per thread: 4 * xrows / 4 / 256
     f32x4v rk[NBK][4];
     const int nblk = 4 * xr4;
     auto load_xk = [&](int chunk) {
 #pragma unroll
         for (int bi = 0; bi < NBK; ++bi) {
-            const int b = min(tid + bi * kClThreads, nblk - 1);
+            const int b = min(tid + bi * kT, nblk - 1);
             const int kq = b / xr4;
             const int j = wstart + (b - kq * xr4) * 4;
             const int jj = (j >= 0 && j < NB) ? j : 0;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     auto store_x = [&]() {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * kClThreads;
+            const int idx = tid + i * kT;
             if (idx < nxf4) {
                 f32x4v rv = rx[i];
                 if (!IN_KM && (xchunk & 1)) rv = rx1[i];
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     auto store_xk = [&]() {
 #pragma unroll
         for (int bi = 0; bi < NBK; ++bi) {
-            const int b = tid + bi * kClThreads;
+            const int b = tid + bi * kT;
             if (b < nblk) {
                 const int kq = b / xr4;
                 const int r0 = (b - kq * xr4) * 4;
@@ -240,25 +246,25 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     // The channels-last epilogue's bias (one value per row of this tile) and column-mask bytes (one per position) are fetched with the
     // first tiles and parked in LDS: read in the epilogue they are dependent global round trips (~1 us each per workgroup; the same
     // change in respair_cl.hip removed 2 ms per step).
-    float* bias_s = reinterpret_cast<float*>(smem + kp.aux_off);          // [TM * 32]
-    unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 64);   // [kClNT]
+    float* bias_s = reinterpret_cast<float*>(smem + kp.aux_off);          // [WM * TM * 32]
+    unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 128);  // [kClNT]
     const bool staged = !OUT_KM && kp.aux_off != 0;
     float bstage = 0.f;
     unsigned char mstage = 1;
     if (staged) {
-        if (tid < TM * 32) {
-            const int m = m0 + tid;
+        if (tid < WM * TM * 32) {
+            const int m = by * (WM * TM * 32) + tid;
             int co = m;
             if (p.phase_rows < (1 << 30)) co = m - (m / p.phase_rows) * p.phase_rows;
             bstage = (p.bias && m < M) ? p.bias[co] : 0.f;
         }
-        if (p.mask) mstage = p.mask[min(n0 + tid, N - 1) >> kp.mask_nshift];
+        if (p.mask) mstage = p.mask[min(n0 + (tid & (kClNT - 1)), N - 1) >> kp.mask_nshift];
     }
     store_w();
     if (IN_KM) store_xk(); else store_x();
     if (staged) {
-        if (tid < TM * 32) bias_s[tid] = bstage;
-        mask_s[tid] = mstage;
+        if (tid < WM * TM * 32) bias_s[tid] = bstage;
+        if (tid < kClNT) mask_s[tid] = mstage;
     }
     __syncthreads();
 
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const char* blk = wsm + ((i * ntaps + tap) * PARTS) * 1024 + lane * 16;
+                const char* blk = wsm + (((wm * TM + i) * ntaps + tap) * PARTS) * 1024 + lane * 16;
                 f.ah[i] = *reinterpret_cast<const ex8*>(blk);
                 if (SPLIT) f.al[i] = *reinterpret_cast<const ex8*>(blk + 1024);
             }
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
             for (int t = 0; t < kMaxPhases; ++t) po = (ph == t) ? p.phase_off[t] : po;
         }
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (staged) b4 = *reinterpret_cast<const float4*>(bias_s + i * 32 + c4);
+        if (staged) b4 = *reinterpret_cast<const float4*>(bias_s + (wm * TM + i) * 32 + c4);
         else if (p.bias && m < M) b4 = *reinterpret_cast<const float4*>(p.bias + co);
         const int nfirst = n0 + wn0 + (lane >> 3);
         int pos = nfirst * ostride + po;              // < 2^31 (checked by the callers)
@@ -457,14 +463,14 @@ __global__ __launch_bounds__(kClThreads) void conv_cl_kernel(const ClKernelParam
     }
 }
 
-template <int TM, int PREC, bool IN_KM, bool OUT_KM>
+template <int TM, int PREC, bool IN_KM, bool OUT_KM, int WM = 1>
 static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     constexpr bool SPLIT = PREC == PREC_BF16X3;
     constexpr int PARTS = SPLIT ? 2 : 1;
     const ConvClParams& p = kp.p;
-    kp.wbytes = p.ntaps * TM * PARTS * 1024;
+    kp.wbytes = p.ntaps * TM * WM * PARTS * 1024;
     size_t lds = (size_t)kp.wbytes + (size_t)kp.xrows * 32 * PARTS;
-    if (!OUT_KM) lds = std::max<size_t>(lds, 4 * 64 * 36 * sizeof(float));  // the epilogue's per-wave transpose tiles
+    if (!OUT_KM) lds = std::max<size_t>(lds, 4 * WM * 64 * 36 * sizeof(float));  // the epilogue's per-wave transpose tiles
     kp.aux_off = 0;
     kp.mask_nshift = 0;
     if (!OUT_KM) {
@@ -480,20 +486,20 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
         if (ok) {
             lds = (lds + 15) / 16 * 16;
             kp.aux_off = (int)lds;
-            lds += 64 * sizeof(float) + kClNT;
+            lds += 128 * sizeof(float) + kClNT;
         }
     }
     static const int pad_lds = getenv("SBV2_CL_PADLDS") ? atoi(getenv("SBV2_CL_PADLDS")) : 0;   // occupancy experiments only
     lds += pad_lds;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
-    auto kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM>;
+    auto kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM, WM>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int ntx = round_up((p.N + kClNT - 1) / kClNT, 8);   // padded so that the (xcd, slot) <-> (tile, row tile) map is a bijection
-    dim3 grid(ntx * (kp.nmt / TM));
+    dim3 grid(ntx * (kp.nmt / (TM * WM)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = conv_prof_active();
     if (prof) {
@@ -501,12 +507,20 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(kern, grid, dim3(kClThreads), lds, stream, kp);
+    hipLaunchKernelGGL(kern, grid, dim3(kClThreads * WM), lds, stream, kp);
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
         conv_prof_add(PREC == PREC_F16 ? 19 + (TM == 2 ? 0 : 1) + ((IN_KM || OUT_KM) ? 2 : 0) : (SPLIT ? 8 : 10) + (TM == 2 ? 0 : 1) + ((IN_KM || OUT_KM) ? 4 : 0), 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
     }
+}
+
+// 128-row workgroups (two 64-row wave groups sharing one staged window) when the row tiles pair up and the grid still covers the chip
+static bool wide_rows(const ClKernelParams& kp) {
+    static const int knob = getenv("SBV2_CL_WM") ? atoi(getenv("SBV2_CL_WM")) : 2;
+    if (knob < 2 || (kp.nmt & 3) != 0) return false;
+    const int64_t wgs = (int64_t)round_up((kp.p.N + kClNT - 1) / kClNT, 8) * (kp.nmt / 4);
+    return wgs >= 512;
 }
 
 template <int TM, int PREC>
@@ -517,6 +531,7 @@ static void launch_cl_layout(const ClKernelParams& kp, hipStream_t stream) {
         else launch_cl<TM, PREC, true, false>(kp, stream);
     } else {
         if (p.out_km) launch_cl<TM, PREC, false, true>(kp, stream);
+        else if (TM == 2 && wide_rows(kp)) launch_cl<TM, PREC, false, false, TM == 2 ? 2 : 1>(kp, stream);
         else launch_cl<TM, PREC, false, false>(kp, stream);
     }
 }
