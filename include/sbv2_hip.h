@@ -209,6 +209,9 @@ int sbv2_prof_end(char* json, int64_t cap);
 /* Times `iters` launches of one dilated conv (device buffers, random data) and returns the mean kernel time in ms. */
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters,
                            float* ms);
+/* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; the
+ * default comes from SBV2_SKINNY_MAX).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
+int sbv2_debug_set_skinny_max(int workgroups);
 
 #ifdef __cplusplus
 }

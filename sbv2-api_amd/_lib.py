@@ -90,6 +90,7 @@ SYMBOLS = {
     "sbv2_debug_conv1d_cl": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int,
                                        C.c_int64, f32p, f32p]),
     "sbv2_debug_time_conv1d": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, f32p]),
+    "sbv2_debug_set_skinny_max": (C.c_int, [C.c_int]),
 }
 
 _lib = None

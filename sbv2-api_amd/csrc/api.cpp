@@ -457,6 +457,8 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
     API_END
 }
 
+int sbv2_debug_set_skinny_max(int workgroups) { return set_skinny_max(workgroups); }
+
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters, float* ms) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));

@@ -188,6 +188,8 @@ struct ConvParams {
 };
 
 void launch_conv(const ConvParams& p, hipStream_t stream);
+int set_skinny_max(int workgroups);   // returns the previous threshold
+bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream);   // gemm_skinny.hip: small-grid 1x1 products
 void conv_prof_begin();
 std::string conv_prof_end();
 bool conv_prof_active();

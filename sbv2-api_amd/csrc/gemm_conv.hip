@@ -20,6 +20,8 @@
 //   [KC][NT + tap span] is staged ONCE in LDS (leaky-ReLU fused into the staging) and re-used by every tap;
 //   the per-tap weight tile [KC][MT] is double-buffered; global loads for step s+1 are issued before the
 //   MFMA block of step s and written to LDS after it (one barrier per step).
+#include <atomic>
+
 #include "common.h"
 
 namespace sbv2 {
@@ -389,8 +391,9 @@ const char* kCfgNames[] = {"conv_gemm<16,1,4,1,4,16>", "conv_gemm<32,1,2,1,4,16>
                            "conv_cl<2,split-bf16>",    "conv_cl<1,split-bf16>",    "conv_cl<2,bf16>",          "conv_cl<1,bf16>",
                            "conv_cl_km<2,split-bf16>", "conv_cl_km<1,split-bf16>", "conv_cl_km<2,bf16>",       "conv_cl_km<1,bf16>",
                            "respair_cl<C<=32>",        "respair_cl<C=64>",         "resblock_cl",
-                           "conv_cl<2,f16>",           "conv_cl<1,f16>",           "conv_cl_km<2,f16>",        "conv_cl_km<1,f16>"};
-constexpr int kNumCfg = 23;
+                           "conv_cl<2,f16>",           "conv_cl<1,f16>",           "conv_cl_km<2,f16>",        "conv_cl_km<1,f16>",
+                           "gemm_skinny<16x16x4>"};
+constexpr int kNumCfg = 24;
 constexpr int cfg_id(int MF, int TM, int TN, int WM) {
     return MF == 16 ? 0 : (WM == 1 ? (TM == 1 ? (TN == 2 ? 1 : 2) : 5) : (TM == 2 ? (TN == 4 ? 3 : 4) : (TN == 2 ? 6 : 7)));
 }
@@ -435,6 +438,9 @@ std::string conv_prof_end() {
     }
     return out + "]";
 }
+
+static std::atomic<int> g_skinny_max{getenv("SBV2_SKINNY_MAX") ? atoi(getenv("SBV2_SKINNY_MAX")) : 128};   // 0 = off
+int set_skinny_max(int v) { return g_skinny_max.exchange(v); }
 
 template <int MF, int TM, int TN, int WM, int WN, int KC>
 static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stream) {
@@ -523,6 +529,8 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         // bit-identical to single calls
         // ... and 64-channel chunks: a workgroup of a small grid is alone on its CU, its K loop is a chain of global round trips
         // (two chunks in flight: ~0.7 us per 16-channel chunk whatever the MFMA work), so it asks for four times as much per trip
+        // ... superseded where it applies by one-wave 16 x 16 tiles fed through an LDS-DMA ring (gemm_skinny.hip: same bits, see there)
+        if (blocks(64, 64) < g_skinny_max.load(std::memory_order_relaxed) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
         if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 64>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
     }

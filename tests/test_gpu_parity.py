@@ -43,6 +43,28 @@ def test_conv1d_kernel(cin, cout, k, dil, L):
         np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,L", [(1024, 1024, 66), (1024, 3072, 130), (4096, 1024, 66), (1024, 4096, 35), (192, 576, 897), (768, 192, 897),
+                                        (192, 29, 300), (96, 192, 4), (1024, 192, 130), (64, 50, 19)])
+def test_gemm_small_grid_kernel_same_bits(cin, cout, L):
+    """The one-wave 16 x 16 kernel of small grids (gemm_skinny.hip) and the tiled kernel give the SAME bits (every f32 MFMA shape is a
+    sequential fma chain over k), which is what keeps a batch row bit-identical to the single call of the same utterance."""
+    rng = np.random.default_rng(cin + cout + L)
+    x = rng.standard_normal((cin, L)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lib = _lib.lib()
+    for slope in (1.0, 0.1):
+        prev = lib.sbv2_debug_set_skinny_max(0)
+        try:
+            tiled = _conv_dev(x, w, b, 1, slope)
+            lib.sbv2_debug_set_skinny_max(1 << 30)
+            skinny = _conv_dev(x, w, b, 1, slope)
+        finally:
+            lib.sbv2_debug_set_skinny_max(prev)
+        assert np.array_equal(tiled.view(np.uint32), skinny.view(np.uint32)), f"{int((tiled != skinny).sum())} of {tiled.size} differ"
+        np.testing.assert_allclose(skinny, O.conv1d_same(O.leaky_relu(x, slope), w, b, 1), atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("cin,cout,k,s,p,L", [(64, 32, 16, 8, 4, 301), (32, 16, 8, 2, 3, 1000), (16, 8, 2, 2, 0, 999),
                                               (512, 256, 16, 8, 4, 57), (8, 4, 4, 4, 0, 33)])
 def test_conv_transpose_kernel(cin, cout, k, s, p, L):
