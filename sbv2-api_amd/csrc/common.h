@@ -189,6 +189,7 @@ struct ConvParams {
 
 void launch_conv(const ConvParams& p, hipStream_t stream);
 int set_skinny_max(int workgroups);   // returns the previous threshold
+int small_grid_max();                 // workgroup count under which the small-grid kernels (gemm_skinny, conv_cl_small) take over; 0 = never
 bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream);   // gemm_skinny.hip: small-grid 1x1 products
 void conv_prof_begin();
 std::string conv_prof_end();
@@ -222,6 +223,7 @@ struct ConvClParams {
     float alpha = 1.0f;         // k-major output only
 };
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
+bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t stream);   // conv_cl_small.hip
 
 // One fused ResBlock1 step y' = beta * (conv2(lrelu(conv1(lrelu(y), dil) + b1)) + b2 + y) on a channels-last plane (respair_cl.hip)
 struct ResPairParams {

@@ -571,6 +571,8 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
     SBV2_REQUIRE(!(p.split && p.f16), "conv_cl: split and f16 are exclusive");
     // small grids (single-utterance calls: the flow's FFN convs at 897 frames are 12 / 48 workgroups of 64 rows): 32-row tiles double the
     // workgroup count; the weights are packed per 32-row tile either way (nmt is a multiple of the packed tm)
+    // ... and the channels-last -> k-major products of such calls run as independent waves fed by an LDS-DMA ring (conv_cl_small.hip: same bits)
+    if ((int64_t)((p.N + kClNT - 1) / kClNT) * std::max(1, p.nmt / 2) < small_grid_max() && launch_conv_cl_small(p, kp.mask_shift, stream)) return;
     int tm = p.tm;
     if (tm == 2 && (int64_t)((p.N + kClNT - 1) / kClNT) * (p.nmt / 2) < 128) tm = 1;
     if (p.split) {

@@ -441,6 +441,7 @@ std::string conv_prof_end() {
 
 static std::atomic<int> g_skinny_max{getenv("SBV2_SKINNY_MAX") ? atoi(getenv("SBV2_SKINNY_MAX")) : 128};   // 0 = off
 int set_skinny_max(int v) { return g_skinny_max.exchange(v); }
+int small_grid_max() { return g_skinny_max.load(std::memory_order_relaxed); }
 
 template <int MF, int TM, int TN, int WM, int WN, int KC>
 static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stream) {

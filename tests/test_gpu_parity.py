@@ -470,6 +470,30 @@ def test_config2_b32_u128_default_path():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_small_grid_kernels_keep_the_bits():
+    """A single-utterance call runs its small grids on gemm_skinny / conv_cl_small; switched off (threshold 0) the same call goes through
+    the tiled kernels of a large batch.  Both must give the same waveform bit for bit (predicted durations + noise, 100 phonemes)."""
+    bc, bw = weights("bert", "full")
+    vc, vw = weights("vits", "full")
+    bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
+    pipe = model.Pipeline(bs, vs)
+    u = synth.make_utterance(100, bc, vc, seed=77)
+    lib = _lib.lib()
+    outs = []
+    for thr in (0, None):
+        prev = lib.sbv2_debug_set_skinny_max(0) if thr == 0 else None
+        try:
+            b = pipe.prepare([u], sdp_ratio=0.2, noise_scale=0.6, noise_scale_w=0.8, noise_seed=5)
+            pipe.run(b)
+            outs.append(pipe.fetch(b)[0])
+        finally:
+            if prev is not None:
+                lib.sbv2_debug_set_skinny_max(prev)
+    assert outs[0].shape == outs[1].shape and outs[0].size > 0
+    np.testing.assert_array_equal(outs[0], outs[1])
+    pipe.close(); bs.close(); vs.close()
+
+
 def test_node_shards_equal_single_gpu_call():
     """sbv2_node_synthesize with four shards on one GPU (the same ordinal four times: peers exchange by device-to-device copies) ==
     one pipeline call of the whole batch, bit for bit, with predicted durations AND noise (streams are keyed by the caller's utterance
