@@ -5,8 +5,8 @@
 // Same arithmetic, element for element: per (chunk, tap) the three split-bf16 MFMAs lo*hi, hi*lo, hi*hi of v_mfma_f32_32x32x16_bf16 in the
 // order of conv_cl.hip, the same hi / lo conversion, the same epilogue expression, so a batch row (conv_cl) and the single call of the
 // same utterance (this kernel) agree bit for bit.  Only the work decomposition differs:
-//   * one WAVE per workgroup, tile 32 rows x (32 * TN) positions: 174 independent waves instead of 24 workgroups;
-//   * no barrier: the wave that issues a load is its only consumer;
+//   * one 32 rows x 32 positions tile per workgroup: 174 workgroups instead of 24, each ONE serial MFMA chain (wave 0) that three helper
+//     waves keep fed (DMA issue, window conversion), one raw s_barrier per chunk;
 //   * both operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-slot ring, up to 3 chunks ahead, counted vmcnt: the weight
 //     fragment blocks are lane-linear 1 KB images already, the activation window lands as raw f32 rows [position][16 channels] and is
 //     converted LDS -> registers -> LDS (leaky-ReLU, hi / lo split, the XOR-swizzled [position][8 | 8] image conv_cl reads) one chunk
@@ -26,7 +26,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-constexpr int kSlots = 4;
+constexpr int kSlots = 8;
 
 struct ClSmallParams {
     ConvClParams p;
@@ -52,13 +52,16 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
     }
 }
 
+constexpr int kLoaders = 3;   // waves 1 .. 3 issue the DMAs and convert the windows; wave 0 only runs the MFMA chain and the epilogue
+
 template <int TN>
-__global__ __launch_bounds__(64) void conv_cl_small_kernel(const ClSmallParams kp) {
+__global__ __launch_bounds__(64 * (kLoaders + 1)) void conv_cl_small_kernel(const ClSmallParams kp) {
     constexpr int NTW = 32 * TN;                       // positions per wave
     constexpr int NCV = (NTW + 64) / 16;               // float4 per lane of one window: (32 TN + 64 span) rows * 4 / 64 lanes
     const ConvClParams& p = kp.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntaps = p.ntaps;
     const int n0 = blockIdx.x * NTW, m0 = blockIdx.y * 32;
     const int M = p.M, N = p.N, NB = p.NB;
@@ -74,14 +77,19 @@ __global__ __launch_bounds__(64) void conv_cl_small_kernel(const ClSmallParams k
     const char* wsrc = reinterpret_cast<const char*>(p.W) + (int64_t)blockIdx.y * wbytes + lane * 16;   // + chunk * nmt * wbytes
     const int64_t wstep = (int64_t)p.nmt * wbytes;
     const int xr = lane >> 2, xq = (lane & 3) * 4;
+    // the 2 * ntaps + xg DMA instructions of a chunk are dealt round-robin over the waves
+    const int nload = 2 * ntaps + kp.xg;
     auto stage = [&](int c) {
         char* dst = ring + (c & (kSlots - 1)) * kp.slot_bytes;
         const char* ws = wsrc + c * wstep;
-        for (int i = 0; i < 2 * ntaps; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(ws + i * 1024), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
-        for (int g = 0; g < kp.xg; ++g) {
-            const int pos = min(max(wstart + g * 16 + xr, 0), NB - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.X + (int64_t)pos * p.ldx + c * 16 + xq), (lds_void_t*)(dst + wbytes + g * 1024), 16, 0, 0);
+        for (int i = wave - 1; i < nload; i += kLoaders) {
+            if (i < 2 * ntaps) {
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(ws + i * 1024), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+            } else {
+                const int g = i - 2 * ntaps;
+                const int pos = min(max(wstart + g * 16 + xr, 0), NB - 1);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.X + (int64_t)pos * p.ldx + c * 16 + xq), (lds_void_t*)(dst + wbytes + g * 1024), 16, 0, 0);
+            }
         }
     };
     // raw window of chunk c (slot c & 3) -> converted image (buffer c & 1); conv_cl.hip's store_x, with LDS as the source
@@ -90,26 +98,29 @@ __global__ __launch_bounds__(64) void conv_cl_small_kernel(const ClSmallParams k
         const char* raw = ring + (c & (kSlots - 1)) * kp.slot_bytes + wbytes;
         char* xs_hi = cvt + (c & 1) * 2 * cvt_bytes;
         char* xs_lo = xs_hi + cvt_bytes;
+        constexpr int NCVL = (NCV + kLoaders - 1) / kLoaders;
+        f32x4v rv[NCVL];
 #pragma unroll
-        for (int i = 0; i < NCV; ++i) {
-            const int idx = lane + i * 64;
+        for (int i = 0; i < NCVL; ++i) rv[i] = *reinterpret_cast<const f32x4v*>(raw + min((wave - 1) * 64 + lane + i * 64 * kLoaders, nxf4 - 1) * 16);
+#pragma unroll
+        for (int i = 0; i < NCVL; ++i) {
+            const int idx = (wave - 1) * 64 + lane + i * 64 * kLoaders;
+            float4 v = make_float4(rv[i][0], rv[i][1], rv[i][2], rv[i][3]);
+            const int row = idx >> 2, q = idx & 3;
+            const int pos = wstart + row;
+            if (pos < 0 || pos >= NB) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slope != 1.0f) {
+                v.x = v.x >= 0.f ? v.x : v.x * slope;
+                v.y = v.y >= 0.f ? v.y : v.y * slope;
+                v.z = v.z >= 0.f ? v.z : v.z * slope;
+                v.w = v.w >= 0.f ? v.w : v.w * slope;
+            }
+            const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
+            bf16x4 h, l;
+            h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+            l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
             if (idx < nxf4) {
-                const f32x4v rv = *reinterpret_cast<const f32x4v*>(raw + idx * 16);
-                float4 v = make_float4(rv[0], rv[1], rv[2], rv[3]);
-                const int row = idx >> 2, q = idx & 3;
-                const int pos = wstart + row;
-                if (pos < 0 || pos >= NB) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (slope != 1.0f) {
-                    v.x = v.x >= 0.f ? v.x : v.x * slope;
-                    v.y = v.y >= 0.f ? v.y : v.y * slope;
-                    v.z = v.z >= 0.f ? v.z : v.z * slope;
-                    v.w = v.w >= 0.f ? v.w : v.w * slope;
-                }
-                const int off = row * 32 + ((((q >> 1) ^ (row >> 3)) & 1) << 4) + ((q & 1) << 3);
-                bf16x4 h, l;
-                h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-                l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-                l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
                 *reinterpret_cast<bf16x4*>(xs_hi + off) = h;
                 *reinterpret_cast<bf16x4*>(xs_lo + off) = l;
             }
@@ -162,22 +173,33 @@ __global__ __launch_bounds__(64) void conv_cl_small_kernel(const ClSmallParams k
         if (tap < ntaps) mfma_frags(fa);
     };
 
-    // ---- pipeline: DMA `ahead` chunks in front, conversion one chunk in front of the MFMAs -------------------------------------------------
-    const int per = 2 * ntaps + kp.xg;      // loads retire in order, `per` of them per chunk
-    const int ahead = kp.ahead;
-    for (int c = 0; c < min(ahead, nchunks); ++c) stage(c);
-    wait_vm_dyn(nchunks > ahead - 1 ? (ahead - 1) * per : 0);     // chunk 0 has landed
-    convert(0);
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + ahead < nchunks) {
-            stage(c + ahead);                // slot of chunk c + ahead - 4 <= c - 1: read by the MFMAs / conversion of earlier passes
-            wait_vm_dyn((ahead - 1) * per);  // all but the newest ahead - 1 chunks: chunk c + 1 has landed
-        } else {
-            wait_vm_dyn(0);
-        }
-        if (c + 1 < nchunks) convert(c + 1);
-        mma_chunk(c);
+    // ---- pipeline --------------------------------------------------------------------------------------------------------------------------
+    // One raw barrier per chunk (__syncthreads would drain the DMAs in flight with vmcnt(0)).  After barrier B(c): the raw chunk c + 1 has
+    // landed (every loader waited for ITS loads: they retire in order, `per` of them per chunk and wave) and the window of chunk c is
+    // converted.  Between B(c) and B(c + 1) wave 0 runs the MFMAs of chunk c while the loaders convert the window of chunk c + 1 and issue
+    // the DMAs of one more chunk, into a slot that holds neither chunk c nor c + 1 (2 <= ahead < kSlots).
+    const int per = wave == 0 ? 0 : (nload - (wave - 1) + kLoaders - 1) / kLoaders;
+    int issued = 0;
+    if (wave != 0) {
+        for (; issued < min(kp.ahead, nchunks); ++issued) stage(issued);
+        wait_vm_dyn((issued - 1) * per);                       // chunk 0
     }
+    __builtin_amdgcn_s_barrier();
+    if (wave != 0) convert(0);
+    for (int c = 0; c < nchunks; ++c) {
+        if (wave != 0) wait_vm_dyn(max(issued - c - 2, 0) * per);   // chunk c + 1 (or everything, at the tail)
+        __builtin_amdgcn_s_barrier();                           // B(c)
+        if (wave == 0) {
+            mma_chunk(c);
+        } else {
+            if (issued < nchunks) {
+                stage(issued);
+                ++issued;
+            }
+            if (c + 1 < nchunks) convert(c + 1);
+        }
+    }
+    if (wave != 0) return;
 
     // ---- epilogue: conv_cl.hip's k-major form ------------------------------------------------------------------------------------------------
     int nn[TN];
@@ -251,7 +273,8 @@ bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t str
     kp.mask_shift = mask_shift;
     kp.slot_bytes = p.ntaps * 2048 + kp.xg * 1024;
     const int per = 2 * p.ntaps + kp.xg;
-    kp.ahead = std::max(1, std::min(kSlots - 1, 62 / per));
+    static const int ahead_max = getenv("SBV2_CLS_AHEAD") ? atoi(getenv("SBV2_CLS_AHEAD")) : 4;   // experiments
+    kp.ahead = std::max(2, std::min(kSlots - 2, ahead_max));   // per-wave outstanding loads stay far below the 6-bit vmcnt: ahead * ceil(30 / 3)
     const size_t lds = (size_t)kSlots * kp.slot_bytes + 4 * (size_t)kp.xrows * 32;
     if (lds > 160 * 1024) return false;
     auto kern = conv_cl_small_kernel<TN>;
@@ -268,7 +291,7 @@ bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t str
         HIP_CHECK(hipEventRecord(e0, stream));
     }
     dim3 grid((p.N + 32 * TN - 1) / (32 * TN), p.nmt);
-    hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, kp);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * (kLoaders + 1)), lds, stream, kp);
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));

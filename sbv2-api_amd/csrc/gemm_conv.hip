@@ -531,7 +531,10 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         // ... and 64-channel chunks: a workgroup of a small grid is alone on its CU, its K loop is a chain of global round trips
         // (two chunks in flight: ~0.7 us per 16-channel chunk whatever the MFMA work), so it asks for four times as much per trip
         // ... superseded where it applies by one-wave 16 x 16 tiles fed through an LDS-DMA ring (gemm_skinny.hip: same bits, see there)
-        if (blocks(64, 64) < g_skinny_max.load(std::memory_order_relaxed) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
+        // (long products pay the tiled kernel's per-chunk round trip 64 times or more: the FFN-up Linear of DeBERTa at 66 tokens, 128 workgroups,
+        // is 43 us tiled, 28 us as 1280 single waves)
+        const int skinny_max = g_skinny_max.load(std::memory_order_relaxed);
+        if (blocks(64, 64) < (p.K >= 512 ? skinny_max + skinny_max / 2 : skinny_max) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
         if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 64>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
     }

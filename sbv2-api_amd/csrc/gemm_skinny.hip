@@ -24,7 +24,6 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-constexpr int kStages = 16;   // ring slots (16 k each)
 
 struct SkinnyParams {
     ConvParams p;
@@ -37,7 +36,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TN>
+template <int TN, int kStages>
 __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyParams kp) {
     const ConvParams& p = kp.p;
     constexpr int SB = (1 + TN) * 1024;   // bytes per ring slot
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyParams kp) 
     }
 }
 
-template <int TN>
+template <int TN, int kStages>
 void launch_skinny(const SkinnyParams& kp, hipStream_t stream) {
     const ConvParams& p = kp.p;
     dim3 grid((p.N + 16 * TN - 1) / (16 * TN), (p.M + 15) / 16);
@@ -174,7 +173,13 @@ void launch_skinny(const SkinnyParams& kp, hipStream_t stream) {
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(gemm_skinny_kernel<TN>, grid, dim3(64), kStages * (1 + TN) * 1024, stream, kp);
+    auto kern = gemm_skinny_kernel<TN, kStages>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64), kStages * (1 + TN) * 1024, stream, kp);
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -193,8 +198,13 @@ bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream)
     kp.mask_shift = mask_shift;
     // one wave per 16 x 16 tile while that is at most one wave per SIMD of the chip; 16 x 32 tiles beyond
     const int64_t waves = (int64_t)((p.M + 15) / 16) * ((p.N + 15) / 16);
-    if (waves <= 1024) launch_skinny<1>(kp, stream);
-    else launch_skinny<2>(kp, stream);
+    static const int deep = getenv("SBV2_SKINNY_DEEP") ? atoi(getenv("SBV2_SKINNY_DEEP")) : 0;   // experiments
+    if (waves <= 1024) {
+        if (deep && waves <= 512) launch_skinny<1, 32>(kp, stream);
+        else launch_skinny<1, 16>(kp, stream);
+    } else {
+        launch_skinny<2, 16>(kp, stream);
+    }
     return true;
 }
 
