@@ -190,7 +190,8 @@ struct ConvParams {
 void launch_conv(const ConvParams& p, hipStream_t stream);
 int set_skinny_max(int workgroups);   // returns the previous threshold
 int small_grid_max();                 // workgroup count under which the small-grid kernels (gemm_skinny, conv_cl_small) take over; 0 = never
-bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream);   // gemm_skinny.hip: small-grid 1x1 products
+bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream);
+bool launch_gemm_skinny_taps(const ConvParams& p, int mask_shift, hipStream_t stream);   // gemm_skinny.hip: small-grid 1x1 products
 void conv_prof_begin();
 std::string conv_prof_end();
 bool conv_prof_active();

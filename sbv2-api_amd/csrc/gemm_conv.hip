@@ -538,6 +538,7 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 64>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
     }
+    if (blocks(64, 64) < g_skinny_max.load(std::memory_order_relaxed) && launch_gemm_skinny_taps(p, kp.mask_shift, stream)) return;
     if (blocks(64, 256) >= 512) return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
     if (blocks(64, 128) >= 256) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
     return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);

@@ -36,6 +36,53 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- epilogue: the arithmetic of gemm_conv.hip's, element for element; every global read before the first store -------------------------
+template <int TN>
+__device__ __forceinline__ void skinny_epilogue(const SkinnyParams& kp, const f32x4s (&acc)[TN], int m0, int n0, int lane) {
+    const ConvParams& p = kp.p;
+    const int M = p.M, N = p.N;
+    const float* Rg = p.R;
+    float rr[TN][4], old[TN][4], bcol[TN], brow[4];
+    unsigned char keep[TN];
+    const int mbase = m0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) brow[r] = (p.bias_mode == BIAS_ROW) ? p.bias[min(mbase + r, M - 1)] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int n = min(n0 + t * 16 + (lane & 15), N - 1);
+        bcol[t] = (p.bias_mode == BIAS_COL) ? p.bias[n] : 0.f;
+        keep[t] = 1;
+        if (p.mask) keep[t] = p.mask[kp.mask_shift >= 0 ? (n >> kp.mask_shift) : (n / p.mask_div)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = min(mbase + r, M - 1);
+            rr[t][r] = Rg ? Rg[(int64_t)m * p.ldr + n] : 0.f;
+            old[t][r] = p.accumulate ? p.C[(int64_t)m * p.ldc + n] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int n = n0 + t * 16 + (lane & 15);
+        if (n >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mbase + r;
+            if (m >= M) continue;
+            float v = acc[t][r] + brow[r];
+            if (p.bias_mode == BIAS_COL) v += bcol[t];
+            if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            else if (p.act == ACT_TANH) v = tanhf(v);
+            v *= p.alpha;
+            if (Rg) v += rr[t][r];
+            v *= p.beta;
+            if (p.accumulate) v += old[t][r];
+            if (!keep[t]) v = 0.f;
+            p.C[(int64_t)m * p.ldc + n] = v;
+        }
+    }
+}
+
 template <int TN, int kStages>
 __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyParams kp) {
     const ConvParams& p = kp.p;
@@ -119,47 +166,97 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyParams kp) 
         cur = nxt;
     }
 
-    // ---- epilogue: the arithmetic of gemm_conv.hip's, element for element; every global read before the first store ---------------------
-    const float* Rg = p.R;
-    float rr[TN][4], old[TN][4], bcol[TN], brow[4];
-    unsigned char keep[TN];
-    const int mbase = m0 + (lane >> 4) * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) brow[r] = (p.bias_mode == BIAS_ROW) ? p.bias[min(mbase + r, M - 1)] : 0.f;
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int n = min(n0 + t * 16 + (lane & 15), N - 1);
-        bcol[t] = (p.bias_mode == BIAS_COL) ? p.bias[n] : 0.f;
-        keep[t] = 1;
-        if (p.mask) keep[t] = p.mask[kp.mask_shift >= 0 ? (n >> kp.mask_shift) : (n / p.mask_div)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = min(mbase + r, M - 1);
-            rr[t][r] = Rg ? Rg[(int64_t)m * p.ldr + n] : 0.f;
-            old[t][r] = p.accumulate ? p.C[(int64_t)m * p.ldc + n] : 0.f;
-        }
+    skinny_epilogue<TN>(kp, acc, m0, n0, lane);
+}
+
+// ---- k > 1 (the k = 3 convolutions of the text encoder's FFN and of the duration predictors: 15-60 workgroups tiled, 40-180 us) ----------
+// Same chain order as the tiled kernel: chunk (16 k) outermost, then tap, then k.  Per chunk the ring slot holds ntaps weight tiles
+// [16 k][16 m] and ONE window [16 k][W columns] that starts at the 16-byte aligned column w0 <= n0 + min shift (W = 32 or 64: 8 or 16
+// lanes x 16 bytes per row, so a DMA covers 8 or 4 rows); tap t reads it at column offset shift_t - (w0 - n0).  Columns outside [0, nb)
+// are zero by contract: their DMA source is redirected to a readable address and the operand is masked at the read.
+struct SkinnyTapParams {
+    ConvParams p;
+    int mask_shift;
+    int W;           // window pitch in floats (32 or 64)
+    int w0_rel;      // w0 - n0 (<= min shift, multiple of 4)
+    int slot_bytes;  // ntaps KB + W / 16 KB
+    int ahead;       // chunks in flight
+};
+constexpr int kTapSlots = 8;
+
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    switch (n) {   // s_waitcnt takes an immediate; n is wave-uniform
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15)
+        W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31)
+        W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47)
+        W_(48) W_(49) W_(50) W_(51) W_(52) W_(53) W_(54) W_(55) W_(56) W_(57) W_(58) W_(59) W_(60) W_(61) W_(62)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+}
+
+__global__ __launch_bounds__(64) void gemm_skinny_taps_kernel(const SkinnyTapParams kp) {
+    const ConvParams& p = kp.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int M = p.M, nb = p.nb, ntaps = p.ntaps, W = kp.W;
+    const int nch = p.K >> 4;
+    const int wbytes = ntaps * 1024;
+    const int xg = W >> 4;                      // DMAs per window
+    const int per = ntaps + xg;
+    // weights: row (lane >> 2) of the chunk, floats 4 * (lane & 3) ..; window: row g * (256 / W) + lane / (W / 4), floats 4 * (lane % (W / 4)) ..
+    const float* asrc = p.A + (int64_t)(lane >> 2) * p.lda + (m0 + (lane & 3) * 4 < M ? m0 + (lane & 3) * 4 : 0);
+    const int lpr = W >> 2, rpg = 64 / lpr;     // lanes per row, rows per DMA
+    const int xrow = lane / lpr;
+    int xcol = n0 + kp.w0_rel + (lane % lpr) * 4;
+    if (xcol < 0 || xcol + 3 >= p.ldb) xcol = 0;
+    const float* bsrc = p.B + (int64_t)xrow * p.ldb + xcol;
+    auto stage = [&](int c) {
+        char* dst = smem + (c & (kTapSlots - 1)) * kp.slot_bytes;
+        for (int t = 0; t < ntaps; ++t)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc + (int64_t)t * p.a_tap_stride + (int64_t)c * 16 * p.lda), (lds_void_t*)(dst + t * 1024), 16, 0, 0);
+        for (int g = 0; g < xg; ++g)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc + ((int64_t)c * 16 + g * rpg) * p.ldb), (lds_void_t*)(dst + wbytes + g * 1024), 16, 0, 0);
+    };
+    f32x4s acc[1];
+    acc[0] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    const float slope = p.pre_slope;
+    const int krow = lane >> 4, lcol = lane & 15;
+    auto mma_chunk = [&](int c) {
+        const float* sl = reinterpret_cast<const float*>(smem + (c & (kTapSlots - 1)) * kp.slot_bytes);
+        const float* xw = sl + (wbytes >> 2);
+        for (int t = 0; t < ntaps; ++t) {
+            const int off = p.shift[t] - kp.w0_rel + lcol;          // column inside the window
+            const int g = n0 + kp.w0_rel + off;                       // global column
+            const bool ok = g >= 0 && g < nb;
+            float a[4], b[4];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int n = n0 + t * 16 + (lane & 15);
-        if (n >= N) continue;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                a[s4] = sl[t * 256 + 64 * s4 + lane];
+                b[s4] = xw[(4 * s4 + krow) * W + off];
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mbase + r;
-            if (m >= M) continue;
-            float v = acc[t][r] + brow[r];
-            if (p.bias_mode == BIAS_COL) v += bcol[t];
-            if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-            else if (p.act == ACT_TANH) v = tanhf(v);
-            v *= p.alpha;
-            if (Rg) v += rr[t][r];
-            v *= p.beta;
-            if (p.accumulate) v += old[t][r];
-            if (!keep[t]) v = 0.f;
-            p.C[(int64_t)m * p.ldc + n] = v;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float bv = ok ? b[s4] : 0.f;
+                if (slope != 1.0f) bv = bv >= 0.f ? bv : bv * slope;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], bv, acc[0], 0, 0, 0);
+            }
         }
+    };
+    const int ahead = kp.ahead;
+    int issued = 0;
+    for (; issued < min(ahead, nch); ++issued) stage(issued);
+    for (int c = 0; c < nch; ++c) {
+        if (issued < nch) {
+            stage(issued);        // slot of chunk issued - 8 < c: consumed by the MFMAs of an earlier pass
+            ++issued;
+        }
+        wait_vm_dyn((issued - c - 1) * per);    // loads retire in order: chunk c has landed
+        mma_chunk(c);
     }
+    skinny_epilogue<1>(SkinnyParams{kp.p, kp.mask_shift}, acc, m0, n0, lane);
 }
 
 template <int TN, int kStages>
@@ -204,6 +301,48 @@ bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream)
         else launch_skinny<1, 16>(kp, stream);
     } else {
         launch_skinny<2, 16>(kp, stream);
+    }
+    return true;
+}
+
+// k > 1 twin; same contract
+bool launch_gemm_skinny_taps(const ConvParams& p, int mask_shift, hipStream_t stream) {
+    if (p.ntaps < 2 || p.groups || (p.K & 15) != 0 || p.K < 16 || p.phase_rows < (1 << 30)) return false;
+    if ((p.lda & 3) != 0 || (p.ldb & 3) != 0 || (p.a_tap_stride & 3) != 0) return false;
+    int smin = p.shift[0], smax = p.shift[0];
+    for (int t = 1; t < p.ntaps; ++t) {
+        smin = std::min(smin, p.shift[t]);
+        smax = std::max(smax, p.shift[t]);
+    }
+    SkinnyTapParams kp;
+    kp.p = p;
+    kp.mask_shift = mask_shift;
+    kp.w0_rel = (smin >= 0) ? (smin / 4) * 4 : -(((-smin) + 3) / 4) * 4;
+    const int need = 16 + smax - kp.w0_rel;            // columns w0 .. n0 + 15 + max shift
+    if (need > 64) return false;
+    kp.W = need <= 32 ? 32 : 64;
+    kp.slot_bytes = p.ntaps * 1024 + (kp.W / 16) * 1024;
+    const int per = p.ntaps + kp.W / 16;
+    kp.ahead = std::max(1, std::min(kTapSlots - 1, 62 / per));
+    dim3 grid((p.N + 15) / 16, (p.M + 15) / 16);
+    if ((int64_t)grid.x * grid.y > 2048) return false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = conv_prof_active();
+    if (prof) {
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_taps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_skinny_taps_kernel, grid, dim3(64), kTapSlots * kp.slot_bytes, stream, kp);
+    HIP_CHECK(hipGetLastError());
+    if (prof) {
+        HIP_CHECK(hipEventRecord(e1, stream));
+        conv_prof_add(23, 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
     }
     return true;
 }

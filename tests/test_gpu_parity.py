@@ -43,26 +43,28 @@ def test_conv1d_kernel(cin, cout, k, dil, L):
         np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("cin,cout,L", [(1024, 1024, 66), (1024, 3072, 130), (4096, 1024, 66), (1024, 4096, 35), (192, 576, 897), (768, 192, 897),
-                                        (192, 29, 300), (96, 192, 4), (1024, 192, 130), (64, 50, 19)])
-def test_gemm_small_grid_kernel_same_bits(cin, cout, L):
-    """The one-wave 16 x 16 kernel of small grids (gemm_skinny.hip) and the tiled kernel give the SAME bits (every f32 MFMA shape is a
+@pytest.mark.parametrize("cin,cout,k,dil,L", [(1024, 1024, 1, 1, 66), (1024, 3072, 1, 1, 130), (4096, 1024, 1, 1, 66), (1024, 4096, 1, 1, 35),
+                                              (192, 576, 1, 1, 897), (768, 192, 1, 1, 897), (192, 29, 1, 1, 300), (96, 192, 1, 1, 4), (1024, 192, 1, 1, 130),
+                                              (64, 50, 1, 1, 19), (192, 768, 3, 1, 257), (768, 192, 3, 1, 257), (256, 256, 3, 1, 130), (192, 192, 5, 1, 61),
+                                              (64, 48, 3, 3, 100), (96, 64, 7, 5, 33), (192, 192, 3, 1, 9)])
+def test_gemm_small_grid_kernel_same_bits(cin, cout, k, dil, L):
+    """The one-wave 16 x 16 kernels of small grids (gemm_skinny.hip) and the tiled kernel give the SAME bits (every f32 MFMA shape is a
     sequential fma chain over k), which is what keeps a batch row bit-identical to the single call of the same utterance."""
-    rng = np.random.default_rng(cin + cout + L)
+    rng = np.random.default_rng(cin + cout + L + k)
     x = rng.standard_normal((cin, L)).astype(np.float32)
-    w = (rng.standard_normal((cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     lib = _lib.lib()
     for slope in (1.0, 0.1):
         prev = lib.sbv2_debug_set_skinny_max(0)
         try:
-            tiled = _conv_dev(x, w, b, 1, slope)
+            tiled = _conv_dev(x, w, b, dil, slope)
             lib.sbv2_debug_set_skinny_max(1 << 30)
-            skinny = _conv_dev(x, w, b, 1, slope)
+            skinny = _conv_dev(x, w, b, dil, slope)
         finally:
             lib.sbv2_debug_set_skinny_max(prev)
         assert np.array_equal(tiled.view(np.uint32), skinny.view(np.uint32)), f"{int((tiled != skinny).sum())} of {tiled.size} differ"
-        np.testing.assert_allclose(skinny, O.conv1d_same(O.leaky_relu(x, slope), w, b, 1), atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(skinny, O.conv1d_same(O.leaky_relu(x, slope), w, b, dil), atol=2e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("cin,cout,k,s,p,L", [(64, 32, 16, 8, 4, 301), (32, 16, 8, 2, 3, 1000), (16, 8, 2, 2, 0, 999),
