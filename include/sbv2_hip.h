@@ -134,6 +134,10 @@ int sbv2_parse_sbv2file(const uint8_t* sbv2_bytes, size_t len, uint8_t** style_v
 void sbv2_bytes_free(uint8_t* p);
 /* style.rs:11-17 `load_style`: {"shape": [n, dim], "data": [[..], ..]} -> owned f32 [n][dim] (release with sbv2_bytes_free) */
 int sbv2_style_load(const uint8_t* json, size_t len, float** data, int64_t* n, int64_t* dim);
+/* tts.rs:84-124 `load_aivmx` (cargo feature "aivmx"): the bytes are the VITS ONNX model itself (hand them to sbv2_vits_create); the style
+ * table is ModelProto.metadata_props["aivm_style_vectors"] = base64(.npy, 2-D float32, C or Fortran order) -> owned f32 [n][dim]
+ * (sbv2_bytes_free).  Errors: key absent; not 2-D ("expected 2D array", the reference's panic); not float32. */
+int sbv2_aivmx_style_vectors(const uint8_t* aivmx_bytes, size_t len, float** data, int64_t* n, int64_t* dim);
 /* style.rs:19-28 `get_style_vector`: out[dim] = mean + (style_vectors[style_id] - mean) * weight, mean = row 0 */
 int sbv2_style_vector(const float* style_vectors, int64_t n, int64_t dim, int64_t style_id, float weight, float* out);
 

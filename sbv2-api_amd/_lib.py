@@ -81,6 +81,7 @@ SYMBOLS = {
     "sbv2_parse_sbv2file": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sbv2_bytes_free": (None, [C.c_void_p]),
     "sbv2_style_load": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), i64p, i64p]),
+    "sbv2_aivmx_style_vectors": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), i64p, i64p]),
     "sbv2_style_vector": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int64, C.c_float, f32p]),
     "sbv2_debug_import_to_container": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sbv2_debug_bucket_table": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),

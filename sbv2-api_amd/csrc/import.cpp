@@ -713,6 +713,120 @@ int sbv2_style_load(const uint8_t* json, size_t len, float** data, int64_t* n, i
     API_END
 }
 
+// tts.rs:84-124 `load_aivmx`: an .aivmx file IS the VITS ONNX model; its ModelProto.metadata_props (field 14, StringStringEntryProto
+// {key = 1, value = 2}) carry "aivm_style_vectors" = base64(.npy of a 2-D float32 array).  The reference reads it through ort's
+// ModelMetadata::custom + base64 + npyz (all absent here): restated from the published formats (RFC 4648 base64; NumPy .npy v1 / v2 / v3:
+// "\x93NUMPY", version, header length (u16 or u32 LE), a Python dict literal with 'descr', 'fortran_order', 'shape').
+namespace {
+std::vector<uint8_t> base64_decode(const Span s) {
+    std::vector<uint8_t> out;
+    out.reserve(s.n / 4 * 3);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = 0; i < s.n; ++i) {
+        const uint8_t c = s.p[i];
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A';
+        else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+        else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62;
+        else if (c == '/' || c == '_') v = 63;
+        else if (c == '=' || c == '\n' || c == '\r' || c == ' ') continue;
+        else throw Error("aivmx: invalid base64 in aivm_style_vectors");
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out.push_back((uint8_t)(acc >> bits));
+        }
+    }
+    return out;
+}
+}  // namespace
+
+int sbv2_aivmx_style_vectors(const uint8_t* aivmx, size_t len, float** data, int64_t* n, int64_t* dim) {
+    API_BEGIN
+    SBV2_REQUIRE(aivmx && data && n && dim, "bad arguments");
+    Span value;
+    {
+        PB pb(Span{aivmx, len});
+        while (!pb.done()) {
+            uint32_t f, wt;
+            pb.tag(f, wt);
+            if (f == 14 && wt == 2) {
+                PB e(pb.bytes());
+                Span k, v;
+                while (!e.done()) {
+                    uint32_t g, w2;
+                    e.tag(g, w2);
+                    if (g == 1 && w2 == 2) k = e.bytes();
+                    else if (g == 2 && w2 == 2) v = e.bytes();
+                    else e.skip(w2);
+                }
+                if (k.str() == "aivm_style_vectors") value = v;
+            } else {
+                pb.skip(wt);
+            }
+        }
+    }
+    if (!value.p) throw Error("model not found: aivm_style_vectors (the ONNX metadata has no such key)");
+    const std::vector<uint8_t> npy = base64_decode(value);
+    SBV2_REQUIRE(npy.size() >= 10 && std::memcmp(npy.data(), "\x93NUMPY", 6) == 0, "aivmx: aivm_style_vectors is not an .npy file");
+    const int major = npy[6];
+    size_t hlen, hoff;
+    if (major == 1) {
+        hlen = (size_t)npy[8] | ((size_t)npy[9] << 8);
+        hoff = 10;
+    } else {
+        SBV2_REQUIRE(npy.size() >= 12, "aivmx: truncated .npy header");
+        hlen = (size_t)npy[8] | ((size_t)npy[9] << 8) | ((size_t)npy[10] << 16) | ((size_t)npy[11] << 24);
+        hoff = 12;
+    }
+    SBV2_REQUIRE(hoff + hlen <= npy.size(), "aivmx: truncated .npy header");
+    const std::string hdr(reinterpret_cast<const char*>(npy.data() + hoff), hlen);
+    auto field = [&](const char* key) {
+        const size_t p = hdr.find(key);
+        if (p == std::string::npos) throw Error(std::string("aivmx: .npy header has no ") + key);
+        return hdr.find(':', p) + 1;
+    };
+    size_t q = field("'descr'");
+    const size_t d0 = hdr.find('\'', q), d1 = hdr.find('\'', d0 + 1);
+    SBV2_REQUIRE(d0 != std::string::npos && d1 != std::string::npos, "aivmx: malformed .npy descr");
+    const std::string descr = hdr.substr(d0 + 1, d1 - d0 - 1);
+    SBV2_REQUIRE(descr == "<f4" || descr == "|f4" || descr == "=f4", "aivmx: style vectors must be little-endian float32 (got " + descr + ")");
+    q = field("'fortran_order'");
+    const bool fortran = hdr.compare(hdr.find_first_not_of(' ', q), 4, "True") == 0;
+    q = field("'shape'");
+    const size_t s0 = hdr.find('(', q), s1 = hdr.find(')', s0);
+    SBV2_REQUIRE(s0 != std::string::npos && s1 != std::string::npos, "aivmx: malformed .npy shape");
+    std::vector<int64_t> shape;
+    for (size_t i = s0 + 1; i < s1;) {
+        if (hdr[i] >= '0' && hdr[i] <= '9') {
+            char* e;
+            shape.push_back(std::strtoll(hdr.c_str() + i, &e, 10));
+            i = (size_t)(e - hdr.c_str());
+        } else {
+            ++i;
+        }
+    }
+    SBV2_REQUIRE(shape.size() == 2 && shape[0] >= 1 && shape[1] >= 1, "aivmx: expected 2D array");   // the reference panics with this text
+    const size_t count = (size_t)shape[0] * (size_t)shape[1];
+    SBV2_REQUIRE(count <= (npy.size() - hoff - hlen) / 4, "aivmx: .npy data shorter than its shape");
+    float* o = static_cast<float*>(std::malloc(sizeof(float) * count));
+    SBV2_REQUIRE(o, "out of host memory");
+    const uint8_t* src = npy.data() + hoff + hlen;
+    if (!fortran) {
+        std::memcpy(o, src, sizeof(float) * count);
+    } else {   // column-major on disk -> the row-major [n][dim] table sbv2_style_vector reads
+        for (int64_t i = 0; i < shape[0]; ++i)
+            for (int64_t j = 0; j < shape[1]; ++j) std::memcpy(o + i * shape[1] + j, src + 4 * ((size_t)j * shape[0] + i), 4);
+    }
+    *data = o;
+    *n = shape[0];
+    *dim = shape[1];
+    API_END
+}
+
 // style.rs:19-28 `get_style_vector`: mean + (style_vectors[style_id] - mean) * weight, mean = row 0
 int sbv2_style_vector(const float* style_vectors, int64_t n, int64_t dim, int64_t style_id, float weight, float* out) {
     API_BEGIN

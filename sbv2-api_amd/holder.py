@@ -38,6 +38,19 @@ def parse_sbv2file(sbv2_bytes: bytes):
         l.sbv2_bytes_free(b)
 
 
+def aivmx_style_vectors(aivmx_bytes: bytes):
+    """tts.rs:92-108 through the C ABI: the style table stored in an .aivmx (= ONNX) file's metadata -> float32 [n, dim]."""
+    import numpy as np
+    l = _lib.lib()
+    d, n, dim = C.c_void_p(), C.c_int64(), C.c_int64()
+    buf = (C.c_char * len(aivmx_bytes)).from_buffer_copy(aivmx_bytes)
+    _lib.check(l.sbv2_aivmx_style_vectors(C.cast(buf, C.c_void_p), len(aivmx_bytes), C.byref(d), C.byref(n), C.byref(dim)))
+    try:
+        return np.ctypeslib.as_array(C.cast(d, C.POINTER(C.c_float)), shape=(n.value, dim.value)).copy()
+    finally:
+        l.sbv2_bytes_free(d)
+
+
 class _TTSModel:
     """tts.rs:32-38"""
 
@@ -81,6 +94,18 @@ class TTSModelHolder:
         sess = self._load_session(vits2_bytes, False) if do_load else None
         sv = orchestrator.load_style(style_vectors_bytes)
         self.models_.append(_TTSModel(ident, sess, sv, bytes(vits2_bytes) if self.max_loaded_models is not None else None))
+
+    # ---- tts.rs:77-130 (cargo feature "aivmx"): same cache rules as load(); the style table comes out of the model file itself
+    def load_aivmx(self, ident: str, aivmx_bytes: bytes):
+        try:
+            self._find(ident)
+            return
+        except ModelNotFoundError:
+            pass
+        do_load = self.max_loaded_models is None or self._resident() < self.max_loaded_models
+        sv = aivmx_style_vectors(aivmx_bytes)
+        sess = self._load_session(aivmx_bytes, False) if do_load else None
+        self.models_.append(_TTSModel(ident, sess, sv, bytes(aivmx_bytes) if self.max_loaded_models is not None else None))
 
     # ---- tts.rs:132-140
     def load_sbv2file(self, ident: str, sbv2_bytes: bytes):

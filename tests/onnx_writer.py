@@ -71,9 +71,30 @@ def node_proto(op: str, inputs, outputs, attrs=(), name="") -> bytes:
     return out + b"".join(_ld(5, a) for a in attrs)
 
 
-def model_proto(nodes, initializers) -> bytes:
+def model_proto(nodes, initializers, metadata=None) -> bytes:
     graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"main_graph") + b"".join(_ld(5, t) for t in initializers)
-    return _key(1, 0) + _varint(8) + _ld(2, b"pytorch") + _ld(3, b"2.5.0") + _ld(7, graph)
+    out = _key(1, 0) + _varint(8) + _ld(2, b"pytorch") + _ld(3, b"2.5.0") + _ld(7, graph)
+    for k, v in (metadata or {}).items():      # ModelProto.metadata_props = 14: StringStringEntryProto {key = 1, value = 2}
+        out += _ld(14, _ld(1, k.encode()) + _ld(2, v if isinstance(v, bytes) else v.encode()))
+    return out
+
+
+def add_metadata(model: bytes, metadata: dict) -> bytes:
+    """Appends metadata_props entries to a serialized ModelProto (protobuf messages concatenate)."""
+    return model + model_proto([], [], metadata)[len(model_proto([], [])):]
+
+
+def aivm_style_vectors(a, fortran=False, version=1) -> str:
+    """The value AivisSpeech's converter stores under "aivm_style_vectors": base64 of np.save(style_vectors) (tts.rs:94-108 reads it back
+    with npyz).  Written by hand so that both memory orders and both header versions can be produced."""
+    import base64
+    a = np.asarray(a, np.float32)
+    hdr = "{'descr': '<f4', 'fortran_order': %s, 'shape': (%s), }" % ("True" if fortran else "False", ", ".join(str(d) for d in a.shape) + ("," if a.ndim == 1 else ""))
+    pre = 10 if version == 1 else 12
+    pad = 64 - (pre + len(hdr) + 1) % 64
+    hdr = hdr + " " * pad + "\n"
+    head = b"\x93NUMPY" + bytes([version, 0]) + (struct.pack("<H", len(hdr)) if version == 1 else struct.pack("<I", len(hdr)))
+    return base64.b64encode(head + hdr.encode("latin1") + a.tobytes(order="F" if fortran else "C")).decode()
 
 
 class _Anon:

@@ -234,6 +234,20 @@ def test_model_holder_cache_semantics():
     assert _FakeSession.live == 0
 
 
+def test_model_holder_load_aivmx():
+    """tts.rs:77-130: an .aivmx entry gets its style table from the ONNX metadata and follows the same cache rules as load()."""
+    import onnx_writer as OW
+    sv = np.arange(12, dtype=np.float32).reshape(3, 4)
+    aivmx = OW.model_proto([], [], {"aivm_style_vectors": OW.aivm_style_vectors(sv, fortran=True)})
+    h = _holder(1)
+    h.load_aivmx("x", aivmx); h.load_aivmx("y", aivmx); h.load_aivmx("x", b"ignored: the ident exists")
+    assert h.models() == ["x", "y"] and [m.vits2 is not None for m in h.models_] == [True, False] and _FakeSession.live == 1
+    assert h._find("x").vits2.data == aivmx and h._find("y").bytes == aivmx
+    np.testing.assert_array_equal(h.get_style_vector("y", 2, 1.0), sv[2])
+    np.testing.assert_array_equal(h.get_style_vector("y", 2, 0.5), sv[0] + (sv[2] - sv[0]) * 0.5)
+    h.close()
+
+
 def test_rest_contract():
     """main.rs:24-100,192-196 + error.rs:10-18: routes, JSON defaults, audio/wav, 'Something went wrong: ...' with status 500."""
     from fastapi.testclient import TestClient

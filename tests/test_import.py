@@ -107,6 +107,35 @@ def test_sbv2_container_round_trip_and_errors():
         _import(OW.model_proto([], [OW.tensor_proto("enc_p.emb.weight", np.zeros((4, 8), np.float32))]), 2)
 
 
+@pytest.mark.parametrize("fortran,version", [(False, 1), (True, 1), (False, 2)])
+def test_aivmx_style_vectors_from_onnx_metadata(fortran, version):
+    """tts.rs:92-108: an .aivmx file is the ONNX model plus metadata_props["aivm_style_vectors"] = base64(.npy).  Cross-checked against
+    numpy's own reader (np.load of the decoded bytes), then the same file is imported as a model: the metadata must not disturb the weights."""
+    import base64, io
+    from sbv2_api_amd import holder
+    vc = O.VITS_TINY
+    W = synth.make_vits_weights(vc, 3)
+    sv = np.random.default_rng(9).standard_normal((5, vc["gin"])).astype(np.float32)
+    b64 = OW.aivm_style_vectors(sv, fortran=fortran, version=version)
+    np.testing.assert_array_equal(np.load(io.BytesIO(base64.b64decode(b64))), sv)        # the hand-written .npy is a valid one
+    aivmx = OW.add_metadata(OW.vits_onnx(W, vc, folded=True), {"aivm_name": "builder-authored", "aivm_style_vectors": b64})
+    got = holder.aivmx_style_vectors(aivmx)
+    assert got.dtype == np.float32 and got.shape == sv.shape
+    np.testing.assert_array_equal(got, sv)
+    kind, _, tensors = _import(aivmx, 2)
+    assert kind == 2
+    _same_weights(tensors, W, exact=True)
+    # error paths: no such key; not 2-D (the reference panics "expected 2D array"); not float32
+    with pytest.raises(_lib.Sbv2Error, match="aivm_style_vectors"):
+        holder.aivmx_style_vectors(OW.vits_onnx(W, vc, folded=True))
+    bad = OW.add_metadata(OW.vits_onnx(W, vc, folded=True), {"aivm_style_vectors": OW.aivm_style_vectors(sv[0])})
+    with pytest.raises(_lib.Sbv2Error, match="expected 2D array"):
+        holder.aivmx_style_vectors(bad)
+    junk = OW.add_metadata(OW.vits_onnx(W, vc, folded=True), {"aivm_style_vectors": base64.b64encode(b"not an npy file at all").decode()})
+    with pytest.raises(_lib.Sbv2Error, match="npy"):
+        holder.aivmx_style_vectors(junk)
+
+
 @pytest.mark.gpu
 def test_imported_models_synthesise_identically():
     """A synthetic .sbv2 + deberta.onnx round-trip to bit-identical device weights: the pipeline output equals the SBV2W001 path's."""
