@@ -2,7 +2,7 @@
 // common.cpp (SBV2W001 container, config JSON helpers) and import.cpp (ONNX protobuf, tar, zstd, style JSON) are compiled with plain g++
 // -fsanitize=address,undefined (no device code, no GPU call is reached) and fed (a) the valid files the Python test wrote and (b) a few
 // thousand mutations of them: truncations, byte flips, overwritten length fields.  Any outcome but "parsed" or "sbv2::Error" aborts under the
-// sanitizers.   usage: host_asan <dir with container.bin vits.onnx bert.onnx model.sbv2 style.json> <iterations>
+// sanitizers.   usage: host_asan <dir with container.bin vits.onnx bert.onnx model.sbv2 style.json style.aivmx> <iterations>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -115,6 +115,32 @@ int main(int argc, char** argv) {
         if (sbv2_parse_sbv2file(sb.data(), sb.size(), &a, &an, &b, &bn) != 0) return 5;
         sbv2_bytes_free(a);
         sbv2_bytes_free(b);
+    }
+    // tts.rs:92-108 mirror: metadata_props -> base64 -> .npy, on a valid file (small ONNX with only metadata) and on mutations of it
+    {
+        const std::vector<uint8_t> av = slurp(d + "style.aivmx");
+        float* data = nullptr;
+        int64_t n = 0, dim = 0;
+        if (sbv2_aivmx_style_vectors(av.data(), av.size(), &data, &n, &dim) != 0 || n < 1 || dim < 1) return 6;
+        sbv2_bytes_free(reinterpret_cast<uint8_t*>(data));
+        for (int it = 0; it < iters; ++it) {
+            std::vector<uint8_t> m(av);
+            switch (rnd() % 3) {
+                case 0: m.resize((size_t)(rnd() % (m.size() + 1))); break;
+                case 1: for (int k = 0; k < 1 + (int)(rnd() % 8); ++k) m[(size_t)(rnd() % m.size())] ^= (uint8_t)(1u << (rnd() % 8)); break;
+                default: {   // damage the .npy header inside the base64 text: overwrite a run with valid base64 characters
+                    const size_t pos = (size_t)(rnd() % m.size());
+                    for (size_t k = pos; k < std::min(m.size(), pos + 1 + (size_t)(rnd() % 24)); ++k) m[k] = (uint8_t)("AQgw/+9z"[rnd() % 8]);
+                }
+            }
+            if (m.empty()) m.push_back(0);
+            if (sbv2_aivmx_style_vectors(m.data(), m.size(), &data, &n, &dim) == 0) {
+                sbv2_bytes_free(reinterpret_cast<uint8_t*>(data));
+                ++parsed;
+            } else {
+                ++rejected;
+            }
+        }
     }
     printf("HOST_ASAN_OK parsed=%d rejected=%d\n", parsed, rejected);
     return 0;

@@ -207,7 +207,8 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
     sv = np.random.default_rng(1).standard_normal((3, cfg["style_dim"])).astype(np.float32)
     onnx = OW.vits_onnx(W, cfg, folded=False)
     files = {"container.bin": synth.pack_blob(synth.KIND_VITS, cfg, W), "vits.onnx": OW.vits_onnx(W, cfg, folded=True),
-             "bert.onnx": OW.deberta_onnx(BW, bc), "model.sbv2": OW.sbv2_file(onnx, OW.style_json(sv)), "style.json": OW.style_json(sv)}
+             "bert.onnx": OW.deberta_onnx(BW, bc), "model.sbv2": OW.sbv2_file(onnx, OW.style_json(sv)), "style.json": OW.style_json(sv),
+             "style.aivmx": OW.model_proto([], [], {"aivm_name": "x", "aivm_style_vectors": OW.aivm_style_vectors(sv, fortran=True, version=2)})}
     for name, data in files.items():
         open(os.path.join(tmp_path, name), "wb").write(data)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
