@@ -237,10 +237,12 @@ def main():
                 import csv
                 import glob
                 pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))[-1]
-                want = {"conv_cl<2,split-bf16>": ("conv_cl_kernel<2, 1, false, false>", "conv_cl_kernel<2, true, false, false>"),
-                        "conv_cl<1,split-bf16>": ("conv_cl_kernel<1, 1, false, false>", "conv_cl_kernel<1, true, false, false>"),
-                        "conv_cl<2,bf16>": ("conv_cl_kernel<2, 0, false, false>", "conv_cl_kernel<2, false, false, false>"),
-                        "conv_cl<2,f16>": ("conv_cl_kernel<2, 2, false, false>",),
+                # (prefixes: the kernel's last template argument is the row-group count WM; the CSV is sorted by total time, the first match
+                # is the variant that dominates)
+                want = {"conv_cl<2,split-bf16>": ("conv_cl_kernel<2, 1, false, false", "conv_cl_kernel<2, true, false, false"),
+                        "conv_cl<1,split-bf16>": ("conv_cl_kernel<1, 1, false, false", "conv_cl_kernel<1, true, false, false"),
+                        "conv_cl<2,bf16>": ("conv_cl_kernel<2, 0, false, false", "conv_cl_kernel<2, false, false, false"),
+                        "conv_cl<2,f16>": ("conv_cl_kernel<2, 2, false, false",),
                         "conv_gemm<32,2,2,1,4,16>": ("conv_gemm_kernel<32, 2, 2, 1, 4, 16>",),
                         "conv_gemm<32,2,4,2,2,16>": ("conv_gemm_kernel<32, 2, 4, 2, 2, 16>",)}.get(dom["kernel"], ("\0",))
                 for r in csv.DictReader(open(pm)):
@@ -249,6 +251,7 @@ def main():
                         roofline["traffic_unit"] = "bytes per launch (HBM, PMC)"
                         roofline["traffic_measured"] = "offline"
                         roofline["traffic_source"] = os.path.relpath(pm, ROOT)
+                        break
             except Exception:
                 pass
 
