@@ -351,11 +351,8 @@ void deberta_attention128(const AttnGroup* groups, int ngroups, const float* Q, 
                           const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s) {
     if (ngroups <= 0) return;
     constexpr size_t lds = sizeof(float) * (kDbT * kDbPp + 8 * kDbScr + 8 * kDbT + 2 * kDbT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_deberta_attn128), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(k_deberta_attn128), lds_allowed);
     hipLaunchKernelGGL(k_deberta_attn128, dim3(ngroups), dim3(512), lds, s, groups, Q, K, ld, V, posk, posq, ldp, win_lo, wlen, tab,
                        tab_center, span, inv_scale, tok_mask, dh, ctx, ldc);
     HIP_CHECK(hipGetLastError());
@@ -368,11 +365,8 @@ void deberta_attention(const AttnGroup* groups, int ngroups, const float* Q, con
                        const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s) {
     if (ngroups <= 0) return;
     constexpr size_t lds = sizeof(float) * (kDaW * kDaPc + kDaT * kDaPp + 4 * kDaT + 2 * kDaT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_deberta_attn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(k_deberta_attn), lds_allowed);
     hipLaunchKernelGGL(k_deberta_attn, dim3(ngroups), dim3(256), lds, s, groups, Q, K, ld, V, posk, posq, ldp, win_lo, wlen, tab,
                        tab_center, span, inv_scale, tok_mask, dh, ctx, ldc);
     HIP_CHECK(hipGetLastError());

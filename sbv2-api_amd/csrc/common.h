@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -186,6 +188,17 @@ struct ConvParams {
     int maxM = 0, maxN = 0;  // grid extents when grouped
     double flops_hint = 0;   // algorithmic FLOP of a grouped launch (profiling only)
 };
+
+// hipFuncSetAttribute applies to the CURRENT device's copy of a kernel; a process that drives several GPUs (sbv2_node_*, one host thread per
+// device) must raise the dynamic-LDS limit once per (kernel, device), not once per kernel.  `done` is the caller's static per-kernel mask.
+inline void allow_full_lds(const void* kernel, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.fetch_or(bit, std::memory_order_release);
+}
 
 void launch_conv(const ConvParams& p, hipStream_t stream);
 int set_skinny_max(int workgroups);   // returns the previous threshold

@@ -493,11 +493,8 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     lds += pad_lds;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
     auto kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM, WM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     const int ntx = round_up((p.N + kClNT - 1) / kClNT, 8);   // padded so that the (xcd, slot) <-> (tile, row tile) map is a bijection
     dim3 grid(ntx * (kp.nmt / (TM * WM)));
     hipEvent_t e0 = nullptr, e1 = nullptr;

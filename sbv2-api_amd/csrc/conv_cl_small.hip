@@ -278,11 +278,8 @@ bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t str
     const size_t lds = (size_t)kSlots * kp.slot_bytes + 4 * (size_t)kp.xrows * 32;
     if (lds > 160 * 1024) return false;
     auto kern = conv_cl_small_kernel<TN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = conv_prof_active();
     if (prof) {

@@ -466,11 +466,8 @@ static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stre
     const size_t lds = std::max(sizeof(float) * (2 * KC * MT + 2 * KC * xw), sizeof(float) * 4 * 32 * 36);   // staging | epilogue tiles
     dim3 grid((Nx + NT - 1) / NT, (Mx + MT - 1) / MT, p.groups ? p.ngroups : 1);
     auto kern = conv_gemm_kernel<MF, TM, TN, WM, WN, KC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     ProfRec rec;
     if (g_prof_on) {
         rec.cfg = cfg_id(MF, TM, TN, WM);

@@ -271,11 +271,8 @@ void launch_skinny(const SkinnyParams& kp, hipStream_t stream) {
         HIP_CHECK(hipEventRecord(e0, stream));
     }
     auto kern = gemm_skinny_kernel<TN, kStages>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipLaunchKernelGGL(kern, grid, dim3(64), kStages * (1 + TN) * 1024, stream, kp);
     HIP_CHECK(hipGetLastError());
     if (prof) {
@@ -333,11 +330,8 @@ bool launch_gemm_skinny_taps(const ConvParams& p, int mask_shift, hipStream_t st
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, stream));
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_taps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(gemm_skinny_taps_kernel), lds_allowed);
     hipLaunchKernelGGL(gemm_skinny_taps_kernel, grid, dim3(64), kTapSlots * kp.slot_bytes, stream, kp);
     HIP_CHECK(hipGetLastError());
     if (prof) {

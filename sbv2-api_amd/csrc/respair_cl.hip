@@ -349,11 +349,8 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     lds = (lds + 15) / 16 * 16;
     SBV2_REQUIRE(lds <= 160 * 1024, "respair: LDS budget exceeded");
     auto kern = respair_cl_kernel<PREC, PERSIST, WM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     const int nto = kRpNT - 2 * h2;
     int per_cu = 1;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), T, lds));
