@@ -667,6 +667,35 @@ def test_pipeline_tiny():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_pipeline_shortest_and_ragged_inputs():
+    """Edge shapes: the shortest utterances the front end can produce (1 and 2 phones -> T_text 3 and 5, one BERT character -> S = 3), alone
+    and batched next to a 40-phone neighbour, with forced and with predicted durations (noise off): every waveform vs the oracle, the
+    short ones bit-equal between the ragged batch and their single calls; an empty batch is an error, not a crash."""
+    bc, bw = weights("bert", "tiny", 3)
+    vc, vw = weights("vits", "tiny", 5)
+    bs, vs = model.load_model(blob("bert", "tiny", 3), True), model.load_model(blob("vits", "tiny", 5), False)
+    pipe = model.Pipeline(bs, vs)
+    utts = [synth.make_utterance(n, bc, vc, seed=400 + n, chars=c) for n, c in ((1, 1), (40, 18), (2, 1), (1, 1))]
+    for kw in (dict(forced=True), dict(sdp_ratio=0.0, length_scale=1.0, noise_scale=0.0, noise_scale_w=0.0)):
+        b = pipe.prepare(utts, **kw)
+        pipe.run(b)
+        pcms = pipe.fetch(b)
+        assert len(pcms) == 4
+        for i, (u, got) in enumerate(zip(utts, pcms)):
+            bert = O.expand_bert_features(O.deberta_forward(bw, bc, u["input_ids"]), u["word2ph"])
+            fd = u["forced_durations"] if "forced" in kw else None
+            ref = O.vits_forward(vw, vc, bert, u["phones"], u["tones"], u["langs"], 0, u["style"], forced_durations=fd, sdp_ratio=0.0)
+            assert got.shape == (ref.shape[-1],) and got.size > 0 and np.isfinite(got).all(), (i, got.shape, ref.shape)
+            np.testing.assert_allclose(got, ref.reshape(-1), atol=2e-4, rtol=0)
+            if u["T_text"] <= 5:
+                b1 = pipe.prepare([u], **kw)
+                pipe.run(b1)
+                np.testing.assert_array_equal(pipe.fetch(b1)[0], got)
+    with pytest.raises((model.Sbv2Error, ValueError)):
+        pipe.run(pipe.prepare([], forced=True))
+    pipe.close(); bs.close(); vs.close()
+
+
 def test_orchestrator_request_tiny():
     """tts.rs:280-349 through ONE batched pipeline call == the reference's per-sentence loop (oracle), including the rule that
     22050 zero samples follow every sentence that is not the request's last LINE (empty lines count), and the WAV framing."""
