@@ -469,6 +469,21 @@ def test_config2_b32_u128_default_path():
             assert err < 5e-5
     finally:
         O.set_conv_backend("numpy")
+    # ... and ALL 32 against the C / OpenMP restatement (oracle/sbv2_ref.c, itself pinned to the same golden vectors: tests/test_oracle_c.py)
+    import sbv2_ref as R
+    lib = R.load()
+    lib.sbv2c_set_threads(R.usable_cpus())
+    m = R.Model(blob("bert", "full"), blob("vits", "full"), lib=lib)
+    worst = 0.0
+    for u, got in zip(utts, pcms):
+        h = m.bert(u["input_ids"], None, hidden=bc["hidden"])
+        bert = np.repeat(h, np.asarray(u["word2ph"], np.int64), axis=0).T.copy()
+        ref = m.vits(bert, u["phones"], u["tones"], u["langs"], 0, u["style"], forced_durations=u["forced_durations"])
+        assert ref.shape == got.shape
+        worst = max(worst, float(np.abs(got - ref).max()))
+    m.close()
+    print(f"configs[2]: worst waveform max-abs error of the 32 utterances vs the C oracle {worst:.3e}")
+    assert worst < 5e-5
     pipe.close(); bs.close(); vs.close()
 
 
