@@ -6,7 +6,9 @@
 // order of conv_cl.hip, the same hi / lo conversion, the same epilogue expression, so a batch row (conv_cl) and the single call of the
 // same utterance (this kernel) agree bit for bit.  Only the work decomposition differs:
 //   * one 32 rows x 32 positions tile per workgroup: 174 workgroups instead of 24, each ONE serial MFMA chain (wave 0) that three helper
-//     waves keep fed (DMA issue, window conversion), one raw s_barrier per chunk;
+//     waves keep fed (wave 1 issues the DMAs, waves 2 and 3 convert the windows), one raw s_barrier per chunk.  Measured per launch (flow FFN
+//     conv 2 of a single-utterance call): conv_cl 102 us; one wave doing everything 80; MFMA wave + three loader / converter waves 50;
+//     roles split as above 43, where the MFMA wave's own chain (15 dependent MFMAs + the fragment reads of 5 taps per chunk) is what is left;
 //   * both operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-slot ring, up to 3 chunks ahead, counted vmcnt: the weight
 //     fragment blocks are lane-linear 1 KB images already, the activation window lands as raw f32 rows [position][16 channels] and is
 //     converted LDS -> registers -> LDS (leaky-ReLU, hi / lo split, the XOR-swizzled [position][8 | 8] image conv_cl reads) one chunk
@@ -37,6 +39,7 @@ struct ClSmallParams {
     int mask_shift;
     int slot_bytes; // ring slot: ntaps * 2 KB of weight fragments, then xg KB of raw window
     int ahead;      // chunks in flight (1 .. 3)
+    int abl;        // timing ablations (SBV2_CLS_ABL): 1 = no DMA after the prologue, 2 = no MFMA, 3 = no conversion
 };
 
 __device__ __forceinline__ void wait_vm_dyn(int n) {
@@ -52,7 +55,8 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
     }
 }
 
-constexpr int kLoaders = 3;   // waves 1 .. 3 issue the DMAs and convert the windows; wave 0 only runs the MFMA chain and the epilogue
+constexpr int kLoaders = 3;      // helper waves: wave 1 issues the DMAs, waves 2 and 3 convert the windows; wave 0 only runs the MFMA chain
+constexpr int kConverters = 2;
 
 template <int TN>
 __global__ __launch_bounds__(64 * (kLoaders + 1)) void conv_cl_small_kernel(const ClSmallParams kp) {
@@ -79,18 +83,22 @@ __global__ __launch_bounds__(64 * (kLoaders + 1)) void conv_cl_small_kernel(cons
     const int xr = lane >> 2, xq = (lane & 3) * 4;
     // the 2 * ntaps + xg DMA instructions of a chunk are dealt round-robin over the waves
     const int nload = 2 * ntaps + kp.xg;
+    // wave 1 issues every DMA of a chunk: 2 * ntaps weight blocks (contiguous KBs) and xg window pieces whose sources are resolved once
+    constexpr int kMaxXg = 6;
+    const char* xsrc[kMaxXg];
+#pragma unroll
+    for (int g = 0; g < kMaxXg; ++g) {
+        const int pos = min(max(wstart + g * 16 + xr, 0), NB - 1);
+        xsrc[g] = reinterpret_cast<const char*>(p.X + (int64_t)pos * p.ldx + xq);
+    }
     auto stage = [&](int c) {
         char* dst = ring + (c & (kSlots - 1)) * kp.slot_bytes;
         const char* ws = wsrc + c * wstep;
-        for (int i = wave - 1; i < nload; i += kLoaders) {
-            if (i < 2 * ntaps) {
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(ws + i * 1024), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
-            } else {
-                const int g = i - 2 * ntaps;
-                const int pos = min(max(wstart + g * 16 + xr, 0), NB - 1);
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.X + (int64_t)pos * p.ldx + c * 16 + xq), (lds_void_t*)(dst + wbytes + g * 1024), 16, 0, 0);
-            }
-        }
+        for (int i = 0; i < 2 * ntaps; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(ws + i * 1024), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < kMaxXg; ++g)
+            if (g < kp.xg) __builtin_amdgcn_global_load_lds((gbl_void_t*)(xsrc[g] + c * 64), (lds_void_t*)(dst + wbytes + g * 1024), 16, 0, 0);
     };
     // raw window of chunk c (slot c & 3) -> converted image (buffer c & 1); conv_cl.hip's store_x, with LDS as the source
     const int nxf4 = kp.xrows * 4;
@@ -98,13 +106,16 @@ __global__ __launch_bounds__(64 * (kLoaders + 1)) void conv_cl_small_kernel(cons
         const char* raw = ring + (c & (kSlots - 1)) * kp.slot_bytes + wbytes;
         char* xs_hi = cvt + (c & 1) * 2 * cvt_bytes;
         char* xs_lo = xs_hi + cvt_bytes;
-        constexpr int NCVL = (NCV + kLoaders - 1) / kLoaders;
+        constexpr int NCVL = (NCV + kConverters - 1) / kConverters;
         f32x4v rv[NCVL];
 #pragma unroll
-        for (int i = 0; i < NCVL; ++i) rv[i] = *reinterpret_cast<const f32x4v*>(raw + min((wave - 1) * 64 + lane + i * 64 * kLoaders, nxf4 - 1) * 16);
+        for (int i = 0; i < NCVL; ++i)
+            if (i == 0 || i * 64 * kConverters < nxf4)
+                rv[i] = *reinterpret_cast<const f32x4v*>(raw + min((wave - 2) * 64 + lane + i * 64 * kConverters, nxf4 - 1) * 16);
 #pragma unroll
         for (int i = 0; i < NCVL; ++i) {
-            const int idx = (wave - 1) * 64 + lane + i * 64 * kLoaders;
+            if (i > 0 && i * 64 * kConverters >= nxf4) break;
+            const int idx = (wave - 2) * 64 + lane + i * 64 * kConverters;
             float4 v = make_float4(rv[i][0], rv[i][1], rv[i][2], rv[i][3]);
             const int row = idx >> 2, q = idx & 3;
             const int pos = wstart + row;
@@ -178,25 +189,26 @@ __global__ __launch_bounds__(64 * (kLoaders + 1)) void conv_cl_small_kernel(cons
     // landed (every loader waited for ITS loads: they retire in order, `per` of them per chunk and wave) and the window of chunk c is
     // converted.  Between B(c) and B(c + 1) wave 0 runs the MFMAs of chunk c while the loaders convert the window of chunk c + 1 and issue
     // the DMAs of one more chunk, into a slot that holds neither chunk c nor c + 1 (2 <= ahead < kSlots).
-    const int per = wave == 0 ? 0 : (nload - (wave - 1) + kLoaders - 1) / kLoaders;
+    const int per = nload;      // wave 1's loads per chunk
     int issued = 0;
-    if (wave != 0) {
+    if (wave == 1) {
         for (; issued < min(kp.ahead, nchunks); ++issued) stage(issued);
         wait_vm_dyn((issued - 1) * per);                       // chunk 0
     }
     __builtin_amdgcn_s_barrier();
-    if (wave != 0) convert(0);
+    if (wave >= 2) convert(0);
     for (int c = 0; c < nchunks; ++c) {
-        if (wave != 0) wait_vm_dyn(max(issued - c - 2, 0) * per);   // chunk c + 1 (or everything, at the tail)
+        if (wave == 1) wait_vm_dyn(kp.abl == 1 ? 0 : max(issued - c - 2, 0) * per);   // chunk c + 1 (or everything, at the tail)
         __builtin_amdgcn_s_barrier();                           // B(c)
         if (wave == 0) {
-            mma_chunk(c);
-        } else {
+            if (kp.abl != 2) mma_chunk(c);
+        } else if (wave == 1) {
             if (issued < nchunks) {
-                stage(issued);
+                if (kp.abl != 1) stage(issued);
                 ++issued;
             }
-            if (c + 1 < nchunks) convert(c + 1);
+        } else {
+            if (c + 1 < nchunks && kp.abl != 3) convert(c + 1);
         }
     }
     if (wave != 0) return;
@@ -274,7 +286,9 @@ bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t str
     kp.slot_bytes = p.ntaps * 2048 + kp.xg * 1024;
     const int per = 2 * p.ntaps + kp.xg;
     static const int ahead_max = getenv("SBV2_CLS_AHEAD") ? atoi(getenv("SBV2_CLS_AHEAD")) : 4;   // experiments
-    kp.ahead = std::max(2, std::min(kSlots - 2, ahead_max));   // per-wave outstanding loads stay far below the 6-bit vmcnt: ahead * ceil(30 / 3)
+    kp.ahead = std::max(2, std::min(std::min(kSlots - 2, ahead_max), 62 / per));   // one wave holds every outstanding load: 6-bit vmcnt
+    static const int abl = getenv("SBV2_CLS_ABL") ? atoi(getenv("SBV2_CLS_ABL")) : 0;
+    kp.abl = abl;
     const size_t lds = (size_t)kSlots * kp.slot_bytes + 4 * (size_t)kp.xrows * 32;
     if (lds > 160 * 1024) return false;
     auto kern = conv_cl_small_kernel<TN>;
