@@ -39,7 +39,6 @@ struct ClSmallParams {
     int mask_shift;
     int slot_bytes; // ring slot: ntaps * 2 KB of weight fragments, then xg KB of raw window
     int ahead;      // chunks in flight (1 .. 3)
-    int abl;        // timing ablations (SBV2_CLS_ABL): 1 = no DMA after the prologue, 2 = no MFMA, 3 = no conversion
 };
 
 __device__ __forceinline__ void wait_vm_dyn(int n) {
@@ -198,17 +197,17 @@ __global__ __launch_bounds__(64 * (kLoaders + 1)) void conv_cl_small_kernel(cons
     __builtin_amdgcn_s_barrier();
     if (wave >= 2) convert(0);
     for (int c = 0; c < nchunks; ++c) {
-        if (wave == 1) wait_vm_dyn(kp.abl == 1 ? 0 : max(issued - c - 2, 0) * per);   // chunk c + 1 (or everything, at the tail)
+        if (wave == 1) wait_vm_dyn(max(issued - c - 2, 0) * per);   // chunk c + 1 (or everything, at the tail)
         __builtin_amdgcn_s_barrier();                           // B(c)
         if (wave == 0) {
-            if (kp.abl != 2) mma_chunk(c);
+            mma_chunk(c);
         } else if (wave == 1) {
             if (issued < nchunks) {
-                if (kp.abl != 1) stage(issued);
+                stage(issued);
                 ++issued;
             }
         } else {
-            if (c + 1 < nchunks && kp.abl != 3) convert(c + 1);
+            if (c + 1 < nchunks) convert(c + 1);
         }
     }
     if (wave != 0) return;
@@ -287,8 +286,6 @@ bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t str
     const int per = 2 * p.ntaps + kp.xg;
     static const int ahead_max = getenv("SBV2_CLS_AHEAD") ? atoi(getenv("SBV2_CLS_AHEAD")) : 4;   // experiments
     kp.ahead = std::max(2, std::min(std::min(kSlots - 2, ahead_max), 62 / per));   // one wave holds every outstanding load: 6-bit vmcnt
-    static const int abl = getenv("SBV2_CLS_ABL") ? atoi(getenv("SBV2_CLS_ABL")) : 0;
-    kp.abl = abl;
     const size_t lds = (size_t)kSlots * kp.slot_bytes + 4 * (size_t)kp.xrows * 32;
     if (lds > 160 * 1024) return false;
     auto kern = conv_cl_small_kernel<TN>;
