@@ -312,6 +312,7 @@ class VitsModel {
     VitsConfig cfg_;
     std::shared_ptr<WeightStore> ws_;
     hipStream_t stream_ = nullptr;
+    hipEvent_t after_ev_ = nullptr;   // orders this context after the producer stream of its DeBERTa features (created on first use)
     Arena arena_, keep_;
     // weights
     float *emb_g_, *emb_, *tone_emb_, *lang_emb_, *style_w_, *style_b_;

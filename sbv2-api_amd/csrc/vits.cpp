@@ -315,6 +315,7 @@ VitsModel* VitsModel::clone() const {
 
 VitsModel::~VitsModel() {
     (void)hipSetDevice(device_);
+    if (after_ev_) (void)hipEventDestroy(after_ev_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -497,11 +498,9 @@ void VitsModel::forward(const VitsBatch& b) {
     keep_.reset();
     traces_.clear();
     if (b.after_stream) {
-        hipEvent_t ev;
-        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(ev, b.after_stream));
-        HIP_CHECK(hipStreamWaitEvent(stream_, ev, 0));
-        HIP_CHECK(hipEventDestroy(ev));
+        if (!after_ev_) HIP_CHECK(hipEventCreateWithFlags(&after_ev_, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(after_ev_, b.after_stream));
+        HIP_CHECK(hipStreamWaitEvent(stream_, after_ev_, 0));
     }
     Arena& ar = arena_;
     const int n = b.n, H = cfg_.hidden, I = cfg_.inter;
