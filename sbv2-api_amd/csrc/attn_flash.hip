@@ -264,6 +264,9 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
     const float* Kg = K + off;
     const float* Vg = V + off;
     const int nb = 2 * w + 1;
+    // logits are kept in the base-2 domain (scores * log2 e): every exponential of the online softmax is then ONE v_exp_f32 instead of the
+    // twelve-instruction expf (argument reduction + ldexp + range checks), 17 of them per lane and key tile
+    const float qs2 = qscale * 1.4426950408889634f;
 
     for (int idx = tid; idx < kFaBand * DR; idx += kFaThreads) {
         const int r = idx / DR, d = idx - r * DR;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             const float other = __shfl_xor(part[r], 32);
             const float lo = kh ? other : part[r];
             const float hi = kh ? part[r] : other;
-            rk_s[wave][r][col] = (lo + hi) * qscale;
+            rk_s[wave][r][col] = (lo + hi) * qs2;
             band_s[wave][r][col] = kFaNegBig;
         }
     }
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float sv = sacc[r] * qscale;
+                float sv = sacc[r] * qs2;
                 if (diag) {
                     const int rr = j - i + w;
                     if (rr >= 0 && rr < nb && j < T) {
@@ -377,11 +380,11 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mn = fmaxf(m, mt);
-            const float alpha = expf(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(sacc[r] - mn);
+                const float e = __builtin_amdgcn_exp2f(sacc[r] - mn);
                 sacc[r] = e;
                 ps += e;
             }
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
     const float inv = 1.0f / l;
     float pb[kFaBand];
 #pragma unroll
-    for (int r = 0; r < kFaBand; ++r) pb[r] = expf(band_s[wave][r][col] - m) * inv;
+    for (int r = 0; r < kFaBand; ++r) pb[r] = __builtin_amdgcn_exp2f(band_s[wave][r][col] - m) * inv;
     float* Cg = ctx + (int64_t)g.head * dk * ldc + g.col0;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
