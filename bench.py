@@ -89,6 +89,66 @@ def exchange_unique_id(model, rank: int) -> bytes:
     raise SystemExit("rank 0 never published the communicator id")
 
 
+class HostGroup:
+    """Barrier / max / sum over the ranks of this node through TCP on 127.0.0.1 (rank 0 serves).  Always set up for N > 1: it lets all ranks
+    AGREE on whether the RCCL communicator came up, and carries the bench's two scalars if it did not (the PCM then stays on each rank's
+    host: the line says so).  Never on the data path."""
+
+    def __init__(self, rank: int, world: int):
+        import socket
+        self.rank, self.world = rank, world
+        port = (int(os.environ.get("MASTER_PORT", "29500")) + 1 + sum(map(ord, uid_path())) % 997) % 64000 + 1024
+        if rank == 0:
+            srv = socket.socket()
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("127.0.0.1", port))
+            srv.listen(world)
+            srv.settimeout(300)
+            self.peers = []
+            for _ in range(world - 1):
+                c, _a = srv.accept()
+                c.settimeout(600)
+                self.peers.append(c)
+            srv.close()
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    self.sock = socket.create_connection(("127.0.0.1", port), timeout=5)
+                    self.sock.settimeout(600)
+                    break
+                except OSError:
+                    if time.time() - t0 > 300:
+                        raise SystemExit("rank 0's host group never came up")
+                    time.sleep(0.05)
+
+    @staticmethod
+    def _recv(c, n=8):
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise SystemExit("a rank of the host group went away")
+            buf += part
+        return buf
+
+    def reduce(self, x: float, op) -> float:
+        import struct
+        if self.rank == 0:
+            vals = [x] + [struct.unpack("<d", self._recv(c))[0] for c in self.peers]
+            r = op(vals)
+            for c in self.peers:
+                c.sendall(struct.pack("<d", r))
+            return r
+        self.sock.sendall(struct.pack("<d", x))
+        return struct.unpack("<d", self._recv(self.sock))[0]
+
+    def max(self, x): return self.reduce(float(x), max)
+    def min(self, x): return self.reduce(float(x), min)
+    def sum(self, x): return self.reduce(float(x), sum)
+    def barrier(self): self.reduce(0.0, max)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,9 +219,20 @@ def main():
     dtype = {0: "f32", 1: "bf16x3-split (decoder convs: bf16 hi/lo MFMA, f32 accumulate/storage) + f32", 2: "bf16 (decoder convs) + f32",
              3: "f16 (decoder convs: fp16 MFMA operands, f32 accumulate/storage) + f32"}[dmode]
 
-    comm = None
+    comm, host, rccl_error = None, None, ""
     if world > 1:
-        comm = model.Comm(exchange_unique_id(model, rank), rank, world, device)
+        host = HostGroup(rank, world)
+        try:
+            comm = model.Comm(exchange_unique_id(model, rank), rank, world, device)
+        except Exception as e:      # e.g. two ranks on one GPU in a plumbing check: RCCL refuses ("invalid usage")
+            rccl_error = str(e).splitlines()[0][:200]
+        if host.min(1.0 if comm is not None else 0.0) < 1.0:    # every rank takes the same path
+            if comm is not None:
+                comm.close()
+            comm = None
+            if rank == 0:
+                print(f"bench.py: no RCCL communicator ({rccl_error or 'another rank failed'}): PCM stays on each rank's host", file=sys.stderr)
+    if comm is not None:
         all_samples = int(comm.max(float(my_samples)))      # capacity bound for the root's buffer
         pin = model.PinnedArray(all_samples * world) if rank == 0 else None
     else:
@@ -190,6 +261,8 @@ def main():
         pipe.sync()
         if comm is not None:
             comm.barrier()
+        elif host is not None:
+            host.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -199,7 +272,10 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if comm is not None:
+    if comm is None and host is not None:
+        dt = host.max(dt)
+        total_samples_per_step = int(host.sum(float(sum(sub_samples))))
+    elif comm is not None:
         dt = comm.max(dt)
         total_samples_per_step = int(sum(c.sum() for c in counts_seen[-len(batches):]))
     else:
@@ -295,8 +371,9 @@ def main():
                                    + (f" -> {int(b.lens[0]) // hop} frames/utt" if args.config == "u128" else "")
                                    + "; timed region = host ids -> PCM on the host of rank 0",
                        "global_batch": global_batch, "audio_seconds_per_step": round(total_samples_per_step / configs.SAMPLE_RATE, 3),
-                       "parallelism": f"utterance-sharded x{world}" + (", RCCL gather of PCM to rank 0 (in-library, no torch)" if world > 1 else ""),
-                       "rccl_ranks": (comm.world if comm is not None else 1),
+                       "parallelism": f"utterance-sharded x{world}" + ((", RCCL gather of PCM to rank 0 (in-library, no torch)" if comm is not None else
+                                                                           f", NO RCCL communicator ({rccl_error or 'a rank failed'}): PCM left on each rank's host") if world > 1 else ""),
+                       "rccl_ranks": (comm.world if comm is not None else (0 if world > 1 else 1)),
                        "shapes": "tiny (plumbing check)" if args.tiny else "full"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -304,6 +381,8 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+    if host is not None:
+        host.barrier()
         if rank == 0:
             try:
                 os.remove(uid_path())

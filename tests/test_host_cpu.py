@@ -248,6 +248,23 @@ def test_model_holder_load_aivmx():
     h.close()
 
 
+def test_bench_host_group_world3(tmp_path):
+    """bench.py's fallback group (TCP on 127.0.0.1: the ranks agree on whether RCCL came up, and exchange the two scalars of the bench line
+    if it did not): three processes, max / min / sum / barrier."""
+    import subprocess, sys, os, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    code = ("import sys, os; sys.path.insert(0, %r); import bench; r = int(os.environ['RANK']); g = bench.HostGroup(r, 3); "
+            "print(g.max(r + 1.5), g.min(r + 1.5), g.sum(r + 1.0)); g.barrier(); print('done')") % root
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_PORT=str(port),
+                                                                     SBV2_BENCH_LAUNCH="cputest", TMPDIR=str(tmp_path)),
+                              stdout=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0].split() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    for o in outs:
+        assert o == ["3.5", "1.5", "6.0", "done"], o
+
+
 def test_rest_contract():
     """main.rs:24-100,192-196 + error.rs:10-18: routes, JSON defaults, audio/wav, 'Something went wrong: ...' with status 500."""
     from fastapi.testclient import TestClient
