@@ -485,9 +485,9 @@ int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, 0.1f);
+    for (int i = 0; i < 3; ++i) conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, 1.0f);
     HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, 0.1f);
+    for (int i = 0; i < iters; ++i) conv_plain(pc, X, Y, (int)dilation, (int)(dilation * (k - 1) / 2), nullptr, 1, nullptr, ACT_NONE, 1.0f);
     HIP_CHECK(hipEventRecord(e1, nullptr));
     HIP_CHECK(hipEventSynchronize(e1));
     float t = 0.f;

@@ -71,7 +71,21 @@ __device__ __forceinline__ float4 load4_guard(const float* src, int j, int lo, i
     return v;
 }
 
-template <int MF, int TM, int TN, int WM, int WN, int KC>
+// RING = true (1x1 products with K % 16 == 0, no shift, no groups): both operand tiles of a chunk are row-contiguous f32 images, so they go
+// L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a kRingSlots-deep ring, kRingSlots - 1 chunks ahead, with no staging register and
+// no staging VALU.  An ablation of the register-staged loop (4096 x 2112 x 1024: 247 us) showed the staging path alone (loads, zero-fill
+// selects, LDS stores) at 111 us and the MFMAs alone at 114 us (= the 155 TFLOP/s the f32 pipe sustains on random data), adding up instead
+// of overlapping, and 64 x 128 tiles pulling 7.5 TB/s from L2 at that rate: the ring removes the staging instructions, and having no
+// staging registers makes 128 x 128 tiles (half the L2 bytes per FLOP) affordable.  Same fragments, same MFMA order, same epilogue: same bits.
+constexpr int kRingSlots = 4;
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+typedef __attribute__((address_space(3))) void ring_lds_t;
+typedef const __attribute__((address_space(1))) void ring_gbl_t;
+
+template <int MF, int TM, int TN, int WM, int WN, int KC, bool RING = false>
 __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams kp) {
     using MM = Mfma<MF>;
     constexpr int MT = MF * TM * WM;
@@ -83,8 +97,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
 
     const ConvParams& p = kp.p;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int XW = kp.xw;
-    float* ws = smem;                 // [2][KC][MT]
+    const int XW = RING ? MF * TN * WN : kp.xw;
+    float* ws = smem;                 // [2][KC][MT]          (RING: slot s = [KC][MT] then [KC][NT] at smem + s * KC * (MT + NT))
     float* xs = smem + 2 * KC * MT;   // [2][KC][XW]
 
     const int tid = threadIdx.x;
@@ -211,6 +225,80 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
         }
     };
 
+    if constexpr (RING) {
+        constexpr int SLOT = KC * (MT + NT);                 // floats per ring slot
+        constexpr int LA = MT / 4, LB = NT / 4;              // lanes per row of the A / B tile
+        constexpr int GA = KC * LA / 64, GB = KC * LB / 64;  // DMA instructions per chunk
+        static_assert((GA + GB) % 4 == 0 && GA >= 1 && GB >= 1, "ring: the DMAs of a chunk are dealt evenly over the four waves");
+        constexpr int PERW = (GA + GB) / 4;
+        // DMA g of a chunk (g < GA: rows of the weight tile, else rows of the activation tile) belongs to wave g % 4
+        const float* src[PERW];
+        int64_t step[PERW];
+        int dst[PERW];
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) {
+            const int gi = wave + 4 * q;
+            if (gi < GA) {
+                const int row = gi * (64 / LA) + lane / LA, col = m0 + (lane % LA) * 4;
+                src[q] = Ag + (int64_t)row * p.lda + (col < M ? col : 0);   // rows / columns outside the problem only feed outputs never stored
+                step[q] = (int64_t)KC * p.lda;
+                dst[q] = gi * 256;
+            } else {
+                const int gb = gi - GA;
+                const int row = gb * (64 / LB) + lane / LB, col = n0 + (lane % LB) * 4;
+                src[q] = Bg + (int64_t)row * p.ldb + (col < N ? col : 0);
+                step[q] = (int64_t)KC * p.ldb;
+                dst[q] = KC * MT + gb * 256;
+            }
+        }
+        auto stage = [&](int c) {
+            float* slot = smem + (c & (kRingSlots - 1)) * SLOT;
+#pragma unroll
+            for (int q = 0; q < PERW; ++q)
+                __builtin_amdgcn_global_load_lds((ring_gbl_t*)(src[q] + c * step[q]), (ring_lds_t*)(slot + dst[q]), 16, 0, 0);
+        };
+        auto compute_ring = [&](int c) {
+            const float* wsb = smem + (c & (kRingSlots - 1)) * SLOT + wm0 + (lane % MF);
+            const float* xsb = wsb - wm0 + KC * MT + wn0;
+            const int lrow_ = lane / MF;
+            // every fragment of the chunk is requested before the first MFMA (left to hipcc each k-step was "ds_read, s_waitcnt lgkmcnt(0), two
+            // MFMAs": one exposed LDS round trip per 128 cycles of matrix work); the register-staged loop above is better off without this
+            // (its staging registers compete: measured 253 -> 289 us at 4096 x 2112 x 1024)
+            constexpr int NK = KC / MM::KS;
+            float a[NK][TM], b[NK][TN];
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int kr = kk * MM::KS + lrow_;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[kk][i] = wsb[kr * MT + i * MF];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[kk][j] = xsb[kr * NT + j * MF];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (slope != 1.0f) {
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[kk][j] = b[kk][j] >= 0.f ? b[kk][j] : b[kk][j] * slope;
+            }
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MM::run(a[kk][i], b[kk][j], acc[i][j]);
+        };
+        for (int c = 0; c < min(kRingSlots - 1, nchunks); ++c) stage(c);
+        for (int c = 0; c < nchunks; ++c) {
+            // this wave's DMAs of chunk c have landed (loads retire in order; at the tail fewer chunks are behind it: wait for all)
+            if (c + kRingSlots - 2 < nchunks) ring_wait_vm<(kRingSlots - 2) * PERW>();
+            else ring_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();   // ... and everybody else's; every wave is also done with chunk c - 1, whose slot is refilled now
+            if (c + kRingSlots - 1 < nchunks) stage(c + kRingSlots - 1);
+            compute_ring(c);
+        }
+        __syncthreads();   // the epilogue re-uses the ring as its transpose tiles
+    } else {
     load_x(rx, 0);
     load_w(rw, 0, 0);
     store_x(rx, 0, 0);
@@ -261,6 +349,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
             chunk = nchunk;
         }
     }
+    }   // !RING
 
     // ---- epilogue --------------------------------------------------------------------------------
     const bool phased = p.phase_rows < (1 << 30);
@@ -443,7 +532,7 @@ static std::atomic<int> g_skinny_max{getenv("SBV2_SKINNY_MAX") ? atoi(getenv("SB
 int set_skinny_max(int v) { return g_skinny_max.exchange(v); }
 int small_grid_max() { return g_skinny_max.load(std::memory_order_relaxed); }
 
-template <int MF, int TM, int TN, int WM, int WN, int KC>
+template <int MF, int TM, int TN, int WM, int WN, int KC, bool RING = false>
 static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stream) {
     constexpr int MT = MF * TM * WM;
     constexpr int NT = MF * TN * WN;
@@ -463,9 +552,10 @@ static void launch_cfg(const KernelParams& kp0, int Mx, int Nx, hipStream_t stre
     }
     kp.xw = xw;
     kp.wshift0 = w0;
-    const size_t lds = std::max(sizeof(float) * (2 * KC * MT + 2 * KC * xw), sizeof(float) * 4 * 32 * 36);   // staging | epilogue tiles
+    const size_t lds = RING ? sizeof(float) * kRingSlots * KC * (MT + NT)
+                            : std::max(sizeof(float) * (2 * KC * MT + 2 * KC * xw), sizeof(float) * 4 * 32 * 36);   // staging | epilogue tiles
     dim3 grid((Nx + NT - 1) / NT, (Mx + MT - 1) / MT, p.groups ? p.ngroups : 1);
-    auto kern = conv_gemm_kernel<MF, TM, TN, WM, WN, KC>;
+    auto kern = conv_gemm_kernel<MF, TM, TN, WM, WN, KC, RING>;
     static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     ProfRec rec;
@@ -521,7 +611,16 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
     if (p.ntaps == 1) {
         // 1x1 products (measured on the DeBERTa / flow shapes with the two-deep prefetch): 64x128 beats 64x256, and 64x64 wins when
         // the grid would otherwise be under two workgroups per CU
-        if (blocks(64, 128) >= 512) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+        static const int ring_on = getenv("SBV2_GEMM_RING") ? atoi(getenv("SBV2_GEMM_RING")) : 2;   // 0 = off, 1 = ring, 2 = ring + 128 x 128 tiles
+        const bool ring = ring_on && !p.groups && p.shift[0] == 0 && (p.K & 15) == 0 && p.K >= 48 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
+                          p.N <= p.nb && p.phase_rows >= (1 << 30);
+        // 128 x 128 tiles (half the L2 bytes per FLOP; 64 KB of ring: two workgroups per CU) when they fill the chip in ONE round: 3072 x 2112 is
+        // 408 workgroups on 512 slots (160 vs 177 us), 4096 x 2112 would be 544 = two rounds (251 vs 222 us)
+        if (ring && ring_on >= 2 && blocks(128, 128) >= 384 && blocks(128, 128) <= 512) return launch_cfg<32, 2, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
+        if (blocks(64, 128) >= 512) {
+            if (ring) return launch_cfg<32, 1, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
+            return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
+        }
         // single-utterance calls (DeBERTa at 64 tokens: 16-64 workgroups of 64 rows on 256 CUs, 47 us per launch whatever the size):
         // 32-row tiles double the workgroup count; the per-element summation order does not depend on the tile, so batch rows stay
         // bit-identical to single calls
@@ -533,6 +632,7 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         const int skinny_max = g_skinny_max.load(std::memory_order_relaxed);
         if (blocks(64, 64) < (p.K >= 512 ? skinny_max + skinny_max / 2 : skinny_max) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
         if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 64>(kp, Mx, Nx, stream);
+        if (ring) return launch_cfg<32, 1, 1, 2, 2, 16, true>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
     }
     if (blocks(64, 64) < g_skinny_max.load(std::memory_order_relaxed) && launch_gemm_skinny_taps(p, kp.mask_shift, stream)) return;
