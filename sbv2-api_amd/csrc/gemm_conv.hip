@@ -611,12 +611,15 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
     if (p.ntaps == 1) {
         // 1x1 products (measured on the DeBERTa / flow shapes with the two-deep prefetch): 64x128 beats 64x256, and 64x64 wins when
         // the grid would otherwise be under two workgroups per CU
-        static const int ring_on = getenv("SBV2_GEMM_RING") ? atoi(getenv("SBV2_GEMM_RING")) : 2;   // 0 = off, 1 = ring, 2 = ring + 128 x 128 tiles
+        static const int ring_on = getenv("SBV2_GEMM_RING") ? atoi(getenv("SBV2_GEMM_RING")) : 2;   // 0 = off, 1 = ring with the register-staged tile policy, 2 = ring + its own tiles
         const bool ring = ring_on && !p.groups && p.shift[0] == 0 && (p.K & 15) == 0 && p.K >= 48 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
                           p.N <= p.nb && p.phase_rows >= (1 << 30);
         // 128 x 128 tiles (half the L2 bytes per FLOP; 64 KB of ring: two workgroups per CU) when they fill the chip in ONE round: 3072 x 2112 is
         // 408 workgroups on 512 slots (160 vs 177 us), 4096 x 2112 would be 544 = two rounds (251 vs 222 us)
         if (ring && ring_on >= 2 && blocks(128, 128) >= 384 && blocks(128, 128) <= 512) return launch_cfg<32, 2, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
+        // ... and 64 x 64 tiles otherwise: 32 KB of ring = five workgroups per CU keep the MFMA pipe fed across the chunk barriers and quantise
+        // better than 64 x 128 (4096 x 2112 x 1024: 211 vs 222 us; 768 x 28704 x 192: 113 vs 118)
+        if (ring && ring_on >= 2) return launch_cfg<32, 1, 1, 2, 2, 16, true>(kp, Mx, Nx, stream);
         if (blocks(64, 128) >= 512) {
             if (ring) return launch_cfg<32, 1, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
             return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
