@@ -611,6 +611,10 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
     if (p.ntaps == 1) {
         // 1x1 products (measured on the DeBERTa / flow shapes with the two-deep prefetch): 64x128 beats 64x256, and 64x64 wins when
         // the grid would otherwise be under two workgroups per CU
+        // small grids first (single-utterance calls): one-wave 16 x 16 tiles fed through an LDS-DMA ring (gemm_skinny.hip: same bits, see there;
+        // long products pay the tiled kernel's per-chunk round trip 64 times or more, so their threshold is higher)
+        const int skinny_max = g_skinny_max.load(std::memory_order_relaxed);
+        if (blocks(64, 64) < (p.K >= 512 ? skinny_max + skinny_max / 2 : skinny_max) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
         static const int ring_on = getenv("SBV2_GEMM_RING") ? atoi(getenv("SBV2_GEMM_RING")) : 2;   // 0 = off, 1 = ring with the register-staged tile policy, 2 = ring + its own tiles
         const bool ring = ring_on && !p.groups && p.shift[0] == 0 && (p.K & 15) == 0 && p.K >= 48 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
                           p.N <= p.nb && p.phase_rows >= (1 << 30);
@@ -632,8 +636,6 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         // ... superseded where it applies by one-wave 16 x 16 tiles fed through an LDS-DMA ring (gemm_skinny.hip: same bits, see there)
         // (long products pay the tiled kernel's per-chunk round trip 64 times or more: the FFN-up Linear of DeBERTa at 66 tokens, 128 workgroups,
         // is 43 us tiled, 28 us as 1280 single waves)
-        const int skinny_max = g_skinny_max.load(std::memory_order_relaxed);
-        if (blocks(64, 64) < (p.K >= 512 ? skinny_max + skinny_max / 2 : skinny_max) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
         if (blocks(64, 64) < 128 && Nx <= 128) return launch_cfg<32, 1, 1, 1, 4, 64>(kp, Mx, Nx, stream);
         if (ring) return launch_cfg<32, 1, 1, 2, 2, 16, true>(kp, Mx, Nx, stream);
         return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);

@@ -487,6 +487,29 @@ def test_config2_b32_u128_default_path():
     pipe.close(); bs.close(); vs.close()
 
 
+def test_small_grid_dispatch_reaches_the_small_grid_kernels():
+    """Dispatch guard (a tile-policy edit once put the ring GEMM in front of the small-grid check: same bits, so no parity test noticed, and
+    single-utterance latency went from 13.4 to 15.7 ms): at the default threshold a DeBERTa Linear of a 66-token call must run on gemm_skinny,
+    the same product at 2112 tokens on the tiled kernel."""
+    import json
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((1024, 1024, 1)) / 32).astype(np.float32)
+    b = np.zeros(1024, np.float32)
+
+    def kernels_of(L):
+        x = rng.standard_normal((1024, L)).astype(np.float32)
+        _lib.check(lib.sbv2_prof_begin())
+        _conv_dev(x, w, b, 1, 1.0)
+        buf = C.create_string_buffer(1 << 14)
+        _lib.check(lib.sbv2_prof_end(buf, len(buf)))
+        return {r["kernel"] for r in json.loads(buf.value.decode()) if r["launches"] > 0}
+
+    small, big = kernels_of(66), kernels_of(2112)
+    assert any(k.startswith("gemm_skinny") for k in small), small
+    assert not any(k.startswith("gemm_skinny") for k in big) and any(k.startswith("conv_gemm") for k in big), big
+
+
 def test_small_grid_kernels_keep_the_bits():
     """A single-utterance call runs its small grids on gemm_skinny / conv_cl_small; switched off (threshold 0) the same call goes through
     the tiled kernels of a large batch.  Both must give the same waveform bit for bit (predicted durations + noise, 100 phonemes)."""
