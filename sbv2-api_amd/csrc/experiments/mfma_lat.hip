@@ -113,6 +113,32 @@ __global__ void kbr(float* out, int iters, const float* rnd) {
     for (int i = 0; i < NACC; ++i) s += acc[i][0];
     if (s == 1234.5f) out[0] = s;
 }
+
+// the 64 x 64 tile's inner loop: per chunk 8 A + 8 B fragment words, 8 MFMAs on ONE accumulator; 32 KB of LDS -> five workgroups per CU
+__global__ void k32lds1(float* out, int chunks, const float* rnd) {
+    extern __shared__ float sm[];
+    for (int i = threadIdx.x; i < 16 * 128 * 2; i += blockDim.x) sm[i] = rnd[i & 4095];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32, lcol = lane & 31, lrow = lane >> 5;
+    f32x16 acc0;
+    for (int r = 0; r < 16; ++r) acc0[r] = 0;
+    for (int c = 0; c < chunks; ++c) {
+        const float* wsb = sm + (c & 1) * (16 * 128) + wm0 + lcol;
+        const float* xsb = sm + (c & 1) * (16 * 128) + 16 * 64 + wn0 + lcol;
+        float a[8], b0[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int kr = kk * 2 + lrow;
+            a[kk] = wsb[kr * 64];
+            b0[kk] = xsb[kr * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b0[kk], acc0, 0, 0, 0);
+    }
+    if (acc0[0] == 1234.5f) out[0] = acc0[0];
+}
 template <class F>
 static float time_us(F f) {
     hipEvent_t a, b;
@@ -152,6 +178,12 @@ int main() {
             float u2 = time_us([&] { k32lds<<<wgs, 256, 2 * 16 * 192 * 4 * 2>>>(out, chunks, rnd); });
             printf("GEMM inner loop (LDS fragments + 16 MFMAs per chunk), %d workgroups x 4 waves, 48 KB LDS each: %.1f us -> %.1f TFLOP/s\n", wgs, u2,
                    (double)wgs * 4 * chunks * 16 * 4096.0 / u2 / 1e6);
+        }
+        for (int wgs : {528, 1280, 2112}) {
+            const int chunks = 1024;
+            float u2 = time_us([&] { k32lds1<<<wgs, 256, 2 * 16 * 128 * 4 * 2>>>(out, chunks, rnd); });
+            printf("64 x 64 inner loop (8 + 8 LDS words, 8 dependent MFMAs per chunk), %d workgroups x 4 waves, 32 KB LDS each: %.1f us -> %.1f TFLOP/s\n", wgs, u2,
+                   (double)wgs * 4 * chunks * 8 * 4096.0 / u2 / 1e6);
         }
         {
             const int it3 = 32768;
