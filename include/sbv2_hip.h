@@ -216,6 +216,10 @@ int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int
 /* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; the
  * default comes from SBV2_SKINNY_MAX).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
 int sbv2_debug_set_skinny_max(int workgroups);
+/* y[M][N] = act(w[M][K] x[K][N] + bias) (+ res) through the split-bf16 1x1 GEMM (gemm_bfs.hip; parts 2 = bf16x3, 3 = bf16x6).  split_out != 0:
+   the result is also emitted as that many bf16 parts and y returns their sum.  iters > 0: average launch time in *ms.  Test hook. */
+int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
+                        int parts, int act, int split_out, int64_t iters, float* y, float* ms);
 
 #ifdef __cplusplus
 }

@@ -459,6 +459,76 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
 
 int sbv2_debug_set_skinny_max(int workgroups) { return set_skinny_max(workgroups); }
 
+int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
+                        int parts, int act, int split_out, int64_t iters, float* y, float* ms) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE((parts == 2 || parts == 3) && x && w && y && M >= 1 && N >= 4 && (N & 3) == 0 && (K & 15) == 0, "bad arguments");
+    Blob b = one_conv_blob(w, bias, {M, K, 1}, M);
+    WeightStore ws(b);
+    ws.set_bfs_parts(parts);
+    PackedConv pc = ws.conv("c");
+    const int ld = round_up((int)N, 64);
+    Plane X{nullptr, (int)K, (int)N, ld}, Y{nullptr, (int)M, (int)N, ld}, R{nullptr, (int)M, (int)N, ld};
+    DevBuf dx((size_t)K * ld), dy((size_t)M * ld), dr((size_t)M * ld), dxs((size_t)parts * K * ld / 2 + 16), dys((size_t)3 * M * ld / 2 + 16);
+    X.p = dx.p;
+    Y.p = dy.p;
+    R.p = dr.p;
+    HIP_CHECK(hipMemset(X.p, 0, sizeof(float) * (size_t)K * ld));
+    HIP_CHECK(hipMemcpy2D(X.p, sizeof(float) * ld, x, sizeof(float) * N, sizeof(float) * N, K, hipMemcpyHostToDevice));
+    if (res) HIP_CHECK(hipMemcpy2D(R.p, sizeof(float) * ld, res, sizeof(float) * N, sizeof(float) * N, M, hipMemcpyHostToDevice));
+    SplitPlanes xs;
+    xs.p = dxs.p;
+    xs.parts = parts;
+    xs.C = (int)K;
+    xs.L = (int)N;
+    xs.ld = ld;
+    xs.pstride = (int64_t)K * ld;
+    split_planes(X, xs, nullptr);
+    SplitPlanes ys;
+    ys.p = dys.p;
+    ys.parts = split_out;
+    ys.C = (int)M;
+    ys.L = (int)N;
+    ys.ld = ld;
+    ys.pstride = (int64_t)M * ld;
+    // split_out: 0 = f32 result only; 2 / 3 = the result is ALSO written as that many bf16 parts, and y returns their sum (what a consumer sees)
+    auto run = [&]() { conv_bfs(pc, xs, &Y, split_out ? &ys : nullptr, nullptr, 1, nullptr, act, res ? &R : nullptr); };
+    run();
+    HIP_CHECK(hipDeviceSynchronize());
+    if (iters > 0 && ms) {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) run();
+        HIP_CHECK(hipEventRecord(e1, nullptr));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        *ms = t / (float)iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    HIP_CHECK(hipMemcpy2D(y, sizeof(float) * N, Y.p, sizeof(float) * ld, sizeof(float) * N, M, hipMemcpyDeviceToHost));
+    if (split_out) {
+        std::vector<uint16_t> hs((size_t)split_out * M * ld);
+        HIP_CHECK(hipMemcpy(hs.data(), ys.p, hs.size() * 2, hipMemcpyDeviceToHost));
+        for (int64_t m = 0; m < M; ++m)
+            for (int64_t n = 0; n < N; ++n) {
+                float acc = 0.f;
+                for (int pp = split_out - 1; pp >= 0; --pp) {
+                    const uint32_t u = (uint32_t)hs[((size_t)pp * M + m) * ld + n] << 16;
+                    float f;
+                    memcpy(&f, &u, 4);
+                    acc += f;
+                }
+                y[(size_t)m * N + n] = acc;
+            }
+    }
+    API_END
+}
+
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters, float* ms) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));

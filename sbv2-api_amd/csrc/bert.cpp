@@ -13,6 +13,10 @@
 
 namespace sbv2 {
 
+// Default arithmetic of DeBERTa's GEMMs.  bf16x6 is f32-grade (it changes the integer durations no more often than a re-ordered f32
+// sum does: profiles/r03_flip_rate.json) at 6/16 of the f32 MFMA's cost.
+int default_bert_bfs_parts() { return 3; }
+
 // modeling_deberta_v2.py:57-69 (float32 arithmetic like torch)
 std::vector<int> BertModel::bucket_table(int maxS, int buckets, int max_rel) {
     std::vector<int> tab(2 * maxS - 1);
@@ -65,17 +69,28 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
                      "the container holds deberta.encoder.conv.* but its config has no conv_kernel_size: refusing to ignore the ConvLayer");
     }
     SBV2_REQUIRE(cfg_.hidden % cfg_.heads == 0 && (cfg_.hidden / cfg_.heads) % 4 == 0, "head size must be a multiple of 4");
-    // GEMM / conv arithmetic outside the decoder: exact f32 MFMA (default) | split-bf16 | plain bf16 through the k-major variant of
-    // conv_cl.hip.  Measured on MI355X (round 1): the k-major variant transposes while staging (32 ds_write_b16 per thread and
-    // chunk) and reaches only ~48 TFLOP/s on these 1x1 shapes, slower than the f32 MFMA kernel, so it is opt-in only.
-    int gemm_parts = 0;   // DeBERTa has 1x1 products only: nothing would use the bf16 fragments by default
+    // Arithmetic of the 1x1 products (all of DeBERTa's GEMMs): SBV2_BERT_GEMM = f32 (exact f32 MFMA, gemm_conv.hip) | bf16x6 (three bf16
+    // parts per operand, six MFMAs per product: f32-grade, the dropped terms are 2^-24) | bf16x3 (two parts, three MFMAs, 2^-16: what
+    // BASELINE configs[2] calls "bf16 MFMA for the DeBERTa GEMMs"; the reference itself offers fp16 TensorRT for BERT, model.rs:11-17).
+    // Both split modes run on gemm_bfs.hip with the activation parts written by LayerNorm / the previous product / split_planes.
+    // (SBV2_GEMM=bf16: the k-major variant of conv_cl.hip for the ConvLayer's k = 3 product, opt-in as before.)
+    int gemm_parts = 0;
     if (const char* m = getenv("SBV2_GEMM")) {
         const std::string v(m);
         if (v == "f32") gemm_parts = 0;
         else if (v == "bf16") gemm_parts = 1;
-        else if (v == "f16") gemm_parts = 0;   // a VITS-side knob; DeBERTa decides the integer durations and stays exact f32
+        else if (v == "f16") gemm_parts = 0;   // a VITS-side knob
         else SBV2_REQUIRE(v == "bf16x3" || v.empty(), "SBV2_GEMM must be f32, bf16x3, bf16 or f16");
     }
+    bfs_parts_ = default_bert_bfs_parts();
+    if (const char* m = getenv("SBV2_BERT_GEMM")) {
+        const std::string v(m);
+        if (v == "f32") bfs_parts_ = 0;
+        else if (v == "bf16x3") bfs_parts_ = 2;
+        else if (v == "bf16x6") bfs_parts_ = 3;
+        else SBV2_REQUIRE(v.empty(), "SBV2_BERT_GEMM must be f32, bf16x3 or bf16x6");
+    }
+    if ((cfg_.hidden & 15) || (cfg_.inter & 15)) bfs_parts_ = 0;   // the split kernel wants 16-deep chunks
     ws_.reset(new WeightStore(blob, gemm_parts));
     const int Hc = cfg_.hidden;
     SBV2_REQUIRE(cfg_.vocab >= 1 && Hc >= 4 && cfg_.layers >= 1 && cfg_.inter >= 1, "bad DeBERTa config");
@@ -118,15 +133,18 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     for (int i = 0; i < cfg_.layers; ++i) {
         const std::string p = "deberta.encoder.layer." + std::to_string(i) + ".";
         Layer& L = layers_[i];
+        // (q, k, v alone serve the load-time position projections and the long-sequence path: exact f32 only)
         L.q = ws_->linear(p + "attention.self.query_proj");
         L.k = ws_->linear(p + "attention.self.key_proj");
         L.v = ws_->linear(p + "attention.self.value_proj");
+        ws_->set_bfs_parts(bfs_parts_);   // the four products of a layer's forward also get their pre-split bf16 fragments
         L.o = ws_->linear(p + "attention.output.dense");
         L.qkv = ws_->conv_cat({p + "attention.self.query_proj", p + "attention.self.key_proj", p + "attention.self.value_proj"});
         L.ln1_g = ws_->tensor(p + "attention.output.LayerNorm.weight", {H});
         L.ln1_b = ws_->tensor(p + "attention.output.LayerNorm.bias", {H});
         L.ffn1 = ws_->linear(p + "intermediate.dense");
         L.ffn2 = ws_->linear(p + "output.dense");
+        ws_->set_bfs_parts(0);
         L.ln2_g = ws_->tensor(p + "output.LayerNorm.weight", {H});
         L.ln2_b = ws_->tensor(p + "output.LayerNorm.bias", {H});
         ws_->expect(L.q, p + "query_proj", H, H, 1);
@@ -252,7 +270,16 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     const int lds = round_up(maxT, 4);
     Plane X = arena_.plane(H, N), QKV = arena_.plane(3 * H, N), ctx = arena_.plane(H, N), A = arena_.plane(H, N);
     Plane Q = QKV.rows(0, H), Kp = QKV.rows(H, H), Vp = QKV.rows(2 * H, H);
-    Plane F = arena_.plane(cfg_.inter, N);
+    const int SP = bfs_parts_;
+    // f32 path: F holds gelu(ffn1); split path: the FFN intermediate exists only as bf16 parts (its one reader is the next product)
+    Plane F = SP ? Plane{} : arena_.plane(cfg_.inter, N);
+    SplitPlanes Xs, As, Cs, Fs;
+    if (SP) {
+        Xs = alloc_split(arena_, SP, H, N);
+        As = alloc_split(arena_, SP, H, N);
+        Cs = alloc_split(arena_, SP, H, N);
+        Fs = alloc_split(arena_, SP, cfg_.inter, N);
+    }
     Plane E0{};   // the embedding output is ConvLayer's input (modeling_deberta_v2.py:664: self.conv(hidden_states, output_states, input_mask))
     if (cfg_.conv_k > 0) E0 = arena_.plane(H, N);
     std::vector<AttnGroup> ag_s, ag_m, ag_l;
@@ -361,9 +388,12 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         fl_tw += 2.0 * (double)a.T * wlen * d;
     }
 
+    if (SP) split_planes(X, Xs, stream_);
     for (int li = 0; li < cfg_.layers; ++li) {
         const Layer& Ly = layers_[li];
-        conv_plain(Ly.qkv, X, QKV, 1, 0, nullptr, 1, stream_);   // q | k | v in one product (k-major planes)
+        // q | k | v in one product (k-major planes)
+        if (SP) conv_bfs(Ly.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_);
+        else conv_plain(Ly.qkv, X, QKV, 1, 0, nullptr, 1, stream_);
         if (ngS)
             deberta_attention(d_agS, ngS, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo_s, wlen_s, d_tab, maxT - 1, span, inv_scale,
                               lay.d_mask, d, ctx.p, ctx.ld, stream_);
@@ -378,17 +408,26 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
             deberta_softmax(d_agL, ngL, maxTL, S, C2P, P2C, d_tab, maxT - 1, span, win_lo, win_ld, inv_scale, lay.d_mask, stream_);
             grouped(VT, H, S, lds, ctx.p, ctx.ld, d_g + 3 * ngL, d, maxTL, 1.0f, fl_tt);
         }
-        conv_plain(Ly.o, ctx, A, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &X);
-        layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
-        conv_plain(Ly.ffn1, A, F, 1, 0, nullptr, 1, stream_, ACT_GELU);
-        conv_plain(Ly.ffn2, F, X, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &A);
-        layernorm_ch(X, X, Ly.ln2_g, Ly.ln2_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
-        if (li == 0 && cfg_.conv_k > 0) {
+        if (SP) {
+            split_planes(ctx, Cs, stream_);
+            conv_bfs(Ly.o, Cs, &A, nullptr, nullptr, 1, stream_, ACT_NONE, &X);
+            layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_, &As);
+            conv_bfs(Ly.ffn1, As, nullptr, &Fs, nullptr, 1, stream_, ACT_GELU);
+            conv_bfs(Ly.ffn2, Fs, &X, nullptr, nullptr, 1, stream_, ACT_NONE, &A);
+        } else {
+            conv_plain(Ly.o, ctx, A, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &X);
+            layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);
+            conv_plain(Ly.ffn1, A, F, 1, 0, nullptr, 1, stream_, ACT_GELU);
+            conv_plain(Ly.ffn2, F, X, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &A);
+        }
+        const bool conv_next = li == 0 && cfg_.conv_k > 0;
+        layernorm_ch(X, X, Ly.ln2_g, Ly.ln2_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_, (SP && !conv_next) ? &Xs : nullptr);
+        if (conv_next) {
             // ConvLayer (:461-470): out = act(conv(embeddings), zeroed where attention_mask == 0); x = LayerNorm(layer0 + out) * mask.
             // act(0) == 0 for gelu / tanh / relu, so zeroing the sum's masked columns before the LayerNorm and again after it (lay.d_mask
-            // = attention mask) gives the same zeros the reference's output * input_mask produces.
+            // = attention mask) gives the same zeros the reference's output * input_mask produces.  (k = 3: stays on the f32 / conv_cl path.)
             conv_plain(conv_, E0, A, 1, cfg_.conv_k / 2, nullptr, 1, stream_, cfg_.conv_act, 1.0f, &X);
-            layernorm_ch(A, X, conv_g_, conv_b_, cfg_.eps, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
+            layernorm_ch(A, X, conv_g_, conv_b_, cfg_.eps, ACT_NONE, nullptr, 0, lay.d_mask, stream_, SP ? &Xs : nullptr);
         }
     }
     out_ = X;

@@ -239,6 +239,56 @@ struct ConvClParams {
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
 bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t stream);   // conv_cl_small.hip
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 1x1 products on k-major planes (gemm_bfs.hip): Y[m][n] = epi(sum_k W[m][k] X[k][n]) on the bf16 matrix cores with both
+// operands PRE-SPLIT into bf16 parts (2 parts = hi + lo, three MFMAs per product, relative error ~2^-16: "bf16x3"; 3 parts = hi + mid + lo,
+// six MFMAs, the dropped terms are 2^-24: f32-grade, "bf16x6").  The activation parts are written by the producer of the plane (LayerNorm,
+// the previous product's epilogue, split_planes), so the GEMM loop has no conversion: both tiles go L2 -> LDS by LDS-DMA.
+// ---------------------------------------------------------------------------------------------
+struct SplitPlanes {        // [part][C][ld] bf16, the column axis contiguous; same column indexing as the f32 plane it mirrors
+    void* p = nullptr;
+    int parts = 0, C = 0, L = 0, ld = 0;
+    int64_t pstride = 0;    // elements from one part to the next
+    SplitPlanes rows(int c0, int n) const {
+        SplitPlanes s = *this;
+        s.p = static_cast<char*>(p) + (size_t)c0 * ld * 2;
+        s.C = n;
+        return s;
+    }
+};
+inline SplitPlanes alloc_split(Arena& ar, int parts, int C, int L) {   // same pitch rule as Arena::plane
+    SplitPlanes s;
+    s.parts = parts;
+    s.C = C;
+    s.L = L;
+    s.ld = round_up(L, 64);
+    s.pstride = (int64_t)C * s.ld;
+    s.p = ar.alloc((size_t)parts * C * s.ld * 2);
+    return s;
+}
+struct BfsWeights {         // W as MFMA A fragments: [K / 16][nmt][parts][64 lanes][8] bf16 (lane l: row 32 mt + (l & 31), k = 16 c + 8 (l >> 5) + j)
+    void* w = nullptr;
+    int nmt = 0, parts = 0, M = 0, K = 0;
+};
+struct GemmBfsParams {
+    BfsWeights W;
+    SplitPlanes X;
+    int M = 0, N = 0, K = 0;
+    float* Y = nullptr;     // f32 result plane [M][ldy] (may be null when only the split copy is wanted)
+    int ldy = 0;
+    SplitPlanes Ys;         // optional split copy of the result (parts = 0: none)
+    const float* bias = nullptr;   // per row
+    int act = ACT_NONE;
+    float alpha = 1.0f, beta = 1.0f;
+    const float* R = nullptr;
+    int ldr = 0;
+    const unsigned char* mask = nullptr;   // output column c is kept iff mask[c / mask_div]
+    int mask_div = 1;
+};
+bool gemm_bfs_usable(const GemmBfsParams& p);
+void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream);
+void split_planes(Plane in, SplitPlanes out, hipStream_t stream);   // out parts = bf16 split of `in` (same columns)
+
 // One fused ResBlock1 step y' = beta * (conv2(lrelu(conv1(lrelu(y), dil) + b1)) + b2 + y) on a channels-last plane (respair_cl.hip)
 struct ResPairParams {
     const float* X = nullptr;   // y  [N][C]

@@ -1,0 +1,464 @@
+// Split-bf16 1x1 products on k-major planes, gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16), operands pre-split.
+//
+//   Y[m][n] = epi( sum_k W[m][k] * X[k][n] ),   W = sum_p Wp, X = sum_p Xp  (bf16 parts, most significant first)
+//
+//   PARTS = 2 ("bf16x3"): lo*hi + hi*lo + hi*hi, three MFMAs per product, dropped term 2^-16 relative.
+//   PARTS = 3 ("bf16x6"): lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi, six MFMAs; the dropped terms (mid*lo, lo*mid, lo*lo) are
+//                         2^-24 relative, i.e. the rounding of an f32 product: f32-grade results at 6/16 of the f32 MFMA's cost.
+//
+// What the reference does here: nothing -- these are the MatMul / Gemm / 1x1 Conv nodes ONNX Runtime executes inside `session.run`
+// (crates/sbv2_core/src/bert.rs:11, model.rs:91); the reference itself offers reduced precision for them (TensorRT fp16 for BERT,
+// model.rs:11-17; TF32 on CUDA, model.rs:27-30).
+//
+// Why a third GEMM kernel: conv_cl.hip converts f32 -> bf16 parts while staging, which at ONE tap costs as much as the MFMAs it feeds
+// (43-75 TFLOP/s measured), and gemm_conv.hip is pinned to the f32 pipe (157 TFLOP/s peak).  Here the parts exist in HBM already (written by
+// the producer of the plane: LayerNorm, the previous product's epilogue, split_planes), so a chunk's tiles go L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) into a ring, the loop holds no VALU work besides addresses, and
+//   * A (weights) is packed at load time as MFMA fragments (1 KB lane-linear blocks -> conflict-free ds_read_b128),
+//   * B (activations) stays a k-major image [16 k][NT n] and is read with ds_read_b64_tr_b16 (the transposing LDS read: a lane receives 4
+//     consecutive k of its column); the 64-byte segments of a row are XOR-swizzled on the DMA's SOURCE address so that the four k rows a
+//     half-wave touches land on four different bank quarters (conflict-free; cdna_hip_programming.md T10 / rule 21).
+// One workgroup = 4 waves = (32 TM WM) x (32 TN WN) outputs; per 16-deep chunk: barrier, fragment reads of chunk c + 1 into the second
+// register set, DMAs of chunk c + NSLOT - 1, MFMAs of chunk c.  The per-element summation order (chunk, then the term order above) does
+// not depend on the tile shape, so a batch row equals the single-utterance call bit for bit whatever configuration either picks.
+#include <atomic>
+#include <type_traits>
+
+#include "common.h"
+
+namespace sbv2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void bfs_lds_t;
+typedef const __attribute__((address_space(1))) void bfs_gbl_t;
+typedef __attribute__((address_space(3))) s16x4 bfs_lds_s16x4;
+
+struct BfsKernelParams {
+    GemmBfsParams p;
+    int mask_shift;
+    int gm, gn, total;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void bfs_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS reads the compiler does not count (see the kernel): 16 bytes per lane / the transposing 4 x 16-bit read
+template <int OFF>
+__device__ __forceinline__ bf16x8 bfs_read_b128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 bfs_read_tr(unsigned addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// XOR applied to the 64-byte segment index of row k of the B image (row = RB bytes): rows k .. k + 3 of one segment column then fall on
+// four different quarters of the 256-byte bank row
+template <int RB>
+__device__ __forceinline__ int bfs_swz(int k) {
+    if (RB >= 256) return k & 3;
+    if (RB == 128) return (k >> 1) & 1;
+    return 0;
+}
+
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT>
+__global__ __launch_bounds__(256) void gemm_bfs_kernel(const BfsKernelParams kp) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN, RB = NT * 2;
+    constexpr int NMT = MT / 32;
+    constexpr int A_BYTES = NMT * PARTS * 1024, B_PART = 16 * RB, B_BYTES = PARTS * B_PART;
+    constexpr int CH = A_BYTES + B_BYTES;     // one 16-deep chunk
+    constexpr int SLOT = KSUB * CH;           // a ring slot = KSUB chunks = the span between two barriers
+    constexpr int GA = A_BYTES / 1024, GBP = B_PART / 1024, GB = GBP * PARTS;
+    static_assert((GA + GB) % 4 == 0 && GBP >= 1, "the DMAs of a chunk are dealt evenly over the four waves");
+    constexpr int PERW = (GA + GB) / 4;
+    static_assert((NSLOT - 1) * KSUB * PERW <= 60, "vmcnt is a 6-bit counter");
+    const GemmBfsParams& p = kp.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs; each XCD walks a contiguous range of tiles (m fastest), so the
+    // tiles co-resident on one L2 share their weight rows / activation columns.  Speed only.
+    const int per = gridDim.x >> 3;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= kp.total) return;
+    const int tmi = t % kp.gm, tni = t / kp.gm;
+    const int m0 = tmi * MT, n0 = tni * NT;
+    const int M = p.M, N = p.N;
+    const int nchunks = p.K >> 4;
+
+    // ---- DMA descriptors: DMA g of a chunk (g < GA: weight fragment blocks, else 1 KB pieces of the activation parts) belongs to wave g % 4
+    const char* src[PERW];
+    int64_t step[PERW];
+    int dst[PERW];
+#pragma unroll
+    for (int q = 0; q < PERW; ++q) {
+        const int gi = wave + 4 * q;
+        if (gi < GA) {
+            const int mt = min(m0 / 32 + gi / PARTS, p.W.nmt - 1), part = gi % PARTS;   // row tiles outside the problem only feed outputs never stored
+            src[q] = static_cast<const char*>(p.W.w) + ((int64_t)mt * PARTS + part) * 1024 + lane * 16;
+            step[q] = (int64_t)p.W.nmt * PARTS * 1024;
+            dst[q] = gi * 1024;
+        } else {
+            const int gb = gi - GA;
+            const int part = gb / GBP, r = gb % GBP;
+            const int pos = r * 1024 + lane * 16;
+            const int k = pos / RB, bq = pos % RB;
+            const int seg = (bq >> 6) ^ bfs_swz<RB>(k);
+            int n = n0 + (((bq & 63) | (seg << 6)) >> 1);
+            if (n >= N) n = 0;   // columns outside the problem only feed outputs never stored
+            src[q] = static_cast<const char*>(p.X.p) + ((int64_t)part * p.X.pstride + (int64_t)k * p.X.ld + n) * 2;
+            step[q] = (int64_t)16 * p.X.ld * 2;
+            dst[q] = A_BYTES + part * B_PART + r * 1024;
+        }
+    }
+    // LDS destinations are wave-uniform (M0): made provably so once, or hipcc re-derives them per DMA with v_readfirstlane
+    int sdst[PERW];
+#pragma unroll
+    for (int q = 0; q < PERW; ++q) sdst[q] = __builtin_amdgcn_readfirstlane(dst[q]);
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    auto dma = [&](int q, int off) {   // DMA q of the next chunk to stage (chunk image at LDS offset off); advances its source pointer
+        __builtin_amdgcn_global_load_lds((bfs_gbl_t*)src[q], (bfs_lds_t*)(uintptr_t)(lds0 + off + sdst[q]), 16, 0, 0);
+        src[q] += step[q];
+    };
+
+    // ---- fragment addresses
+    const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const int kq = 8 * (g16 >> 1) + q4;
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int bcol = ((wn * TN + j) * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+        const int seg = (bcol >> 6) ^ bfs_swz<RB>(kq);
+        boff[j] = A_BYTES + kq * RB + ((bcol & 63) | (seg << 6));
+    }
+    const int aoff = (wm * TM) * PARTS * 1024 + lane * 16;
+
+    // Fragment reads are inline asm: hipcc waits vmcnt(0) in front of the ds_read_tr builtin whenever an LDS-DMA is pending (it treats the
+    // intrinsic as a possible write to the DMA's LDS range), which drains the ring every chunk; and for its own ds_reads it waits lgkmcnt(0)
+    // before the MFMAs of chunk c although they only need the reads issued one chunk earlier.  With asm reads the kernel counts for itself:
+    // one lgkmcnt(0) per chunk, placed BEFORE the next chunk's reads are issued (cdna_hip_programming.md 5.7 form iii).
+    struct Frags {
+        bf16x8 a[TM][PARTS];
+        s16x4 blo[TN][PARTS], bhi[TN][PARTS];
+    };
+    constexpr int NRA = TM * PARTS, NR = NRA + TN * PARTS * 2;   // LDS reads of one chunk's fragments
+    // read r of a chunk: r < NRA the weight fragments (row tile, part), then per column tile (part, k half)
+    auto read_one = [&](Frags& f, auto rc, unsigned aaddr, const unsigned (&baddr)[TN]) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r < NRA) {
+            f.a[r / PARTS][r % PARTS] = bfs_read_b128<r * 1024>(aaddr);
+        } else {
+            constexpr int e = r - NRA, j = e / (2 * PARTS), pp = (e % (2 * PARTS)) / 2, half = e & 1;
+            if constexpr (half == 0) f.blo[j][pp] = bfs_read_tr<pp * B_PART>(baddr[j]);
+            else f.bhi[j][pp] = bfs_read_tr<pp * B_PART + 4 * RB>(baddr[j]);
+        }
+    };
+    auto frag_b = [](const Frags& f, int j, int pp) {
+        const s16x4 lo = f.blo[j][pp], hi = f.bhi[j][pp];
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // MFMA n of a chunk: term-major (every accumulator takes term t before any takes t + 1: TM * TN independent MFMAs between two that
+    // share an accumulator); the terms in ascending magnitude
+    constexpr int NT_ = PARTS == 2 ? 3 : 6, NM = NT_ * TM * TN;
+    auto mfma_one = [&](const Frags& f, auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr int t = n / (TM * TN), i = (n % (TM * TN)) / TN, j = n % TN;
+        constexpr int pa = PARTS == 2 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 2 || t == 3 ? 1 : 0));
+        constexpr int pb = PARTS == 2 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4 ? 1 : 0));
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], frag_b(f, j, pb), acc[i][j], 0, 0, 0);
+    };
+
+    // ---- ring of NSLOT slots of KSUB chunks.  Chunk c lives at LDS offset (c / KSUB % NSLOT) * SLOT + (c % KSUB) * CH.
+    // Prologue: chunks 0 .. (NSLOT - 1) KSUB are staged.  Iteration c: [the fragments of chunk c, requested an iteration ago, have landed: lgkmcnt(0)];
+    // when chunk c + 1 opens a new slot: {this wave's DMAs of that slot have landed (counted vmcnt), barrier: everybody's have, and
+    // everybody is done reading the slot of chunk c}; then the MFMAs of chunk c with the fragment reads of chunk c + 1 dealt two per gap
+    // over the first gaps and the DMAs of chunk c + 1 + (NSLOT - 1) KSUB (it goes to the slot just released) one per gap after them.
+    // An MFMA holds the matrix pipe for 32 cycles during which the wave can issue a few other instructions; issued as one block in front
+    // of the MFMAs, the 12 reads and 4 DMAs (~100 cycles each to issue) left the pipe idle for as long as the MFMAs keep it busy (28 % of
+    // peak with one wave per SIMD); reads placed late in the chunk exposed their latency at the next lgkmcnt(0).  sched_barrier pins the
+    // interleave (the reads are asm and stay where they are while the MFMAs would move).
+    constexpr int AHEAD = (NSLOT - 1) * KSUB;   // chunks staged beyond c + 1 in the steady state
+    const int npre = min(AHEAD + 1, nchunks);   // chunks 0 .. AHEAD: iteration c then stages chunk c + 1 + AHEAD
+    for (int c = 0; c < npre; ++c)
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) dma(q, (c / KSUB) * SLOT + (c % KSUB) * CH);
+    if (npre == AHEAD + 1) bfs_wait_vm<(AHEAD + 1 - KSUB) * PERW>();   // slot 0 has landed
+    else bfs_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    Frags fa, fb;
+    {
+        unsigned baddr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) baddr[j] = lds0 + boff[j];
+        static_for<0, NR>([&](auto rc) { read_one(fa, rc, lds0 + aoff, baddr); });
+    }
+    int roff = KSUB > 1 ? CH : SLOT;   // LDS offset of chunk c + 1 (nchunks >= 2 whenever it is used)
+    int rsub = KSUB > 1 ? 1 : 0;
+    // LDS offset of chunk g = c + 1 + AHEAD (the next one to stage): it goes to the slot of chunks c + 1 - KSUB .. c, released at the barrier
+    int dsub = (AHEAD + 1) % KSUB;
+    int doff = (((AHEAD + 1) / KSUB) % NSLOT) * SLOT + dsub * CH;
+    constexpr int DG = NM >= PERW + (NR + 1) / 2 ? PERW : 1;                     // gaps that carry DMAs (after the reads)
+    constexpr int RPG_MIN = (NR + (NM - DG) - 1) / (NM - DG);
+    constexpr int RPG = RPG_MIN > 2 ? RPG_MIN : 2;                                // fragment reads per MFMA gap
+    constexpr int RG = (NR + RPG - 1) / RPG;                                      // gaps that carry reads
+    constexpr int DPG = (PERW + DG - 1) / DG;                                     // DMAs per gap
+    static_assert(RG + DG <= NM && DG * DPG >= PERW, "the chunk's MFMA gaps hold its reads and DMAs");
+    auto step_chunk = [&](int c, Frags& cur, Frags& nxt, auto mainc, auto barc) {
+        constexpr bool MAIN = decltype(mainc)::value;   // steady state: chunk c + 1 + AHEAD exists, no conditions in the body
+        constexpr bool BAR = decltype(barc)::value;     // chunk c + 1 opens a new slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of chunk c (requested one chunk ago)
+        if (BAR) {
+            if (MAIN) bfs_wait_vm<(AHEAD - KSUB) * PERW>();
+            else bfs_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool rd = MAIN || c + 1 < nchunks, st = MAIN || c + 1 + AHEAD < nchunks;
+        unsigned baddr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) baddr[j] = lds0 + roff + boff[j];
+        const unsigned aaddr = lds0 + roff + aoff;
+        static_for<0, NM>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            mfma_one(cur, nc);
+            if constexpr (n < RG) {
+                if (rd) static_for<n * RPG, (n + 1) * RPG < NR ? (n + 1) * RPG : NR>([&](auto rc) { read_one(nxt, rc, aaddr, baddr); });
+            } else if constexpr (n < RG + DG) {
+                if (st) static_for<(n - RG) * DPG, (n - RG + 1) * DPG < PERW ? (n - RG + 1) * DPG : PERW>([&](auto qc) { dma(decltype(qc)::value, doff); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // advance the two running LDS offsets by one chunk
+        if (KSUB == 1) {
+            roff = roff + SLOT == NSLOT * SLOT ? 0 : roff + SLOT;
+            doff = doff + SLOT == NSLOT * SLOT ? 0 : doff + SLOT;
+        } else {
+            if (++rsub == KSUB) {
+                rsub = 0;
+                roff += CH;
+                if (roff == NSLOT * SLOT) roff = 0;
+            } else {
+                roff += CH;
+            }
+            if (++dsub == KSUB) {
+                dsub = 0;
+                doff += CH;
+                if (doff == NSLOT * SLOT) doff = 0;
+            } else {
+                doff += CH;
+            }
+        }
+    };
+    // chunk c + 1 opens a new slot iff (c + 1) % KSUB == 0; the loop is unrolled by two (fragment register sets ping-pong), KSUB <= 2
+    static_assert(KSUB == 1 || KSUB == 2, "one or two chunks per slot");
+    using BarEven = std::integral_constant<bool, KSUB == 1>;   // c even
+    using BarOdd = std::true_type;                             // c odd
+    int c = 0;
+    const int nmain = nchunks - 1 - AHEAD;   // c < nmain: chunk c + 1 + AHEAD exists
+    for (; c + 2 <= nmain; c += 2) {
+        step_chunk(c, fa, fb, std::true_type{}, BarEven{});
+        step_chunk(c + 1, fb, fa, std::true_type{}, BarOdd{});
+    }
+    for (; c + 2 <= nchunks; c += 2) {
+        step_chunk(c, fa, fb, std::false_type{}, BarEven{});
+        step_chunk(c + 1, fb, fa, std::false_type{}, BarOdd{});
+    }
+    if (c < nchunks) step_chunk(c, fa, fb, std::false_type{}, BarEven{});
+    __syncthreads();   // the epilogue re-uses the ring as its transpose tiles
+
+    // ---- epilogue: each wave passes its 32 x 32 tiles through a private LDS tile and leaves with 16-byte stores (8 lanes = 128 bytes of a row)
+    float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+    const int lcol = lane & 31, lh = lane >> 5;
+    const int lrow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lcol] = acc[i][j][r];
+            const int n = n0 + (wn * TN + j) * 32 + c4;
+            const int mb = m0 + (wm * TM + i) * 32 + lrow;
+            f32x4v av[4], rr[4];
+            float brow[4];
+            // everything read from global memory before the first store (loads and stores share the in-order vmcnt queue)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                av[ps] = *reinterpret_cast<const f32x4v*>(tile + (ps * 8 + lrow) * 36 + c4);
+                const int m = min(mb + ps * 8, M - 1);
+                brow[ps] = p.bias ? p.bias[m] : 0.f;
+                if (p.R) rr[ps] = *reinterpret_cast<const f32x4v*>(p.R + (int64_t)m * p.ldr + min(n, N - 4));
+            }
+            bool keep[4] = {true, true, true, true};
+            if (p.mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int oc = min(n + e, N - 1);
+                    keep[e] = p.mask[kp.mask_shift >= 0 ? (oc >> kp.mask_shift) : (oc / p.mask_div)] != 0;
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int m = mb + ps * 8;
+                if (m >= M || n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = av[ps][e] + brow[ps];
+                    if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (p.act == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                    else if (p.act == ACT_TANH) x = tanhf(x);
+                    x *= p.alpha;
+                    if (p.R) x += rr[ps][e];
+                    x *= p.beta;
+                    v[e] = keep[e] ? x : 0.f;
+                }
+                if (p.Y) *reinterpret_cast<f32x4v*>(p.Y + (int64_t)m * p.ldy + n) = f32x4v{v[0], v[1], v[2], v[3]};
+                if (p.Ys.parts) {
+                    float res[4] = {v[0], v[1], v[2], v[3]};
+                    for (int pp = 0; pp < p.Ys.parts; ++pp) {
+                        bf16x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = (__bf16)res[e];
+                            res[e] -= (float)h[e];
+                        }
+                        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.Ys.p) + (int64_t)pp * p.Ys.pstride + (int64_t)m * p.Ys.ld + n) = h;
+                    }
+                }
+            }
+        }
+}
+
+// ---- f32 plane -> bf16 parts (for producers that do not emit the parts themselves) ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_planes(Plane in, SplitPlanes out) {
+    const int64_t nq = (int64_t)in.C * (in.ld >> 2);
+    const int lq = in.ld >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+        const int c = (int)(q / lq), j = (int)(q - (int64_t)c * lq) * 4;
+        if (j >= out.ld) continue;
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(in.p + (int64_t)c * in.ld + j);
+        float res[4] = {v[0], v[1], v[2], v[3]};
+        for (int pp = 0; pp < out.parts; ++pp) {
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (__bf16)res[e];
+                res[e] -= (float)h[e];
+            }
+            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out.p) + (int64_t)pp * out.pstride + (int64_t)c * out.ld + j) = h;
+        }
+    }
+}
+
+void split_planes(Plane in, SplitPlanes out, hipStream_t stream) {
+    SBV2_REQUIRE(in.C == out.C && out.parts >= 1 && out.parts <= 3 && (in.ld & 3) == 0 && (out.ld & 3) == 0 && out.ld <= in.ld + 63,
+                 "split_planes: shape mismatch");
+    const int64_t nq = (int64_t)in.C * (in.ld >> 2);
+    const int grid = (int)std::min<int64_t>((nq + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_split_planes, dim3(grid), dim3(256), 0, stream, in, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------
+bool gemm_bfs_usable(const GemmBfsParams& p) {
+    return p.W.w && (p.W.parts == 2 || p.W.parts == 3) && p.X.p && p.X.parts == p.W.parts && (p.K & 15) == 0 && p.K >= 16 && (p.N & 3) == 0 &&
+           (p.X.ld & 7) == 0 && (!p.Y || (p.ldy & 3) == 0) && (!p.R || (p.ldr & 3) == 0) && (!p.Ys.parts || (p.Ys.ld & 3) == 0) && p.N >= 4;
+}
+
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT>
+static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream) {
+    constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN;
+    constexpr int SLOT = KSUB * ((MT / 32) * PARTS * 1024 + PARTS * 16 * NT * 2);
+    const GemmBfsParams& p = kp.p;
+    kp.gm = (p.M + MT - 1) / MT;
+    kp.gn = (p.N + NT - 1) / NT;
+    kp.total = kp.gm * kp.gn;
+    const size_t lds = std::max<size_t>((size_t)NSLOT * SLOT, 4 * 32 * 36 * sizeof(float));
+    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT>;
+    static std::atomic<uint64_t> lds_allowed{0};
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = conv_prof_active();
+    if (prof) {
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(round_up(kp.total, 8)), dim3(256), lds, stream, kp);
+    HIP_CHECK(hipGetLastError());
+    if (prof) {
+        HIP_CHECK(hipEventRecord(e1, stream));
+        conv_prof_add(PARTS == 2 ? 24 : 25, 2.0 * p.M * (double)p.N * p.K, e0, e1);
+    }
+}
+
+void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
+    SBV2_REQUIRE(gemm_bfs_usable(p), "gemm_bfs: operands do not fit the split-bf16 kernel");
+    SBV2_REQUIRE(p.X.C >= p.K && p.W.K == p.K && p.W.M == p.M, "gemm_bfs: shape mismatch");
+    if (p.M <= 0 || p.N <= 0) return;
+    BfsKernelParams kp;
+    kp.p = p;
+    kp.mask_shift = -1;
+    if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
+        int s = 0;
+        while ((1 << s) < p.mask_div) ++s;
+        kp.mask_shift = s;
+    }
+    auto blocks = [&](int mt, int nt) { return (int64_t)((p.M + mt - 1) / mt) * ((p.N + nt - 1) / nt); };
+    static const int force = getenv("SBV2_BFS_CFG") ? atoi(getenv("SBV2_BFS_CFG")) : 0;   // experiments: 1 = 128 x 128 always, 2 = 64 x 64 always
+    static const int slots = getenv("SBV2_BFS_SLOTS") ? atoi(getenv("SBV2_BFS_SLOTS")) : 0;   // experiments: ring depth of the 128 x 128 tiles
+    const bool big = force == 1 || (force != 2 && blocks(128, 128) >= 128);
+    // Ring depth = bytes in flight per CU: a chunk's DMAs take ~1 us to land under load, a chunk's MFMAs 0.2 - 0.4 us.  Grids that leave one
+    // workgroup per CU take the whole LDS (144 KB); larger grids run two workgroups per CU with 80 / 72 KB each.
+    const bool lone = blocks(128, 128) <= 256;
+    const bool k32 = (p.K & 31) == 0;
+    // configuration id (SBV2_BFS_SLOTS, experiments): tens = chunks per slot, units = slots
+    if (p.W.parts == 2) {
+        if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8>(kp, stream);
+        else if (slots == 15) launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5>(kp, stream);
+        else if (slots == 19) launch_bfs_cfg<2, 2, 2, 2, 2, 1, 9>(kp, stream);
+        else if (k32 && slots == 22) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 2>(kp, stream);
+        else if (k32 && slots == 24) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4>(kp, stream);
+        else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4>(kp, stream);
+        else launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5>(kp, stream);
+    } else {
+        if (!big) launch_bfs_cfg<3, 1, 1, 2, 2, 1, 6>(kp, stream);
+        else if (slots == 13) launch_bfs_cfg<3, 2, 2, 2, 2, 1, 3>(kp, stream);
+        else if (slots == 16) launch_bfs_cfg<3, 2, 2, 2, 2, 1, 6>(kp, stream);
+        else if (k32 && slots == 23) launch_bfs_cfg<3, 2, 2, 2, 2, 2, 3>(kp, stream);
+        else if (lone) launch_bfs_cfg<3, 2, 2, 2, 2, 1, 6>(kp, stream);
+        else launch_bfs_cfg<3, 2, 2, 2, 2, 1, 3>(kp, stream);
+    }
+}
+
+}  // namespace sbv2

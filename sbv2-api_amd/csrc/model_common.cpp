@@ -46,6 +46,48 @@ void WeightStore::expect(const PackedConv& c, const std::string& prefix, int cou
                     "], the model config implies [" + std::to_string(cout) + "," + std::to_string(cin) + "," + std::to_string(k) + "]");
 }
 
+static inline uint16_t bfs_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bfs_bf16_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts) {
+    SBV2_REQUIRE((parts == 2 || parts == 3) && (K & 15) == 0 && M >= 1, "pack_bfs: bad shape");
+    BfsWeights b;
+    b.M = M;
+    b.K = K;
+    b.parts = parts;
+    b.nmt = round_up((M + 31) / 32, 4);   // whole 128-row tiles: a tile's fragment blocks of a chunk are one contiguous DMA source
+    const int nchunks = K / 16;
+    std::vector<uint16_t> h((size_t)nchunks * b.nmt * parts * 512, 0);
+    for (int ch = 0; ch < nchunks; ++ch)
+        for (int mt = 0; mt < b.nmt; ++mt) {
+            uint16_t* blk = h.data() + (((size_t)ch * b.nmt + mt) * parts) * 512;
+            for (int l = 0; l < 64; ++l) {
+                const int m = mt * 32 + (l & 31);
+                if (m >= M) continue;
+                for (int j = 0; j < 8; ++j) {
+                    float r = w[(size_t)m * K + ch * 16 + 8 * (l >> 5) + j];
+                    for (int p = 0; p < parts; ++p) {
+                        const uint16_t q = bfs_bf16_rne(r);
+                        blk[p * 512 + l * 8 + j] = q;
+                        r -= bfs_bf16_f32(q);
+                    }
+                }
+            }
+        }
+    b.w = ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
+    return b;
+}
+
 PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
     const HostTensor& t = blob_.get(prefix + ".weight");
     SBV2_REQUIRE(t.dims.size() == 3, "conv weight must be [Cout][Cin][k]: " + prefix);
@@ -65,6 +107,7 @@ PackedConv WeightStore::conv(const std::string& prefix, bool bias) {
         pc.cl = pack_cl(*this, t.data, pc.cout, pc.cin, pc.k, cl_parts_, nullptr);
         pc.cl.bias = pc.bias;
     }
+    if (bfs_parts_ && pc.k == 1 && (pc.cin & 15) == 0) pc.bfs = pack_bfs(*this, t.data, pc.cout, pc.cin, bfs_parts_);
     return pc;
 }
 
@@ -99,6 +142,12 @@ PackedConv WeightStore::conv_cat(const std::vector<std::string>& prefixes) {
     }
     pc.w = upload(h.data(), h.size());
     pc.bias = upload(b.data(), b.size());
+    if (bfs_parts_ && (pc.cin & 15) == 0) {
+        std::vector<float> rows((size_t)pc.cout * pc.cin);
+        for (int co = 0; co < pc.cout; ++co)
+            for (int ci = 0; ci < pc.cin; ++ci) rows[(size_t)co * pc.cin + ci] = h[(size_t)ci * pc.lda + co];
+        pc.bfs = pack_bfs(*this, rows.data(), pc.cout, pc.cin, bfs_parts_);
+    }
     return pc;
 }
 
@@ -119,6 +168,7 @@ PackedConv WeightStore::linear(const std::string& prefix) {
         pc.cl = pack_cl(*this, t.data, pc.cout, pc.cin, 1, cl_parts_, nullptr);
         pc.cl.bias = pc.bias;
     }
+    if (bfs_parts_ && (pc.cin & 15) == 0) pc.bfs = pack_bfs(*this, t.data, pc.cout, pc.cin, bfs_parts_);
     return pc;
 }
 
@@ -270,6 +320,38 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
     p.mask = mask;
     p.mask_div = mask_div;
     launch_conv(p, s);
+}
+
+// 1x1 product on the bf16 matrix cores with pre-split operands (gemm_bfs.hip); y and / or ys receive the result.
+void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
+              hipStream_t s, int act, const Plane* res, float alpha, float beta) {
+    SBV2_REQUIRE(w.bfs.parts && w.k == 1 && xs.C == w.cin && xs.parts == w.bfs.parts, "conv_bfs: operands were not prepared for the split-bf16 kernel");
+    GemmBfsParams p;
+    p.W = w.bfs;
+    p.X = xs;
+    p.M = w.cout;
+    p.N = xs.L;
+    p.K = w.cin;
+    if (y) {
+        SBV2_REQUIRE(y->C == w.cout && y->L == xs.L, "conv_bfs: output shape");
+        p.Y = y->p;
+        p.ldy = y->ld;
+    }
+    if (ys) {
+        SBV2_REQUIRE(ys->C == w.cout && ys->L == xs.L, "conv_bfs: split output shape");
+        p.Ys = *ys;
+    }
+    p.bias = w.bias;
+    p.act = act;
+    p.alpha = alpha;
+    p.beta = beta;
+    if (res) {
+        p.R = res->p;
+        p.ldr = res->ld;
+    }
+    p.mask = mask;
+    p.mask_div = mask_div;
+    launch_gemm_bfs(p, s);
 }
 
 // The two halves of a conv -> activation -> conv pair whose wide intermediate stays channels-last (the encoders' FFN: 192 -> 768 -> 192):

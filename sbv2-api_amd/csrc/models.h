@@ -22,6 +22,7 @@ struct PackedConv {
     float* bias = nullptr;
     int cout = 0, cin = 0, k = 1, lda = 0;
     ClConv cl;
+    BfsWeights bfs;   // 1x1 products only: pre-split bf16 fragments for gemm_bfs.hip (parts = 0: not packed)
     int64_t tap_stride() const { return (int64_t)cin * lda; }
 };
 // One ConvTranspose1d split into groups of output phases that share the same input taps.
@@ -57,6 +58,8 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
 class WeightStore;
 // w is [M][K][k] (Conv1d layout); K is zero-padded to a multiple of 16
 ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
+// w is [M][K] (Linear / 1x1 conv): bf16 parts (2 = hi + lo, 3 = hi + mid + lo) as MFMA A fragments; K must be a multiple of 16
+BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts);
 
 class WeightStore {
   public:
@@ -64,6 +67,9 @@ class WeightStore {
     explicit WeightStore(const Blob& b, int cl_parts = 0) : blob_(b), cl_parts_(cl_parts) {}
     int cl_parts() const { return cl_parts_; }
     void set_cl_parts(int parts) { cl_parts_ = parts; }
+    // 1x1 products loaded from now on also get their pre-split fragments for gemm_bfs.hip (0 = none, 2 = bf16x3, 3 = bf16x6)
+    int bfs_parts() const { return bfs_parts_; }
+    void set_bfs_parts(int parts) { bfs_parts_ = parts; }
     ~WeightStore();
     float* upload(const float* host, size_t n);
     float* tensor(const std::string& name);                      // raw copy
@@ -80,7 +86,7 @@ class WeightStore {
 
   private:
     const Blob& blob_;
-    int cl_parts_ = 0;
+    int cl_parts_ = 0, bfs_parts_ = 0;
     std::vector<void*> allocs_;
     size_t bytes_ = 0;
 };
@@ -89,6 +95,9 @@ class WeightStore {
 void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const unsigned char* mask, int mask_div, hipStream_t s,
                 int act = ACT_NONE, float pre_slope = 1.0f, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f,
                 int accumulate = 0);
+// 1x1 product with pre-split bf16 operands (gemm_bfs.hip): y (f32 plane) and / or ys (bf16 parts) receive act(W x + b) * alpha (+ res) * beta
+void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
+              hipStream_t s, int act = ACT_NONE, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f);
 // y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
 bool conv_km_to_cl(const PackedConv& w, Plane x, float* y, int ldy, int dil, int pad_l, const unsigned char* mask, int mask_div,
                    hipStream_t s);
@@ -96,6 +105,8 @@ bool conv_cl_to_km(const PackedConv& w, const float* x, int ldx, Plane y, int di
                    hipStream_t s, float pre_slope, const Plane* res);
 void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_t s);
 
+// the library-wide default arithmetic of DeBERTa's 1x1 products (bert.cpp documents the choice): bf16 parts per operand, 0 = exact f32
+int default_bert_bfs_parts();
 struct BertConfig {
     int vocab, hidden, layers, heads, inter, buckets, max_rel;
     float eps;
@@ -128,6 +139,7 @@ class BertModel {
     };
     int device_;
     BertConfig cfg_;
+    int bfs_parts_ = 0;   // 0 = exact-f32 products, 2 = bf16x3, 3 = bf16x6 (gemm_bfs.hip)
     std::shared_ptr<WeightStore> ws_;
     float *emb_, *emb_g_, *emb_b_;
     PackedConv conv_;                       // encoder.conv.conv (k = conv_k)

@@ -19,8 +19,9 @@ struct AttnGroup {
 void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamma, const float* beta, float eps,
                       Plane out, hipStream_t s);
 // out = mask * ( act(LN_c(in)) + res )   (act: ACT_NONE / ACT_GELU; res optional; in == out allowed)
+// split != null: the result is also written as bf16 parts (the operand format of gemm_bfs.hip)
 void layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res,
-                  int ldr, const unsigned char* mask, hipStream_t s);
+                  int ldr, const unsigned char* mask, hipStream_t s, const SplitPlanes* split = nullptr);
 // out = mask * gelu(LN_c(depthwise_conv_k3(in, dilation) + b))
 void dds_dw_ln_gelu(Plane in, Plane out, const float* w, const float* b, int dil, const float* gamma,
                     const float* beta, const unsigned char* mask, hipStream_t s);

@@ -64,7 +64,7 @@ void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamm
 template <bool DW, int CPT, int COLS>
 __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps,
                                                        int act, const float* res, int ldr, const unsigned char* mask,
-                                                       const float* dw_w, const float* dw_b, int dil) {
+                                                       const float* dw_w, const float* dw_b, int dil, SplitPlanes sp) {
     constexpr int G = 256 / COLS;   // channel groups: thread (tx, ty) owns column tx and channels ty, ty + G, ...
     __shared__ float red[G][COLS + 1];
     const int tx = threadIdx.x % COLS, ty = threadIdx.x / COLS;
@@ -129,11 +129,24 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     const float rstd = 1.0f / sqrtf(var / C + eps);
     if (!ok) return;
     const bool keep = !mask || mask[n];
+    // the result, and (sp.parts != 0) its bf16 parts for the split-bf16 products that read this plane (gemm_bfs.hip)
+    auto put = [&](int c, float v) {
+        out.p[(size_t)c * out.ld + n] = v;
+        if (sp.parts) {
+            __bf16* q = static_cast<__bf16*>(sp.p) + (size_t)c * sp.ld + n;
+            float r = v;
+            for (int pp = 0; pp < sp.parts; ++pp) {
+                const __bf16 h = (__bf16)r;
+                q[(size_t)pp * sp.pstride] = h;
+                r -= (float)h;
+            }
+        }
+    };
     auto emit = [&](int c, float x) {
         float v = (x - mean) * rstd * gamma[c] + beta[c];
         if (act == ACT_GELU) v = gelu_exact(v);
         if (res) v += res[(size_t)c * ldr + n];
-        out.p[(size_t)c * out.ld + n] = keep ? v : 0.f;
+        put(c, keep ? v : 0.f);
     };
     if (CPT > 0 && CPT <= 32) {
         // gamma / beta / residual of every owned channel are read before the first store: a load issued after a store is not usable
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
                 float v = (xv[k] - mean) * rstd * gv[k] + bv[k];
                 if (act == ACT_GELU) v = gelu_exact(v);
                 if (res) v += rv[k];
-                out.p[(size_t)(ty + G * k) * out.ld + n] = keep ? v : 0.f;
+                put(ty + G * k, keep ? v : 0.f);
             }
     } else if (CPT > 0) {
 #pragma unroll
@@ -164,24 +177,25 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
 }
 template <bool DW>
 static void launch_layernorm(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
-                             const unsigned char* mask, const float* w, const float* b, int dil, hipStream_t s) {
+                             const unsigned char* mask, const float* w, const float* b, int dil, hipStream_t s, SplitPlanes sp = SplitPlanes{}) {
+    SBV2_REQUIRE(!sp.parts || (sp.C == out.C && sp.ld >= out.L), "layernorm: split output shape");
     const dim3 block(256);
     // few, wide columns (DeBERTa: 1024 channels x ~2k tokens): 8 columns x 32 channel groups per workgroup, or the grid is 64 workgroups
     if (!DW && in.C >= 512 && in.L <= 8192 && in.C <= 32 * 32) {
-        hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 8>), dim3((in.L + 7) / 8), block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+        hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 8>), dim3((in.L + 7) / 8), block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
         return;
     }
     const dim3 grid((in.L + 31) / 32);
     const int cpt = (in.C + 7) / 8;
-    if (cpt <= 8) hipLaunchKernelGGL((k_layernorm_ch<DW, 8, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else if (cpt <= 24) hipLaunchKernelGGL((k_layernorm_ch<DW, 24, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else if (cpt <= 32) hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else if (cpt <= 128) hipLaunchKernelGGL((k_layernorm_ch<DW, 128, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
-    else hipLaunchKernelGGL((k_layernorm_ch<DW, 0, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil);
+    if (cpt <= 8) hipLaunchKernelGGL((k_layernorm_ch<DW, 8, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
+    else if (cpt <= 24) hipLaunchKernelGGL((k_layernorm_ch<DW, 24, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
+    else if (cpt <= 32) hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
+    else if (cpt <= 128) hipLaunchKernelGGL((k_layernorm_ch<DW, 128, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
+    else hipLaunchKernelGGL((k_layernorm_ch<DW, 0, 32>), grid, block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
 }
 void layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps, int act, const float* res, int ldr,
-                  const unsigned char* mask, hipStream_t s) {
-    launch_layernorm<false>(in, out, gamma, beta, eps, act, res, ldr, mask, nullptr, nullptr, 1, s);
+                  const unsigned char* mask, hipStream_t s, const SplitPlanes* split) {
+    launch_layernorm<false>(in, out, gamma, beta, eps, act, res, ldr, mask, nullptr, nullptr, 1, s, split ? *split : SplitPlanes{});
 }
 void dds_dw_ln_gelu(Plane in, Plane out, const float* w, const float* b, int dil, const float* gamma, const float* beta,
                     const unsigned char* mask, hipStream_t s) {

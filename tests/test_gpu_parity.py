@@ -43,6 +43,46 @@ def test_conv1d_kernel(cin, cout, k, dil, L):
         np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
 
 
+def _gemm_bfs(x, w, b, r, parts, act=0, split_out=0):
+    m, k = w.shape
+    n = x.shape[1]
+    y = np.empty((m, n), np.float32)
+    P = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).ctypes.data_as(f32p)
+    xs, ws = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(w, np.float32)
+    bs = None if b is None else np.ascontiguousarray(b, np.float32)
+    rs = None if r is None else np.ascontiguousarray(r, np.float32)
+    _lib.check(_lib.lib().sbv2_debug_gemm_bfs(0, P(xs), P(ws), P(bs), P(rs), m, n, k, parts, act, split_out, 0, y.ctypes.data_as(f32p), None))
+    return y
+
+
+@pytest.mark.parametrize("K,M,N", [(16, 1, 4), (32, 29, 68), (48, 50, 132), (96, 192, 900), (192, 576, 2052), (1024, 1024, 68), (1024, 3072, 260),
+                                   (4096, 1024, 132), (1024, 4096, 2112), (64, 130, 388), (1024, 1024, 2112), (192, 192, 28704)])
+def test_gemm_bfs_kernel(K, M, N):
+    """The split-bf16 1x1 GEMM on k-major planes (gemm_bfs.hip: pre-split operands, LDS-DMA ring, transposing LDS reads), every tile / ring
+    configuration the launcher can pick, against an f64 product of the SAME f32 inputs.  Tolerances: bf16x3 drops the lo*lo term
+    (2^-16 relative per product: ~2e-5 on O(1) sums), bf16x6 only 2^-24 terms (f32-grade: compared with numpy's own f32 product)."""
+    rng = np.random.default_rng(K + M + N)
+    x = rng.standard_normal((K, N)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    ref = w.astype(np.float64) @ x.astype(np.float64) + b[:, None] + r
+    err32 = float(np.abs((w @ x + b[:, None] + r).astype(np.float32) - ref).max())
+    y3 = _gemm_bfs(x, w, b, r, 2)
+    y6 = _gemm_bfs(x, w, b, r, 3)
+    assert float(np.abs(y3 - ref).max()) < 1e-4
+    assert float(np.abs(y6 - ref).max()) < max(4 * err32, 2e-5)
+    # GELU epilogue without bias / residual; the result re-emitted as bf16 parts (what the next product reads) loses nothing at 3 parts
+    g = O.gelu(w.astype(np.float64) @ x.astype(np.float64)) if hasattr(O, "gelu") else None
+    if g is not None:
+        y6g = _gemm_bfs(x, w, None, None, 3, act=2)
+        assert float(np.abs(y6g - g).max()) < max(4 * err32, 2e-5)
+        y6s = _gemm_bfs(x, w, None, None, 3, act=2, split_out=3)
+        assert float(np.abs(y6s - y6g).max()) <= 1e-7 * max(1.0, float(np.abs(y6g).max()))
+        y3s = _gemm_bfs(x, w, None, None, 2, act=2, split_out=2)
+        assert float(np.abs(y3s - g).max()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,k,dil,L", [(1024, 1024, 1, 1, 66), (1024, 3072, 1, 1, 130), (4096, 1024, 1, 1, 66), (1024, 4096, 1, 1, 35),
                                               (192, 576, 1, 1, 897), (768, 192, 1, 1, 897), (192, 29, 1, 1, 300), (96, 192, 1, 1, 4), (1024, 192, 1, 1, 130),
                                               (64, 50, 1, 1, 19), (192, 768, 3, 1, 257), (768, 192, 3, 1, 257), (256, 256, 3, 1, 130), (192, 192, 5, 1, 61),
