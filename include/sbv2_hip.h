@@ -216,6 +216,11 @@ int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int
 /* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; the
  * default comes from SBV2_SKINNY_MAX).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
 int sbv2_debug_set_skinny_max(int workgroups);
+/* Diagnostics (MI355X_MICROARCH.md "DVFS give-back" item 6): the dominant decoder convolution (C x C, k taps, channels-last, split-bf16,
+   128-row workgroups) on random data, `seconds` of back-to-back launches, then out4 = {in-kernel shader clock in MHz = d s_memtime /
+   d s_memrealtime x 100 (median over workgroups), ms per launch, shader cycles of a workgroup's chunk loop, workgroups stamped}.
+   abl: 0 = the kernel, 1 = without its MFMAs, 2 = its MFMAs only, 3 = staging + barriers only. */
+int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4);
 /* y[M][N] = act(w[M][K] x[K][N] + bias) (+ res) through the split-bf16 1x1 GEMM (gemm_bfs.hip; parts 2 = bf16x3, 3 = bf16x6).  split_out != 0:
    the result is also emitted as that many bf16 parts and y returns their sum.  iters > 0: average launch time in *ms.  Test hook. */
 int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,

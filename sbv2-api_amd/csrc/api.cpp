@@ -459,6 +459,91 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
 
 int sbv2_debug_set_skinny_max(int workgroups) { return set_skinny_max(workgroups); }
 
+int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(out4 && C >= 128 && (C & 127) == 0 && k >= 1 && k <= kMaxTaps && L >= 256 && abl >= 0 && abl <= 3, "bad arguments");
+    std::vector<float> w((size_t)C * C * k), bias((size_t)C, 0.1f), x((size_t)L * C);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() {   // N(0,1)-ish random data: zero or constant operands would let the chip hold a higher clock (DVFS give-back, items 1 and 7)
+        float a = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            a += (float)((st >> 40) * (1.0 / 16777216.0)) - 0.5f;
+        }
+        return a * 1.7320508f;
+    };
+    for (auto& v : w) v = rnd() / std::sqrt((float)(C * k));
+    for (auto& v : x) v = rnd();
+    Blob b = one_conv_blob(w.data(), bias.data(), {C, C, k}, C);
+    WeightStore ws(b);
+    ClConv c = pack_cl(ws, w.data(), (int)C, (int)C, (int)k, 2, bias.data());
+    DevBuf dx(x.size()), dy(x.size());
+    HIP_CHECK(hipMemcpy(dx.p, x.data(), sizeof(float) * x.size(), hipMemcpyHostToDevice));
+    ConvClParams p;
+    p.X = dx.p;
+    p.ldx = (int)C;
+    p.NB = (int)L;
+    p.W = c.w;
+    p.nmt = c.nmt;
+    p.tm = c.tm;
+    p.split = 1;
+    p.M = (int)C;
+    p.N = (int)L;
+    p.K = (int)C;
+    p.ntaps = (int)k;
+    for (int j = 0; j < k; ++j) p.shift[j] = (int)(j * dilation - dilation * (k - 1) / 2);
+    p.Y = dy.p;
+    p.ldy = (int)C;
+    p.bias = c.bias;
+    p.pre_slope = 0.1f;
+    const int nwg = round_up((int)((L + 255) / 256), 8) * (c.nmt / 4);
+    unsigned long long* d_st = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 4 * nwg));
+    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 4 * nwg));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    // >= `seconds` of back-to-back launches so that the power management has settled, then one timed batch whose last launch's stamps are read
+    launch_conv_cl_diag(p, abl, d_st, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 20; ++i) launch_conv_cl_diag(p, abl, d_st, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t20 = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t20, e0, e1));
+    const int reps = std::max(20, (int)(seconds * 1e3 / std::max(t20 / 20.f, 1e-3f)));
+    for (int i = 0; i < reps; ++i) launch_conv_cl_diag(p, abl, d_st, nullptr);
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 50; ++i) launch_conv_cl_diag(p, abl, d_st, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t50 = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t50, e0, e1));
+    std::vector<unsigned long long> hs((size_t)4 * nwg);
+    HIP_CHECK(hipMemcpy(hs.data(), d_st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(d_st);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<double> mhz, cyc;
+    for (int g = 0; g < nwg; ++g) {
+        const unsigned long long t0 = hs[4 * g], r0 = hs[4 * g + 1], t1 = hs[4 * g + 2], r1 = hs[4 * g + 3];
+        if (r1 > r0 && t1 > t0) {
+            mhz.push_back((double)(t1 - t0) / (double)(r1 - r0) * 100.0);
+            cyc.push_back((double)(t1 - t0));
+        }
+    }
+    SBV2_REQUIRE(!mhz.empty(), "no stamps");
+    std::sort(mhz.begin(), mhz.end());
+    std::sort(cyc.begin(), cyc.end());
+    out4[0] = mhz[mhz.size() / 2];           // in-kernel shader clock, MHz (median over workgroups)
+    out4[1] = t50 / 50.0;                    // ms per launch
+    out4[2] = cyc[cyc.size() / 2];           // shader cycles of one workgroup's chunk loop (median)
+    out4[3] = (double)mhz.size();
+    API_END
+}
+
 int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
                         int parts, int act, int split_out, int64_t iters, float* y, float* ms) {
     API_BEGIN

@@ -238,6 +238,7 @@ struct ConvClParams {
 };
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
 bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t stream);   // conv_cl_small.hip
+void launch_conv_cl_diag(const ConvClParams& p, int abl, unsigned long long* stamps, hipStream_t stream);   // diagnostics (clock stamps + ablations)
 
 // ---------------------------------------------------------------------------------------------
 // Split-bf16 1x1 products on k-major planes (gemm_bfs.hip): Y[m][n] = epi(sum_k W[m][k] X[k][n]) on the bf16 matrix cores with both

@@ -63,11 +63,15 @@ struct ClKernelParams {
     int mask_shift;
     int aux_off;      // LDS offset of the staged bias / mask bytes (channels-last epilogue), 0 = not staged
     int mask_nshift;  // mask index of position n * out_stride + phase offset == n >> mask_nshift (power-of-two strides)
+    unsigned long long* stamps;   // diagnostics only (sbv2_debug_conv_cl_clock): per workgroup {s_memtime, s_memrealtime} before / after the chunk loop
 };
 
 // WM = 2: eight waves; waves 0-3 and 4-7 compute two DIFFERENT row groups (TM * 32 rows each) over the SAME 256 positions, so the activation
 // window of a position tile is fetched, converted and written to LDS once for 2 * TM * 32 output rows instead of once per TM * 32.
-template <int TM, int PREC, bool IN_KM, bool OUT_KM, int WM>
+// ABL (diagnostic builds only, never launched by the product path): 0 = the kernel; 1 = no MFMAs (fragments still read); 2 = MFMAs only (no
+// staging, no fragment reads inside the loop); 3 = staging + barriers only.  Used with the clock stamps to tell a scheduling bound from
+// a clock (power) bound: MI355X_MICROARCH.md "DVFS give-back" item 6.
+template <int TM, int PREC, bool IN_KM, bool OUT_KM, int WM, int ABL = 0>
 __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernelParams kp) {
     constexpr int kT = kClThreads * WM;
     constexpr bool SPLIT = PREC == PREC_BF16X3;
@@ -269,9 +273,14 @@ __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernel
     __syncthreads();
 
     const int lcol = lane & 31, lh = lane >> 5;
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (kp.stamps) {
+        st_t0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
-        if (more) {
+        if (more && ABL != 2) {
             load_w(chunk + 1);
             if (IN_KM) load_xk(chunk + 1);
             else if (((chunk + 1) & 1) == 0) load_x(chunk + 1);
@@ -299,6 +308,13 @@ __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernel
             }
         };
         auto mfma_frags = [&](const Frags& f) {
+            if (ABL == 1 || ABL == 3) {   // keep the fragments live, issue nothing
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(f.ah[i]), "v"(f.al[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(f.bh[j]), "v"(f.bl[j]));
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -311,6 +327,17 @@ __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernel
                 }
         };
         Frags fa, fb;
+        if (ABL == 2 || ABL == 3) {   // fragments read once per chunk (ABL 2: MFMA stream only; ABL 3: nothing but staging)
+            if (ABL == 2 || chunk == 0) {
+                load_frags(fa, 0);
+                load_frags(fb, 0);
+            }
+            if (ABL == 2)
+                for (int tap = 0; tap < ntaps; tap += 2) {
+                    mfma_frags(fa);
+                    if (tap + 1 < ntaps) mfma_frags(fb);
+                }
+        } else {
         load_frags(fa, 0);
         int tap = 0;
         for (; tap + 2 <= ntaps; tap += 2) {
@@ -320,13 +347,19 @@ __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernel
             mfma_frags(fb);
         }
         if (tap < ntaps) mfma_frags(fa);
-        __syncthreads();   // every wave is done reading this chunk's tiles
-        if (more) {
+        }
+        if (ABL != 2) __syncthreads();   // every wave is done reading this chunk's tiles
+        if (more && ABL != 2) {
             xchunk = chunk + 1;
             store_w();
             if (IN_KM) store_xk(); else store_x();
         }
-        __syncthreads();
+        if (ABL != 2) __syncthreads();
+    }
+    if (kp.stamps && tid == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = kp.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st_t0; o[1] = st_r0; o[2] = t1; o[3] = r1;
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
@@ -559,6 +592,7 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
     kp.sh_step = p.ntaps > 1 ? p.shift[1] - p.shift[0] : 0;
     for (int t = 1; t < p.ntaps; ++t) SBV2_REQUIRE(p.shift[t] - p.shift[t - 1] == kp.sh_step, "conv_cl: tap shifts must be an arithmetic progression");
     kp.nmt = p.nmt;
+    kp.stamps = nullptr;
     kp.mask_shift = -1;
     if (p.mask && p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0) {
         int s = 0;
@@ -582,6 +616,45 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         if (tm == 2) launch_cl_layout<2, PREC_BF16>(kp, stream);
         else launch_cl_layout<1, PREC_BF16>(kp, stream);
     }
+}
+
+// Diagnostic launch of the dominant configuration (128-row workgroups, split-bf16, channels-last in and out) with an ablation variant and
+// the clock stamps: stamps[4 * workgroup] = {s_memtime, s_memrealtime} before, {..} after the chunk loop.  Results of abl != 0 are garbage.
+void launch_conv_cl_diag(const ConvClParams& p, int abl, unsigned long long* stamps, hipStream_t stream) {
+    SBV2_REQUIRE(p.split && !p.in_km && !p.out_km && p.tm == 2 && (p.nmt & 3) == 0, "conv_cl diag: the 128-row split-bf16 configuration only");
+    ClKernelParams kp;
+    kp.p = p;
+    int smin = p.shift[0], smax = p.shift[0];
+    for (int t = 1; t < p.ntaps; ++t) {
+        smin = std::min(smin, p.shift[t]);
+        smax = std::max(smax, p.shift[t]);
+    }
+    kp.wshift0 = smin;
+    kp.xrows = kClNT + (smax - smin);
+    kp.sh0 = p.shift[0] - kp.wshift0;
+    kp.sh_step = p.ntaps > 1 ? p.shift[1] - p.shift[0] : 0;
+    kp.nmt = p.nmt;
+    kp.mask_shift = -1;
+    kp.stamps = stamps;
+    kp.wbytes = p.ntaps * 2 * 2 * 2 * 1024;
+    size_t lds = std::max<size_t>((size_t)kp.wbytes + (size_t)kp.xrows * 32 * 2, 4 * 2 * 64 * 36 * sizeof(float));
+    lds = (lds + 15) / 16 * 16;
+    kp.aux_off = (int)lds;
+    kp.mask_nshift = 0;
+    lds += 128 * sizeof(float) + kClNT;
+    const int ntx = round_up((p.N + kClNT - 1) / kClNT, 8);
+    dim3 grid(ntx * (kp.nmt / 4));
+    auto go = [&](auto kern) {
+        static std::atomic<uint64_t> lds_allowed{0};
+        (void)lds_allowed;
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, grid, dim3(kClThreads * 2), lds, stream, kp);
+        HIP_CHECK(hipGetLastError());
+    };
+    if (abl == 0) go(conv_cl_kernel<2, PREC_BF16X3, false, false, 2, 0>);
+    else if (abl == 1) go(conv_cl_kernel<2, PREC_BF16X3, false, false, 2, 1>);
+    else if (abl == 2) go(conv_cl_kernel<2, PREC_BF16X3, false, false, 2, 2>);
+    else go(conv_cl_kernel<2, PREC_BF16X3, false, false, 2, 3>);
 }
 
 }  // namespace sbv2
