@@ -216,6 +216,12 @@ int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int
 /* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; the
  * default comes from SBV2_SKINNY_MAX).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
 int sbv2_debug_set_skinny_max(int workgroups);
+/* 1 (default): the ResBlocks of the wide decoder stages run on conv_clx.hip; 0: on conv_cl.hip (same bits).  Returns the previous value. */
+int sbv2_debug_set_clx(int on);
+/* Same contract as sbv2_debug_conv1d_cl (mode 1) through conv_clx.hip: x is split into bf16 parts of lrelu(x, pre_slope) first (split_cl), the
+   convolution reads the parts; y = (conv + bias + res) * beta; ys_sum (optional) = hi + lo of the parts of lrelu(y, 0.1) the epilogue emits. */
+int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const float* bias, const float* res, int64_t cin, int64_t cout, int64_t k,
+                          int64_t L, int64_t dilation, float pre_slope, float beta, int64_t iters, float* y, float* ys_sum, float* ms);
 /* Diagnostics (MI355X_MICROARCH.md "DVFS give-back" item 6): the dominant decoder convolution (C x C, k taps, channels-last, split-bf16,
    128-row workgroups) on random data, `seconds` of back-to-back launches, then out4 = {in-kernel shader clock in MHz = d s_memtime /
    d s_memrealtime x 100 (median over workgroups), ms per launch, shader cycles of a workgroup's chunk loop, workgroups stamped}.

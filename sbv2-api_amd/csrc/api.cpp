@@ -458,11 +458,95 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
 }
 
 int sbv2_debug_set_skinny_max(int workgroups) { return set_skinny_max(workgroups); }
+int sbv2_debug_set_clx(int on) { return set_clx(on); }
+
+int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const float* bias, const float* res, int64_t cin, int64_t cout, int64_t k,
+                          int64_t L, int64_t dilation, float pre_slope, float beta, int64_t iters, float* y, float* ys_sum, float* ms) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(x && w && y, "bad arguments");
+    Blob b = one_conv_blob(w, bias, {cout, cin, k}, cout);
+    WeightStore ws(b);
+    ClConv c = pack_cl(ws, w, (int)cout, (int)cin, (int)k, 2, bias);
+    std::vector<float> xt((size_t)L * cin), yt((size_t)L * cout), rt;
+    for (int64_t ci = 0; ci < cin; ++ci)
+        for (int64_t n = 0; n < L; ++n) xt[(size_t)n * cin + ci] = x[(size_t)ci * L + n];
+    DevBuf dx(xt.size()), dy(yt.size()), dr(res ? yt.size() : 4);
+    HIP_CHECK(hipMemcpy(dx.p, xt.data(), sizeof(float) * xt.size(), hipMemcpyHostToDevice));
+    if (res) {
+        rt.resize(yt.size());
+        for (int64_t co = 0; co < cout; ++co)
+            for (int64_t n = 0; n < L; ++n) rt[(size_t)n * cout + co] = res[(size_t)co * L + n];
+        HIP_CHECK(hipMemcpy(dr.p, rt.data(), sizeof(float) * rt.size(), hipMemcpyHostToDevice));
+    }
+    DevBuf dxs(split_cl_bytes((int)cin, L) / 4 + 4), dys(split_cl_bytes((int)cout, L) / 4 + 4);
+    SplitClPlanes xs = make_split_cl(dxs.p, (int)cin, L, nullptr), ysp = make_split_cl(dys.p, (int)cout, L, nullptr);
+    split_cl(dx.p, (int)cin, L, (int)cin, pre_slope, xs, nullptr);
+    ConvClxParams p;
+    p.X = xs;
+    p.W = c.w;
+    p.nmt = c.nmt;
+    p.M = (int)cout;
+    p.N = (int)L;
+    p.K = (int)cin;
+    p.ntaps = (int)k;
+    p.shift0 = (int)(-dilation * (k - 1) / 2);
+    p.shift_step = (int)dilation;
+    p.Y = dy.p;
+    p.ldy = (int)cout;
+    if (ys_sum) {
+        p.Ys = ysp;
+        p.ys_slope = 0.1f;
+    }
+    p.bias = c.bias;
+    if (res) {
+        p.R = dr.p;
+        p.ldr = (int)cout;
+    }
+    p.beta = beta;
+    SBV2_REQUIRE(conv_clx_usable(p), "shape not supported by conv_clx");
+    launch_conv_clx(p, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (iters > 0 && ms) {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) launch_conv_clx(p, nullptr);
+        HIP_CHECK(hipEventRecord(e1, nullptr));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        *ms = t / (float)iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    HIP_CHECK(hipMemcpy(yt.data(), dy.p, sizeof(float) * yt.size(), hipMemcpyDeviceToHost));
+    for (int64_t co = 0; co < cout; ++co)
+        for (int64_t n = 0; n < L; ++n) y[(size_t)co * L + n] = yt[(size_t)n * cout + co];
+    if (ys_sum) {
+        const int64_t rows = kClxFront + L + kClxBack;
+        std::vector<uint16_t> hs(split_cl_bytes((int)cout, L) / 2);
+        HIP_CHECK(hipMemcpy(hs.data(), ysp.p, hs.size() * 2, hipMemcpyDeviceToHost));
+        auto f = [](uint16_t h) {
+            const uint32_t u = (uint32_t)h << 16;
+            float v;
+            memcpy(&v, &u, 4);
+            return v;
+        };
+        for (int64_t co = 0; co < cout; ++co)
+            for (int64_t n = 0; n < L; ++n) {
+                const size_t hi = (((size_t)(co >> 4) * 2) * rows + kClxFront + n) * 16 + (co & 15);
+                ys_sum[(size_t)co * L + n] = f(hs[hi + (size_t)rows * 16]) + f(hs[hi]);
+            }
+    }
+    API_END
+}
 
 int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
-    SBV2_REQUIRE(out4 && C >= 128 && (C & 127) == 0 && k >= 1 && k <= kMaxTaps && L >= 256 && abl >= 0 && abl <= 3, "bad arguments");
+    SBV2_REQUIRE(out4 && C >= 128 && (C & 127) == 0 && k >= 1 && k <= kMaxTaps && L >= 256 && ((abl >= 0 && abl <= 3) || abl == 10), "bad arguments");
     std::vector<float> w((size_t)C * C * k), bias((size_t)C, 0.1f), x((size_t)L * C);
     uint64_t st = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() {   // N(0,1)-ish random data: zero or constant operands would let the chip hold a higher clock (DVFS give-back, items 1 and 7)
@@ -497,13 +581,39 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     p.ldy = (int)C;
     p.bias = c.bias;
     p.pre_slope = 0.1f;
-    const int nwg = round_up((int)((L + 255) / 256), 8) * (c.nmt / 4);
+    int nwg = round_up((int)((L + 255) / 256), 8) * (c.nmt / 4);
+    // abl 10: the same convolution through conv_clx.hip (operands pre-split)
+    DevBuf dxs(abl == 10 ? split_cl_bytes((int)C, L) / 4 + 4 : 4);
+    ConvClxParams px;
+    if (abl == 10) {
+        SplitClPlanes xs = make_split_cl(dxs.p, (int)C, L, nullptr);
+        split_cl(dx.p, (int)C, L, (int)C, 0.1f, xs, nullptr);
+        px.X = xs;
+        px.W = c.w;
+        px.nmt = c.nmt;
+        px.M = (int)C;
+        px.N = (int)L;
+        px.K = (int)C;
+        px.ntaps = (int)k;
+        px.shift0 = (int)(-dilation * (k - 1) / 2);
+        px.shift_step = (int)dilation;
+        px.Y = dy.p;
+        px.ldy = (int)C;
+        px.bias = c.bias;
+        SBV2_REQUIRE(conv_clx_usable(px), "conv_clx: shape");
+        nwg *= 2;   // (64-row workgroups at most)
+    }
     unsigned long long* d_st = nullptr;
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 4 * nwg));
     HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 4 * nwg));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
+    px.stamps = d_st;
+    auto launch_conv_cl_diag = [&](const ConvClParams& q, int a, unsigned long long* st, hipStream_t sm) {
+        if (a == 10) launch_conv_clx(px, sm);
+        else sbv2::launch_conv_cl_diag(q, a, st, sm);
+    };
     // >= `seconds` of back-to-back launches so that the power management has settled, then one timed batch whose last launch's stamps are read
     launch_conv_cl_diag(p, abl, d_st, nullptr);
     HIP_CHECK(hipDeviceSynchronize());

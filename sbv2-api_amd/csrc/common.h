@@ -290,6 +290,44 @@ bool gemm_bfs_usable(const GemmBfsParams& p);
 void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream);
 void split_planes(Plane in, SplitPlanes out, hipStream_t stream);   // out parts = bf16 split of `in` (same columns)
 
+// ---------------------------------------------------------------------------------------------
+// conv_clx.hip: the ResBlock convolutions of the wide decoder stages on pre-split, pre-activated operands (LDS-DMA only, no staging registers)
+// ---------------------------------------------------------------------------------------------
+constexpr int kClxFront = 64;    // zero rows in front of every (chunk, part) plane: the left zero padding of the first tile's window
+constexpr int kClxBack = 384;    // ... and behind it: right padding + the last position tile's overhang + DMA piece rounding
+struct SplitClPlanes {           // bf16 hi / lo of a channels-last activation, chunk-major: [C / 16][2 parts][front + N + back][16] bf16
+    void* p = nullptr;
+    int C = 0;
+    int64_t N = 0;
+    int front = 0, back = 0;
+};
+size_t split_cl_bytes(int C, int64_t N);
+SplitClPlanes make_split_cl(void* mem, int C, int64_t N, hipStream_t stream);   // adopts `mem` (split_cl_bytes) and zeroes the halo rows
+void split_cl(const float* X, int ldx, int64_t N, int C, float slope, const SplitClPlanes& out, hipStream_t stream);   // out = split(lrelu(X))
+struct ConvClxParams {
+    SplitClPlanes X;            // operand: bf16 parts of the ACTIVATED input
+    const void* W = nullptr;    // pack_cl fragments (split-bf16: parts = 2), nmt row tiles of 32
+    int nmt = 0;
+    int M = 0, N = 0, K = 0, ntaps = 1;
+    int shift0 = 0, shift_step = 1;   // tap t reads position + shift0 + t * shift_step
+    float* Y = nullptr;         // f32 result [N][ldy] (optional)
+    int ldy = 0;
+    SplitClPlanes Ys;           // bf16 parts of lrelu(result, ys_slope) (optional: p == nullptr)
+    float ys_slope = 1.0f;
+    const float* bias = nullptr;
+    const float* R = nullptr;   // residual [N][ldr]
+    int ldr = 0;
+    float beta = 1.0f;
+    int accumulate = 0;         // Y += result
+    const unsigned char* mask = nullptr;   // position n is kept iff mask[n >> mask_shift]
+    int mask_shift = -1;
+    unsigned long long* stamps = nullptr;  // diagnostics: per workgroup {s_memtime, s_memrealtime} before / after the step loop
+};
+bool conv_clx_usable(const ConvClxParams& p);
+bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
+int set_clx(int on);  // returns the previous setting
+void launch_conv_clx(const ConvClxParams& p, hipStream_t stream);
+
 // One fused ResBlock1 step y' = beta * (conv2(lrelu(conv1(lrelu(y), dil) + b1)) + b2 + y) on a channels-last plane (respair_cl.hip)
 struct ResPairParams {
     const float* X = nullptr;   // y  [N][C]

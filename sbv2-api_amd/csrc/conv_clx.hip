@@ -1,0 +1,494 @@
+// Channels-last split-bf16 convolution of the HiFi-GAN ResBlocks on PRE-SPLIT, PRE-ACTIVATED operands: the restructured conv_cl.
+//
+//   Y[pos][m] (+)= ( sum_tap sum_k W_tap[m][k] * Xs[pos + shift_tap][k] + b[m] + R[pos][m] ) * beta,   Xs = bf16 hi + bf16 lo of lrelu(x)
+//   and / or   Ys = bf16 hi + lo of lrelu(that result)   (the operand of the NEXT convolution)
+//
+// Why (profiles/r03_conv_cl_clock_probe.jsonl, C = 128, k = 7): conv_cl's chunk loop costs 72.8k cycles per workgroup = 23.7k of MFMA issue
+// per wave + 44.7k of staging (global loads, f32 -> hi / lo conversion, LDS stores, two barriers per chunk): with one 8-wave workgroup per CU
+// (VGPR bound) every wave is in the same phase, so the halves ADD; the MFMA stream alone reaches 448 TFLOP/s against 302 for the kernel.
+// Here no wave ever stages through registers:
+//   * the activation operand exists in HBM as bf16 parts already, written by the producing epilogue (this kernel's, or split_cl for a stage
+//     input), CHUNK-MAJOR: for every 16-channel chunk and part a plane [front + N + back][16] bf16 (32-byte rows, zero halo rows), so a
+//     chunk's window [256 + span rows] is one contiguous run per part -> LDS-DMA straight into conv_cl's window layout (the 16-byte half
+//     swizzle is applied on the DMA's SOURCE address);
+//   * the weight fragments of one (chunk, tap) = 8 KB for 128 rows are LDS-DMA'd into a ring of kWR slots, seven steps ahead;
+//   * a step = one tap of one chunk: lgkmcnt(0) [its fragments, requested a step ago] -> counted vmcnt + barrier -> 12 MFMAs per wave with
+//     the 8 fragment reads of the next step and the DMAs dealt BETWEEN them.  Waves 0 .. 3 issue the weight DMAs, waves 4 .. 7 the window
+//     DMAs (vmcnt is per wave and in order: a wave that issued both kinds would have to wait for young window pieces to reach an old
+//     weight block).
+// Same fragments, same MFMA order (chunk, tap, lo*hi, hi*lo, hi*hi) as conv_cl: bit-identical results (tests/test_gpu_parity.py).
+#include <atomic>
+#include <type_traits>
+
+#include "common.h"
+
+namespace sbv2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void clx_lds_t;
+typedef const __attribute__((address_space(1))) void clx_gbl_t;
+
+constexpr int kClxNT = 256;          // positions per workgroup
+constexpr int kClxXR = 320;          // window rows per buffer (256 + span <= 64)
+
+struct ClxKernelParams {
+    ConvClxParams p;
+    int xrows;     // window rows actually read (256 + tap span)
+    int wshift0;   // first window row = n0 + wshift0
+    int sh0, sh_step;
+    int gy;        // row tiles (of 64 * WM rows)
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void clx_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        clx_static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void clx_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void clx_wait_vm_dyn(int n) {   // wave-uniform n
+    switch (n) {
+        case 0: clx_wait_vm<0>(); break;
+        case 1: clx_wait_vm<1>(); break;
+        case 2: clx_wait_vm<2>(); break;
+        case 3: clx_wait_vm<3>(); break;
+        case 4: clx_wait_vm<4>(); break;
+        case 5: clx_wait_vm<5>(); break;
+        case 6: clx_wait_vm<6>(); break;
+        case 7: clx_wait_vm<7>(); break;
+        case 8: clx_wait_vm<8>(); break;
+        case 9: clx_wait_vm<9>(); break;
+        default: clx_wait_vm<10>(); break;
+    }
+}
+__device__ __forceinline__ bf16x8 clx_read_b128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 clx_read_b128o(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// WM = 2: 8 waves, 128 rows x 256 positions (both 64-row wave groups read the one staged window), one workgroup per CU.
+// WM = 1: 4 waves, 64 rows; <= 80 KB of LDS so that TWO workgroups share a CU: their barriers, prologues and epilogues interleave.
+// kClxWR weight ring slots, kClxXB window buffers.
+template <int NTAPS, int WM, int kClxWR, int kClxXB>
+__global__ __launch_bounds__(256 * WM) void conv_clx_kernel(const ClxKernelParams kp) {
+    constexpr int NW = 4 * WM;                 // waves
+    constexpr int kClxPW = 20 / (NW / 2);      // window DMA pieces per window wave and chunk (2 parts x 10 pieces of 32 rows)
+    constexpr int PPT = (kClxPW + NTAPS - 2) / (NTAPS - 1);   // ... per tap (the last tap of a chunk carries none)
+    static_assert(PPT <= 8, "a tap's MFMA gaps hold its window pieces");
+    constexpr int WSLOT = 2 * WM * 2 * 1024;   // one (chunk, tap): 2 WM row tiles x 2 parts x 1 KB
+    constexpr int WBYTES = kClxWR * WSLOT;
+    constexpr int XPART = kClxXR * 32, XBUF = 2 * XPART;
+    constexpr int NWW = NW / 2;                // weight-DMA waves (the others carry the window)
+    constexpr int WPW = (2 * WM * 2) / NWW;    // weight DMAs per weight wave and step (= 2)
+    static_assert(WPW == 2, "two weight blocks per weight wave and step");
+    const ConvClxParams& p = kp.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, wm = wave >> 2;
+    // XCD-aware tile order as in conv_cl (1-D grid; the gy row tiles of one position tile share their window: ids 8 apart = same XCD)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int by = slot % kp.gy;
+    const int bx = (slot / kp.gy) * 8 + xcd;
+    const int n0 = bx * kClxNT;
+    if (n0 >= p.N) return;
+    const int m0 = (by * WM + wm) * 64;        // first output row of this WAVE's tile
+    const int M = p.M, N = p.N;
+    const int nchunks = p.K >> 4;
+    const int S = nchunks * NTAPS;             // steps
+
+    // ---- DMA sources.  All per-step state is incremental (running pointers and LDS offsets, wave-uniform where possible): the address
+    // arithmetic of a step sits in front of its first MFMA, right behind the barrier, where nothing overlaps it.
+    const bool wwave = wave < NWW;
+    // weight wave w: row tile w of the workgroup's 2 WM, both parts (2 KB contiguous per step); fragment order [chunk][mtile][tap][part]
+    const int mtw = min(by * 2 * WM + wave, kp.p.nmt - 1);
+    const char* wptr = static_cast<const char*>(p.W) + ((int64_t)mtw * NTAPS * 2) * 1024 + lane * 16;   // next weight block to fetch
+    const int64_t wjump = (int64_t)kp.p.nmt * NTAPS * 2 * 1024 - (int64_t)NTAPS * 2048;   // from a chunk's last tap to the next chunk's first
+    int wtap = 0;                                                                            // tap of the block wptr points at
+    const unsigned wdst0 = lds0 + (wave & (NWW - 1)) * 2048;
+    unsigned wdoff = 0;                                                                      // ring offset the next weight block goes to
+    auto dma_w = [&]() {
+        __builtin_amdgcn_global_load_lds((clx_gbl_t*)wptr, (clx_lds_t*)(uintptr_t)(wdst0 + wdoff), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((clx_gbl_t*)(wptr + 1024), (clx_lds_t*)(uintptr_t)(wdst0 + wdoff + 1024), 16, 0, 0);
+        wptr += 2048;
+        if (++wtap == NTAPS) {
+            wtap = 0;
+            wptr += wjump;
+        }
+        wdoff = wdoff + WSLOT == WBYTES ? 0 : wdoff + WSLOT;
+    };
+    // window wave v = wave - NWW: pieces e = v, v + NXW, ... of the 2 * npc pieces of a chunk (piece = 32 rows of one part); this lane:
+    // row = 32 * piece + lane / 2, 16-byte half (lane & 1) ^ ((row >> 3) & 1)  [conv_cl's LDS swizzle, applied on the source]
+    constexpr int NXW = NW - NWW;
+    const int npc = (kp.xrows + 31) >> 5;      // pieces per part
+    const int64_t xplane = (int64_t)(p.X.front + p.X.N + p.X.back) * 32;   // bytes of one (chunk, part) plane
+    const int xv = wave - NWW;
+    const char* xptr[kClxPW];                  // source of this wave's piece i in the next window to fetch
+    unsigned xdst[kClxPW];
+    int nmine = 0;                             // pieces of this window wave
+#pragma unroll
+    for (int i = 0; i < kClxPW; ++i) {
+        const int e = max(xv, 0) + i * NXW;
+        const int ec = min(e, 2 * npc - 1);
+        const int part = ec / npc, pc = ec - part * npc;
+        const int row = pc * 32 + (lane >> 1);
+        const int half = (lane & 1) ^ ((row >> 3) & 1);
+        xptr[i] = static_cast<const char*>(p.X.p) + (int64_t)part * xplane + ((int64_t)p.X.front + n0 + kp.wshift0 + row) * 32 + half * 16;
+        xdst[i] = __builtin_amdgcn_readfirstlane(lds0 + WBYTES + part * XPART + pc * 1024);
+        if (!wwave && e < 2 * npc) ++nmine;
+    }
+    nmine = __builtin_amdgcn_readfirstlane(nmine);
+    unsigned xdoff = 0;                        // buffer offset the next window goes to
+    auto dma_x = [&](auto ic) {                // piece i of the next window; the last piece of a window advances to the following chunk
+        constexpr int i = decltype(ic)::value;
+        if (i < nmine) {
+            __builtin_amdgcn_global_load_lds((clx_gbl_t*)xptr[i], (clx_lds_t*)(uintptr_t)(xdst[i] + xdoff), 16, 0, 0);
+            xptr[i] += 2 * xplane;
+        }
+    };
+    auto next_window = [&]() { xdoff = xdoff + XBUF == kClxXB * XBUF ? 0 : xdoff + XBUF; };
+
+    // ---- fragments
+    struct Frags {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+    };
+    const int lcol = lane & 31, lh = lane >> 5;
+    const unsigned abase = lds0 + (wm * 2) * 2048 + lane * 16;
+    unsigned boff0[NTAPS], boff1[NTAPS];       // window offsets of this lane's B fragments per tap (the XOR swizzle depends on the row)
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int r0 = wq * 64 + lcol + kp.sh0 + t * kp.sh_step, r1 = r0 + 32;
+        boff0[t] = lds0 + WBYTES + r0 * 32 + (((lh ^ (r0 >> 3)) & 1) << 4);
+        boff1[t] = lds0 + WBYTES + r1 * 32 + (((lh ^ (r1 >> 3)) & 1) << 4);
+    }
+    auto read_frag = [&](Frags& f, auto rc, unsigned aaddr, unsigned b0, unsigned b1) {
+        constexpr int r = decltype(rc)::value;   // 0..3: A (row tile, part); 4..7: B (position tile, part)
+        if constexpr (r == 0) f.ah[0] = clx_read_b128o<0>(aaddr);
+        else if constexpr (r == 1) f.al[0] = clx_read_b128o<1024>(aaddr);
+        else if constexpr (r == 2) f.ah[1] = clx_read_b128o<2048>(aaddr);
+        else if constexpr (r == 3) f.al[1] = clx_read_b128o<3072>(aaddr);
+        else if constexpr (r == 4) f.bh[0] = clx_read_b128o<0>(b0);
+        else if constexpr (r == 5) f.bl[0] = clx_read_b128o<XPART>(b0);
+        else if constexpr (r == 6) f.bh[1] = clx_read_b128o<0>(b1);
+        else f.bl[1] = clx_read_b128o<XPART>(b1);
+    };
+    unsigned wroff = 0;        // ring offset of the weight slot the NEXT fragment reads take (step s + 1 while step s runs)
+    unsigned xroff = 0;        // buffer offset of the window those reads take
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // MFMA n of a step: term-major (lo*hi for the four tiles, hi*lo, hi*hi): per accumulator the order of conv_cl
+    auto mfma_one = [&](const Frags& f, auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr int t = n / 4, i = (n & 3) >> 1, j = n & 1;
+        if constexpr (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        else if constexpr (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: the whole weight ring, the windows of chunks 0 .. kClxXB - 2 (iteration `chunk` stages chunk + kClxXB - 1)
+    if (wwave) {
+        const int npre = min(kClxWR, S);
+        for (int u = 0; u < npre; ++u) dma_w();
+        if (npre == kClxWR) clx_wait_vm<2 * (kClxWR - 1)>();
+        else clx_wait_vm<0>();
+    } else {
+        const int nwin = min(kClxXB - 1, nchunks);
+        for (int c = 0; c < nwin; ++c) {
+            clx_static_for<0, kClxPW>([&](auto ic) { dma_x(ic); });
+            next_window();
+        }
+        clx_wait_vm_dyn((nwin - 1) * nmine);   // chunk 0's window has landed
+    }
+    __builtin_amdgcn_s_barrier();
+    Frags fa, fb;
+    clx_static_for<0, 8>([&](auto rc) { read_frag(fa, rc, abase, boff0[0], boff1[0]); });
+    wroff = WSLOT == WBYTES ? 0 : WSLOT;
+
+    // One step: tap `tap` of chunk `chunk` (s = chunk * NTAPS + tap).  LAST = the step's successor opens a new chunk.
+    auto step = [&](int s, int chunk, auto tapc, Frags& cur, Frags& nxt) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr bool LAST = tap == NTAPS - 1;
+        constexpr int tapn = LAST ? 0 : tap + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of step s (requested a step ago): its weight slot is free after the barrier
+        if (wwave) {
+            // the weight blocks of step s + 1 have landed: everything but the blocks of steps s + 2 .. s + kClxWR - 1 (all issued in the steady state)
+            if (s + kClxWR - 1 < S) clx_wait_vm<2 * (kClxWR - 2)>();
+            else clx_wait_vm<0>();
+        } else if (LAST && chunk + 1 < nchunks) {
+            // the window of chunk + 1 has landed: everything but the windows of chunks + 2 .. + kClxXB - 1 (all issued in the steady state)
+            if (chunk + kClxXB - 1 < nchunks) clx_wait_vm_dyn((kClxXB - 2) * nmine);
+            else clx_wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool rd = s + 1 < S;
+        if (LAST) xroff = xroff + XBUF == kClxXB * XBUF ? 0 : xroff + XBUF;   // the next step reads the next chunk's window
+        const unsigned aaddr = abase + wroff, b0 = boff0[tapn] + xroff, b1 = boff1[tapn] + xroff;
+        wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
+        const bool stw = wwave && s + kClxWR < S;
+        const bool stx = !wwave && chunk + kClxXB - 1 < nchunks;
+        clx_static_for<0, 12>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            mfma_one(cur, nc);
+            if constexpr (n < 4) {
+                if (rd) {
+                    read_frag(nxt, std::integral_constant<int, 2 * n>{}, aaddr, b0, b1);
+                    read_frag(nxt, std::integral_constant<int, 2 * n + 1>{}, aaddr, b0, b1);
+                }
+            } else {
+                if constexpr (n == 5) {
+                    if (stw) dma_w();   // the blocks of step s + kClxWR, into the slot of step s (released by this step's barrier)
+                }
+                // window pieces of chunk + kClxXB - 1 (its buffer held chunk - 1): PPT per tap, one per gap, none with the chunk's last tap
+                if constexpr (tap < NTAPS - 1 && n - 4 < PPT) {
+                    constexpr int i = tap * PPT + (n - 4);
+                    if constexpr (i < kClxPW) {
+                        if (stx) dma_x(std::integral_constant<int, i>{});
+                    }
+                }
+                if constexpr (LAST && n == 4) {
+                    if (stx) next_window();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (p.stamps) {
+        st_t0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        // two chunks per iteration: NTAPS is odd, the fragment register sets ping-pong per step
+        const int s0 = chunk * NTAPS;
+        clx_static_for<0, NTAPS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr ((t & 1) == 0) step(s0 + t, chunk, tc, fa, fb);
+            else step(s0 + t, chunk, tc, fb, fa);
+        });
+        if (chunk + 1 < nchunks) {
+            clx_static_for<0, NTAPS>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (((NTAPS + t) & 1) == 0) step(s0 + NTAPS + t, chunk + 1, tc, fa, fb);
+                else step(s0 + NTAPS + t, chunk + 1, tc, fb, fa);
+            });
+        }
+    }
+    if (p.stamps && tid == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st_t0; o[1] = st_r0; o[2] = t1; o[3] = r1;
+    }
+    __syncthreads();   // the epilogue re-uses the rings as its transpose tiles
+
+    // ---- epilogue (conv_cl's channels-last epilogue): each wave transposes its 32 x 64 sub-tiles through a private LDS tile [64 positions][36]
+    // so that 8 consecutive lanes hold one full 128-byte line of a row; everything read from global memory is requested before the first store.
+    float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
+    const float beta = p.beta;
+    const int64_t yplane = (int64_t)(p.Ys.front + p.Ys.N + p.Ys.back) * 32;
+    const int c4 = (lane & 7) * 4;
+    const int nfirst = n0 + wq * 64 + (lane >> 3);
+    const float* trow = tile + (lane >> 3) * 36 + c4;
+    const float sl = p.ys_slope;
+    clx_static_for<0, 2>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *reinterpret_cast<f32x4v*>(tile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
+            }
+        const int m = m0 + i * 32 + c4;
+        const bool mok = m < M;
+        const int mc = mok ? m : 0;
+        const f32x4v b4 = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + mc) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        f32x4v rold[8], rres[8];
+        unsigned char keep[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t pp = min(nfirst + it * 8, N - 1);
+            if (p.accumulate) rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + mc);
+            if (p.R) rres[it] = *reinterpret_cast<const f32x4v*>(p.R + pp * p.ldr + mc);
+            keep[it] = p.mask ? p.mask[pp >> p.mask_shift] : 1;
+        }
+        float* yp = p.Y ? p.Y + (int64_t)nfirst * p.ldy + m : nullptr;
+        const int64_t ystep = (int64_t)8 * p.ldy;
+        // bf16 parts of lrelu(result), chunk-major (4 channels = 8 bytes of a 32-byte row; the lo plane follows the hi plane)
+        char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nfirst) * 32 + (m & 15) * 2 : nullptr;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int n = nfirst + it * 8;
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
+            if (n < N && mok) {
+                f32x4v v = a + b4;
+                if (p.R) v += rres[it];
+                if (beta != 1.0f) v *= beta;
+                if (p.accumulate) v += rold[it];
+                if (!keep[it]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (yp) *reinterpret_cast<f32x4v*>(yp) = v;
+                if (qs) {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[e] >= 0.f ? v[e] : v[e] * sl;
+                        h[e] = (__bf16)x;
+                        l[e] = (__bf16)(x - (float)h[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(qs) = h;
+                    *reinterpret_cast<bf16x4*>(qs + yplane) = l;
+                }
+            }
+            if (yp) yp += ystep;
+            if (qs) qs += 8 * 32;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the second row tile's loads stay behind this one's stores: hoisted, the two tiles' registers spill)
+    });
+}
+
+// ---- f32 channels-last plane -> chunk-major bf16 parts of lrelu(x) (a stage input; every other operand is written by an epilogue) ----------------
+__global__ __launch_bounds__(256) void k_split_cl(const float* __restrict__ X, int ldx, int64_t N, int C, float slope, SplitClPlanes out) {
+    const int64_t plane = (int64_t)(out.front + out.N + out.back) * 32;
+    const int c4n = C >> 2;
+    const int64_t total = N * c4n;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t n = q / c4n;
+        const int c = (int)(q - n * c4n) * 4;
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(X + n * ldx + c);
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e] >= 0.f ? v[e] : v[e] * slope;
+            h[e] = (__bf16)x;
+            l[e] = (__bf16)(x - (float)h[e]);
+        }
+        char* dst = static_cast<char*>(out.p) + ((int64_t)(c >> 4) * 2) * plane + ((int64_t)out.front + n) * 32 + (c & 15) * 2;
+        *reinterpret_cast<bf16x4*>(dst) = h;
+        *reinterpret_cast<bf16x4*>(dst + plane) = l;
+    }
+}
+// zero halo rows in front of and behind every (chunk, part) plane: the zero padding of the convolutions at the ends of the batch
+__global__ __launch_bounds__(256) void k_clx_zero_halo(SplitClPlanes s) {
+    const int64_t rows = (int64_t)s.front + s.N + s.back;
+    const int nplanes = (s.C >> 4) * 2;
+    const int per = (s.front + s.back) * 2;   // 16-byte pieces per plane
+    const int64_t total = (int64_t)nplanes * per;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int pl = (int)(q / per);
+        int e = (int)(q - (int64_t)pl * per);
+        int64_t row = e >> 1;
+        if (row >= s.front) row += s.N;
+        *reinterpret_cast<f32x4v*>(static_cast<char*>(s.p) + ((int64_t)pl * rows + row) * 32 + (e & 1) * 16) = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+size_t split_cl_bytes(int C, int64_t N) { return (size_t)(C >> 4) * 2 * (size_t)(kClxFront + N + kClxBack) * 32; }
+
+SplitClPlanes make_split_cl(void* mem, int C, int64_t N, hipStream_t stream) {
+    SplitClPlanes s;
+    s.p = mem;
+    s.C = C;
+    s.N = N;
+    s.front = kClxFront;
+    s.back = kClxBack;
+    const int64_t total = (int64_t)(C >> 4) * 2 * (s.front + s.back) * 2;
+    hipLaunchKernelGGL(k_clx_zero_halo, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1024)), dim3(256), 0, stream, s);
+    HIP_CHECK(hipGetLastError());
+    return s;
+}
+
+void split_cl(const float* X, int ldx, int64_t N, int C, float slope, const SplitClPlanes& out, hipStream_t stream) {
+    SBV2_REQUIRE((C & 15) == 0 && out.C == C && out.N == N && (ldx & 3) == 0, "split_cl: shape mismatch");
+    const int64_t total = N * (C >> 2);
+    hipLaunchKernelGGL(k_split_cl, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, stream, X, ldx, N, C, slope, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool conv_clx_usable(const ConvClxParams& p) {
+    if (!(p.ntaps == 3 || p.ntaps == 7 || p.ntaps == 11)) return false;
+    if ((p.K & 15) || (p.M & 63) || p.K != p.X.C || p.nmt * 32 < p.M || (p.nmt & 1)) return false;
+    const int span = (p.ntaps - 1) * std::abs(p.shift_step);
+    if (span > kClxXR - kClxNT || p.shift0 < -kClxFront || p.shift0 + span > 64) return false;
+    if (p.mask && p.mask_shift < 0) return false;
+    if (p.Y && (p.ldy & 3)) return false;
+    if (p.R && (p.ldr & 3)) return false;
+    if (p.Ys.p && (p.Ys.C != p.M || p.Ys.N != p.N)) return false;
+    return p.N >= 1 && p.X.N == p.N;
+}
+
+template <int NTAPS, int WM, int WR, int XB>
+static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
+    const ConvClxParams& p = kp.p;
+    kp.gy = p.M / (64 * WM);
+    const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * kClxXR * 32, (size_t)4 * WM * 64 * 36 * sizeof(float));
+    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB>;
+    static std::atomic<uint64_t> lds_allowed{0};
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
+    const int ntx = round_up((p.N + kClxNT - 1) / kClxNT, 8);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = conv_prof_active();
+    if (prof) {
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(ntx * kp.gy), dim3(256 * WM), lds, stream, kp);
+    HIP_CHECK(hipGetLastError());
+    if (prof) {
+        HIP_CHECK(hipEventRecord(e1, stream));
+        conv_prof_add(26, 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+    }
+}
+
+void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
+    SBV2_REQUIRE(conv_clx_usable(p), "conv_clx: operands do not fit the pre-split channels-last kernel");
+    ClxKernelParams kp;
+    kp.p = p;
+    const int step = p.shift_step;
+    const int smin = step >= 0 ? p.shift0 : p.shift0 + (p.ntaps - 1) * step;
+    const int smax = step >= 0 ? p.shift0 + (p.ntaps - 1) * step : p.shift0;
+    kp.wshift0 = smin;
+    kp.xrows = kClxNT + (smax - smin);
+    kp.sh0 = p.shift0 - smin;
+    kp.sh_step = step;
+    static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 1;   // experiments: 2 = 128-row workgroups (one per CU), 1 = 64-row (two per CU)
+    if (cfg == 2 && (p.M & 127) == 0) {
+        if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
+        else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
+        else launch_clx<11, 2, 8, 3>(kp, stream);
+    } else if (cfg == 3) {
+        if (p.ntaps == 3) launch_clx<3, 1, 8, 2>(kp, stream);
+        else if (p.ntaps == 7) launch_clx<7, 1, 8, 2>(kp, stream);
+        else launch_clx<11, 1, 8, 2>(kp, stream);
+    } else {
+        if (p.ntaps == 3) launch_clx<3, 1, 4, 3>(kp, stream);
+        else if (p.ntaps == 7) launch_clx<7, 1, 4, 3>(kp, stream);
+        else launch_clx<11, 1, 4, 3>(kp, stream);
+    }
+}
+
+}  // namespace sbv2

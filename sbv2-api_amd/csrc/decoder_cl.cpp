@@ -3,6 +3,7 @@
 //   dec_mode_ 1 = split-bf16 (hi/lo operands, 3 MFMAs per product, f32-grade), 2 = plain bf16 operands, 3 = fp16 operands
 //   (1 MFMA per product like bf16, 11-bit significands).  pack_cl's precision code: 1 = bf16, 2 = bf16 hi + lo, 3 = fp16.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -146,6 +147,11 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
     }
 }
 
+// conv_clx.hip for the wide stages' ResBlocks (SBV2_CLX=0 / sbv2_debug_set_clx(0): the conv_cl path, bit-identical, for A/B runs and the test)
+static std::atomic<int> g_clx{getenv("SBV2_CLX") ? atoi(getenv("SBV2_CLX")) : 1};
+bool clx_enabled() { return g_clx.load(std::memory_order_relaxed) != 0; }
+int set_clx(int on) { return g_clx.exchange(on); }
+
 void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l,
                         const unsigned char* mask, int mask_div, float pre_slope, const float* R, int ldr, float beta, int accumulate) {
     ConvClParams p;
@@ -226,15 +232,83 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
             launch_conv_cl(p, stream_);
         }
+        // Wide stages (>= 128 channels, split-bf16): the ResBlock convolutions read PRE-SPLIT operands (conv_clx.hip: LDS-DMA only, one barrier
+        // per tap).  The stage input is split once (split_cl); every other operand is written by the producing convolution's epilogue as the
+        // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
+        int ushift = 0;
+        while ((1 << ushift) < U) ++ushift;
+        bool clx = clx_enabled() && dec_mode_ == 1 && C >= 128 && (C & 63) == 0 && (1 << ushift) == U;
+        for (int j = 0; j < nk && clx; ++j) {
+            const ClBranch& rb = st.branches[j];
+            if (!(rb.k == 3 || rb.k == 7 || rb.k == 11)) clx = false;
+            for (int d : rb.dil)
+                if (d * (rb.k - 1) > 64 || d * (rb.k - 1) / 2 > kClxFront) clx = false;
+        }
+        SplitClPlanes XUs, T1s, YsA, YsB;
+        if (clx) {
+            const size_t sb = split_cl_bytes(C, Lo);
+            XUs = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            T1s = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            YsA = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            YsB = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            split_cl(XU, C, Lo, C, 0.1f, XUs, stream_);
+        }
         for (int j = 0; j < nk; ++j) {
             const ClBranch& rb = st.branches[j];
             const float* y = XU;
+            const SplitClPlanes* ys = &XUs;   // bf16 parts of lrelu(y)
             const int nd = (int)rb.dil.size();
             for (int q = 0; q < nd; ++q) {
                 const int d = rb.dil[q];
                 const bool last = q + 1 == nd;
                 float* yn = last ? XS : ((y == YA) ? YB : YA);
                 static const int fuse_max_c = getenv("SBV2_FUSE_PAIRS_MAXC") ? atoi(getenv("SBV2_FUSE_PAIRS_MAXC")) : 64;   // A/B knob
+                if (clx) {
+                    ConvClxParams p1;
+                    p1.X = *ys;
+                    p1.W = rb.c1[q].w;
+                    p1.nmt = rb.c1[q].nmt;
+                    p1.M = C;
+                    p1.N = (int)Lo;
+                    p1.K = C;
+                    p1.ntaps = rb.k;
+                    p1.shift0 = -d * (rb.k - 1) / 2;
+                    p1.shift_step = d;
+                    p1.Ys = T1s;               // conv1's result is only ever read as conv2's operand
+                    p1.ys_slope = 0.1f;
+                    p1.bias = rb.c1[q].bias;
+                    p1.mask = fl.d_mask;
+                    p1.mask_shift = ushift;
+                    launch_conv_clx(p1, stream_);
+                    ConvClxParams p2;
+                    p2.X = T1s;
+                    p2.W = rb.c2[q].w;
+                    p2.nmt = rb.c2[q].nmt;
+                    p2.M = C;
+                    p2.N = (int)Lo;
+                    p2.K = C;
+                    p2.ntaps = rb.k;
+                    p2.shift0 = -(rb.k - 1) / 2;
+                    p2.shift_step = 1;
+                    p2.Y = yn;
+                    p2.ldy = C;
+                    const SplitClPlanes* yns = (ys == &YsA) ? &YsB : &YsA;
+                    if (!last) {
+                        p2.Ys = *yns;
+                        p2.ys_slope = 0.1f;
+                    }
+                    p2.bias = rb.c2[q].bias;
+                    p2.R = y;
+                    p2.ldr = C;
+                    p2.beta = last ? 1.0f / nk : 1.0f;
+                    p2.accumulate = last && j > 0;
+                    p2.mask = fl.d_mask;
+                    p2.mask_shift = ushift;
+                    launch_conv_clx(p2, stream_);
+                    ys = yns;
+                    y = yn;
+                    continue;
+                }
                 if (fuse_pairs_ && C <= fuse_max_c && C <= 64 && (U & (U - 1)) == 0) {
                     // stages of <= 64 channels are HBM bound: conv1 -> conv2 fused, the intermediate stays in LDS (respair_cl.hip)
                     ResPairParams rp;

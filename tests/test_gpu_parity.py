@@ -43,6 +43,32 @@ def test_conv1d_kernel(cin, cout, k, dil, L):
         np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("C,k,dil,L", [(128, 3, 1, 700), (128, 7, 3, 1500), (128, 11, 5, 1030), (256, 7, 1, 515), (256, 11, 3, 300), (256, 3, 5, 257),
+                                       (128, 7, 5, 256), (128, 11, 1, 8200)])
+def test_conv1d_clx_kernel_same_bits_as_conv_cl(C, k, dil, L):
+    """conv_clx.hip (pre-split operands, LDS-DMA rings, one barrier per tap) gives the SAME bits as conv_cl.hip's split-bf16 path: same
+    fragments, same MFMA order.  Also with a residual and beta, and the bf16 parts of lrelu(result) it emits for the next convolution
+    are exactly the split conv_cl would compute while staging."""
+    rng = np.random.default_rng(C + k + dil + L)
+    x = rng.standard_normal((C, L)).astype(np.float32)
+    w = (rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    r = rng.standard_normal((C, L)).astype(np.float32)
+    P = lambda a: None if a is None else a.ctypes.data_as(f32p)
+    lib = _lib.lib()
+    ref = np.empty((C, L), np.float32)
+    _lib.check(lib.sbv2_debug_conv1d_cl(0, P(x), P(w), P(b), C, C, k, L, dil, 0.1, 1, 0, P(ref), None))
+    got, ys = np.empty((C, L), np.float32), np.empty((C, L), np.float32)
+    _lib.check(lib.sbv2_debug_conv1d_clx(0, P(x), P(w), P(b), None, C, C, k, L, dil, 0.1, 1.0, 0, P(got), P(ys), None))
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_allclose(got, O.conv1d_same(O.leaky_relu(x, 0.1), w, b, dil), atol=3e-5, rtol=1e-5)
+    lr = np.where(ref >= 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    assert float(np.abs(ys - lr).max()) <= 2.0 ** -16 * float(np.abs(lr).max())
+    got2 = np.empty((C, L), np.float32)
+    _lib.check(lib.sbv2_debug_conv1d_clx(0, P(x), P(w), P(b), P(r), C, C, k, L, dil, 0.1, 1.0 / 3, 0, P(got2), None, None))
+    np.testing.assert_array_equal(got2, ((ref + r) * np.float32(1.0 / 3)).astype(np.float32))
+
+
 def _gemm_bfs(x, w, b, r, parts, act=0, split_out=0):
     m, k = w.shape
     n = x.shape[1]
@@ -350,6 +376,25 @@ def test_vits_full_small_utterance():
     err = float(np.abs(pcm[0, 0] - r["pcm"]).max())
     print("full-config waveform max-abs error:", err)
     assert err < 2e-4
+    s.close()
+
+
+def test_decoder_clx_path_same_bits_as_conv_cl_path():
+    """Full JP-Extra shape: the wide decoder stages on conv_clx.hip (pre-split operands written by the producing epilogues, LDS-DMA rings:
+    the default) against the same stages on conv_cl.hip (sbv2_debug_set_clx(0)): every sample of a mixed batch identical, bit for bit."""
+    cfg, W = weights("vits", "full")
+    s = model.load_model(blob("vits", "full"), False)
+    utts = make_utts([12, 31, 5], O.DEBERTA_FULL, cfg, seed0=77)
+    lib = _lib.lib()
+    prev = lib.sbv2_debug_set_clx(1)
+    try:
+        a = model.synthesize_batch(s, utts, forced=True)
+        lib.sbv2_debug_set_clx(0)
+        b = model.synthesize_batch(s, utts, forced=True)
+    finally:
+        lib.sbv2_debug_set_clx(prev)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
     s.close()
 
 
