@@ -208,11 +208,18 @@ def main():
         nsub = max(1, -(-max(per_rank) // 65536))
     order = sorted(range(len(utts)), key=lambda i: -frames([utts[i]]))
     groups = [[utts[i] for i in order[g::nsub]] for g in range(nsub)]
+    if not utts:
+        raise SystemExit(f"bench.py: rank {rank} was dealt no utterance (world {world} > utterances): use fewer ranks for this config")
     batches = [pipe.prepare(g, forced=True) for g in groups if g]   # benchmark mode: blank 1 frame, phone 6 frames
-    while len(batches) < nsub:      # a rank with fewer utterances than sub-batches repeats its last one (keeps the collective count equal)
-        batches.append(batches[-1])
-    b = batches[0]
     sub_samples = [frames(g) * hop for g in groups if g]
+    # a rank with fewer sub-batches than the others repeats its last one so that every rank makes the same number of collective calls; the
+    # repeats are fillers: their audio is NOT counted (weight 0)
+    sub_weight = [1] * len(batches)
+    while len(batches) < nsub:
+        batches.append(batches[-1])
+        sub_samples.append(sub_samples[-1])
+        sub_weight.append(0)
+    b = batches[0]
     my_samples = max(sub_samples)
 
     dmode = l.sbv2_vits_decoder_mode(vs.handle)
@@ -274,12 +281,14 @@ def main():
     dt = time.perf_counter() - t0
     if comm is None and host is not None:
         dt = host.max(dt)
-        total_samples_per_step = int(host.sum(float(sum(sub_samples))))
+        total_samples_per_step = int(host.sum(float(sum(s * w for s, w in zip(sub_samples, sub_weight)))))
     elif comm is not None:
         dt = comm.max(dt)
-        total_samples_per_step = int(sum(c.sum() for c in counts_seen[-len(batches):]))
+        # real sub-batches only: every rank's own sum, added over the ranks through the communicator's host-visible reduction
+        mine_real = float(sum(s * w for s, w in zip(sub_samples, sub_weight)))
+        total_samples_per_step = int(round(host.sum(mine_real))) if host is not None else int(mine_real)
     else:
-        total_samples_per_step = sum(sub_samples)
+        total_samples_per_step = sum(s * w for s, w in zip(sub_samples, sub_weight))
     total_audio = total_samples_per_step / configs.SAMPLE_RATE * args.steps
     value = total_audio / dt
 
@@ -309,27 +318,43 @@ def main():
             # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the per-launch FETCH_SIZE (x2, the
             # gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE of the SAME command line under `rocprofv3 --pmc` is kept in profiles/:
             # an OFFLINE measurement (of the build the file name says), replayed here.
+            # The file is chosen by name (profiles/<round tag>_pmc_hbm_traffic.csv, the lexicographically last = the newest round) and the row
+            # by the kernel's mangled-name prefix below; a dominant kernel that file has no row for reports traffic null and says so: it
+            # never falls back to an older round's file.
+            roofline["traffic_source"] = None
             try:
                 import csv
                 import glob
                 pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))[-1]
-                # (prefixes: the kernel's last template argument is the row-group count WM; the CSV is sorted by total time, the first match
-                # is the variant that dominates)
-                want = {"conv_cl<2,split-bf16>": ("conv_cl_kernel<2, 1, false, false", "conv_cl_kernel<2, true, false, false"),
-                        "conv_cl<1,split-bf16>": ("conv_cl_kernel<1, 1, false, false", "conv_cl_kernel<1, true, false, false"),
-                        "conv_cl<2,bf16>": ("conv_cl_kernel<2, 0, false, false", "conv_cl_kernel<2, false, false, false"),
+                # sbv2_prof_end's kernel name -> prefixes of the rocprofv3 kernel names it covers (the CSV is sorted by total time: the
+                # first match is the variant that dominates)
+                want = {"conv_clx<split-bf16>": ("conv_clx_kernel<",),
+                        "conv_cl<2,split-bf16>": ("conv_cl_kernel<2, 1, false, false",),
+                        "conv_cl<1,split-bf16>": ("conv_cl_kernel<1, 1, false, false",),
+                        "conv_cl<2,bf16>": ("conv_cl_kernel<2, 0, false, false",),
+                        "conv_cl<1,bf16>": ("conv_cl_kernel<1, 0, false, false",),
                         "conv_cl<2,f16>": ("conv_cl_kernel<2, 2, false, false",),
-                        "conv_gemm<32,2,2,1,4,16>": ("conv_gemm_kernel<32, 2, 2, 1, 4, 16>",),
-                        "conv_gemm<32,2,4,2,2,16>": ("conv_gemm_kernel<32, 2, 4, 2, 2, 16>",)}.get(dom["kernel"], ("\0",))
+                        "conv_cl<1,f16>": ("conv_cl_kernel<1, 2, false, false",),
+                        "conv_cl_km<2,split-bf16>": ("conv_cl_kernel<2, 1, true", "conv_cl_kernel<2, 1, false, true"),
+                        "conv_cl_km<1,split-bf16>": ("conv_cl_kernel<1, 1, true", "conv_cl_kernel<1, 1, false, true"),
+                        "respair_cl<C<=32>": ("respair_cl_kernel<1, false, 1>", "respair_cl_kernel<1, true, 1>"),
+                        "respair_cl<C=64>": ("respair_cl_kernel<1, false, 2>",),
+                        "gemm_bfs<bf16x3>": ("gemm_bfs_kernel<2,",),
+                        "gemm_bfs<bf16x6>": ("gemm_bfs_kernel<3,",),
+                        "gemm_skinny<16x16x4>": ("gemm_skinny",)}.get(dom["kernel"])
+                if want is None and dom["kernel"].startswith("conv_gemm<"):
+                    want = ("conv_gemm_kernel<" + dom["kernel"][len("conv_gemm<"):-1].replace(",", ", "),)
                 for r in csv.DictReader(open(pm)):
-                    if any(w in r["kernel"] for w in want):
+                    if want and any(w in r["kernel"] for w in want):
                         roofline["traffic"] = round(float(r["fetch_bytes_per_launch(x2 gfx950 correction)"]) + float(r["write_bytes_per_launch"]))
                         roofline["traffic_unit"] = "bytes per launch (HBM, PMC)"
                         roofline["traffic_measured"] = "offline"
                         roofline["traffic_source"] = os.path.relpath(pm, ROOT)
                         break
-            except Exception:
-                pass
+                else:
+                    roofline["traffic_source"] = f"no row for {dom['kernel']} in {os.path.relpath(pm, ROOT)}"
+            except Exception as e:
+                roofline["traffic_source"] = f"unavailable ({type(e).__name__})"
 
     # ---- CPU baseline leg (rank 0, N = 1): the C / OpenMP restatement, batch 1 looped, bounded time ----------------------
     cpu = None

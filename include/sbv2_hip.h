@@ -147,6 +147,10 @@ int sbv2_style_vector(const float* style_vectors, int64_t n, int64_t dim, int64_
  * RCCL is dlopen'ed on first use: single-GPU callers never load it. ------------------------------------------------------------------ */
 /* rank_of[i] = rank that synthesises utterance i (host only, deterministic on every rank). */
 int sbv2_deal(int64_t n, const int64_t* costs, int world, int32_t* rank_of);
+/* Host only: the gather of a dealt batch.  Rank r's message is the PCM of its utterances in ascending caller index; the messages sit in
+   rank order in the root's staging buffer.  counts[world] = samples per rank, table[3 n] = {offset in the staging buffer, offset in the
+   caller's utterance order, samples} per utterance (the permutation sbv2_node_synthesize applies on the device). */
+int sbv2_gather_plan(int64_t n, const int64_t* pcm_lens, const int32_t* rank_of, int world, int64_t* counts, int64_t* table);
 
 /* (a) one process per GPU: rank 0 obtains a 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any side channel. */
 typedef struct sbv2_comm sbv2_comm;

@@ -59,6 +59,7 @@ SYMBOLS = {
     "sbv2_host_alloc": (C.c_void_p, [C.c_size_t]),
     "sbv2_host_free": (None, [C.c_void_p]),
     "sbv2_deal": (C.c_int, [C.c_int64, i64p, C.c_int, C.POINTER(C.c_int32)]),
+    "sbv2_gather_plan": (C.c_int, [C.c_int64, i64p, C.POINTER(C.c_int32), C.c_int, i64p, i64p]),
     "sbv2_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sbv2_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sbv2_comm_destroy": (None, [C.c_void_p]),

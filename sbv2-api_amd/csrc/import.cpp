@@ -91,9 +91,14 @@ struct OnnxTensor {
     Span raw;
     std::vector<float> fdata;      // float_data (field 4)
     std::vector<int64_t> idata;    // int64_data (field 7)
+    // checked product (a crafted initializer such as four dims of 65536 would wrap a plain product to 0 while keeping the huge dims, from
+    // which config values are derived): same bound as parse_blob's containers
     int64_t numel() const {
         int64_t n = 1;
-        for (int64_t d : dims) n *= d;
+        for (int64_t d : dims) {
+            SBV2_REQUIRE(d >= 0 && (d == 0 || n <= (1ll << 40) / std::max<int64_t>(d, 1)), "ONNX: tensor too large: " + name);
+            n *= d;
+        }
         return n;
     }
 };
@@ -131,7 +136,9 @@ OnnxTensor parse_tensor(Span s) {
         else if (f == 13 || f == 14) throw Error("ONNX: external tensor data is not supported (the reference loads single-file models: model.rs:6)");
         else pb.skip(wt);
     }
+    SBV2_REQUIRE(t.dims.size() <= 8, "ONNX: tensor rank out of range: " + t.name);
     for (int64_t d : t.dims) SBV2_REQUIRE(d >= 0 && d < (1ll << 31), "ONNX: tensor dimension out of range: " + t.name);
+    (void)t.numel();   // refuses an overflowing shape here, before any config value is read from the dims
     return t;
 }
 
@@ -456,7 +463,10 @@ int count_indexed(const Named& t, const std::string& prefix, const std::string& 
 const std::vector<int64_t>& dims_of(const Named& t, const std::string& name) {
     auto it = t.dims.find(name);
     if (it == t.dims.end()) throw Error("ONNX import: tensor '" + name + "' not found in the graph (initializer names after onnxsim differ from what "
-                                        "csrc/import.cpp expects; see the naming rules at the top of that file)");
+                                        "csrc/import.cpp expects; see the naming rules at the top of that file).  onnxsim constant-folds subgraphs that "
+                                        "depend only on initializers (DeBERTa: rel_embeddings -> encoder.LayerNorm -> per-layer position projections; "
+                                        "VITS: exp(-sdp.flows.0.logs)); an export folded that way is NOT supported: convert it with the onnxsim step "
+                                        "skipped (INTEGRATION.md, 'Real weights')");
     return it->second;
 }
 

@@ -108,6 +108,30 @@ std::vector<int> deal(const std::vector<int64_t>& costs, int world) {
     return rank_of;
 }
 
+// The gather of one dealt batch: rank r's message = the PCM of its utterances in ascending caller index, messages in rank order in the staging
+// buffer; table[3 e] = {offset in the staging buffer, offset in the caller's utterance order, samples} for every utterance (k_copy_segments).
+void gather_plan(int n, const int64_t* pcm_lens, const int* rank_of, int world, std::vector<int64_t>& counts, std::vector<int64_t>& table) {
+    counts.assign(world, 0);
+    table.assign((size_t)3 * n, 0);
+    std::vector<int64_t> out_off(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        SBV2_REQUIRE(rank_of[i] >= 0 && rank_of[i] < world && pcm_lens[i] >= 0, "gather plan: bad rank or length");
+        counts[rank_of[i]] += pcm_lens[i];
+        out_off[i + 1] = out_off[i] + pcm_lens[i];
+    }
+    int e = 0;
+    int64_t so = 0;
+    for (int r = 0; r < world; ++r)
+        for (int i = 0; i < n; ++i)
+            if (rank_of[i] == r) {
+                table[3 * e] = so;
+                table[3 * e + 1] = out_off[i];
+                table[3 * e + 2] = pcm_lens[i];
+                so += pcm_lens[i];
+                ++e;
+            }
+}
+
 }  // namespace
 
 struct sbv2_comm {
@@ -118,6 +142,8 @@ struct sbv2_comm {
     double* d_val = nullptr;       // [2]
     GrowBuf stage;                 // root: every rank's PCM, rank order
     hipEvent_t ev = nullptr;
+    hipStream_t copy = nullptr;    // root: device -> host copies, overlapped with the receives still in flight
+    std::vector<hipEvent_t> gev;   // root: one event per receive group
 };
 
 struct sbv2_node {
@@ -145,6 +171,17 @@ int sbv2_deal(int64_t n, const int64_t* costs, int world, int32_t* rank_of) {
     API_END
 }
 
+int sbv2_gather_plan(int64_t n, const int64_t* pcm_lens, const int32_t* rank_of, int world, int64_t* counts, int64_t* table) {
+    API_BEGIN
+    SBV2_REQUIRE(n >= 0 && world >= 1 && counts && (n == 0 || (pcm_lens && rank_of && table)), "bad arguments");
+    std::vector<int> ro(rank_of, rank_of + n);
+    std::vector<int64_t> c, t;
+    gather_plan((int)n, pcm_lens, ro.data(), world, c, t);
+    std::copy(c.begin(), c.end(), counts);
+    std::copy(t.begin(), t.end(), table);
+    API_END
+}
+
 // ---- one process per GPU ------------------------------------------------------------------------------------------------------------
 int sbv2_comm_unique_id(uint8_t* id128) {
     API_BEGIN
@@ -168,7 +205,10 @@ int sbv2_comm_create(const uint8_t* id128, int rank, int world, int device, sbv2
     std::memcpy(&id, id128, 128);
     NCCL_CHECK(rccl().CommInitRank(&c->comm, world, id, rank));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    c->gev.resize(world + 1);
+    for (auto& e : c->gev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c->d_counts), sizeof(int64_t) * (world + 1)));
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c->d_val), sizeof(double) * 2));
     *out = c.release();
@@ -186,6 +226,12 @@ void sbv2_comm_destroy(sbv2_comm* c) {
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_val) (void)hipFree(c->d_val);
     if (c->ev) (void)hipEventDestroy(c->ev);
+    for (auto e : c->gev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->copy) {
+        (void)hipStreamSynchronize(c->copy);
+        (void)hipStreamDestroy(c->copy);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -235,21 +281,37 @@ int sbv2_comm_gather_pcm(sbv2_comm* c, sbv2_pipeline* p, int64_t ticket, int roo
         total += counts[r];
     }
     if (c->rank == root) {
+        // The serial part of an N-GPU step is this rank's device -> host traffic (N x 59 MB at batch 32 x U128 over one PCIe link), so it starts
+        // as early as it can: the root's own block goes to the host straight from the run's buffer while the peers' blocks are still on
+        // their xGMI links, and the peers are received in groups of `per` (SBV2_GATHER_GROUP, default 2: each peer has its own link, a
+        // group's receives run in parallel) whose copies to the host overlap the next group's receives.
         float* st = static_cast<float*>(c->stage.get(sizeof(float) * (size_t)std::max<int64_t>(total, 1)));
-        NCCL_CHECK(R.GroupStart());
-        int64_t off = 0;
-        for (int r = 0; r < c->world; ++r) {
-            if (r != root && counts[r] > 0) NCCL_CHECK(R.Recv(st + off, (size_t)counts[r], ncclFloat, r, c->comm, c->stream));
-            off += counts[r];
+        std::vector<int64_t> offs(c->world + 1, 0);
+        for (int r = 0; r < c->world; ++r) offs[r + 1] = offs[r] + counts[r];
+        const bool fits = total <= capacity;
+        static const int per = std::max(1, getenv("SBV2_GATHER_GROUP") ? atoi(getenv("SBV2_GATHER_GROUP")) : 2);
+        HIP_CHECK(hipEventRecord(c->gev[c->world], c->stream));          // (the run has finished: c->stream waited for it above)
+        HIP_CHECK(hipStreamWaitEvent(c->copy, c->gev[c->world], 0));
+        if (fits && mine > 0)
+            HIP_CHECK(hipMemcpyAsync(dst_host + offs[root], vm.pcm_device(), sizeof(float) * (size_t)mine, hipMemcpyDeviceToHost, c->copy));
+        std::vector<int> peers;
+        for (int r = 0; r < c->world; ++r)
+            if (r != root && counts[r] > 0) peers.push_back(r);
+        for (size_t g0 = 0, gi = 0; g0 < peers.size(); g0 += per, ++gi) {
+            const size_t g1 = std::min(peers.size(), g0 + per);
+            NCCL_CHECK(R.GroupStart());
+            for (size_t k = g0; k < g1; ++k) NCCL_CHECK(R.Recv(st + offs[peers[k]], (size_t)counts[peers[k]], ncclFloat, peers[k], c->comm, c->stream));
+            NCCL_CHECK(R.GroupEnd());
+            HIP_CHECK(hipEventRecord(c->gev[gi], c->stream));
+            HIP_CHECK(hipStreamWaitEvent(c->copy, c->gev[gi], 0));
+            if (fits)
+                for (size_t k = g0; k < g1; ++k)
+                    HIP_CHECK(hipMemcpyAsync(dst_host + offs[peers[k]], st + offs[peers[k]], sizeof(float) * (size_t)counts[peers[k]],
+                                             hipMemcpyDeviceToHost, c->copy));
         }
-        NCCL_CHECK(R.GroupEnd());
-        off = 0;
-        for (int r = 0; r < root; ++r) off += counts[r];
-        if (mine > 0) HIP_CHECK(hipMemcpyAsync(st + off, vm.pcm_device(), sizeof(float) * (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
-        if (total <= capacity && total > 0)
-            HIP_CHECK(hipMemcpyAsync(dst_host, st, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
-        SBV2_REQUIRE(total <= capacity, "PCM buffer too small: " + std::to_string(capacity) + " < " + std::to_string(total));
+        HIP_CHECK(hipStreamSynchronize(c->copy));
+        SBV2_REQUIRE(fits, "PCM buffer too small: " + std::to_string(capacity) + " < " + std::to_string(total));
     } else {
         if (mine > 0) {
             NCCL_CHECK(R.GroupStart());
@@ -431,16 +493,12 @@ int sbv2_node_synthesize(sbv2_node* nd, const sbv2_batch* batch, const int64_t* 
         if (!s.err.empty()) throw Error(s.err);
 
     // ---- gather to device 0: one message per device into `stage` (device order), then a permutation into utterance order -------------
-    std::vector<int64_t> cnt(ndev, 0), doff(ndev + 1, 0);
-    for (int r = 0; r < ndev; ++r) {
-        for (int64_t l : sh[r].lens) cnt[r] += l;
-        doff[r + 1] = doff[r] + cnt[r];
-    }
-    const int64_t total = doff[ndev];
-    std::vector<int64_t> out_off(n + 1, 0);
     for (int r = 0; r < ndev; ++r)
         for (size_t j = 0; j < sh[r].ids.size(); ++j) pcm_lens[sh[r].ids[j]] = sh[r].lens[j];
-    for (int i = 0; i < n; ++i) out_off[i + 1] = out_off[i] + pcm_lens[i];
+    std::vector<int64_t> cnt, tab, doff(ndev + 1, 0);
+    gather_plan(n, pcm_lens, rank_of.data(), ndev, cnt, tab);
+    for (int r = 0; r < ndev; ++r) doff[r + 1] = doff[r] + cnt[r];
+    const int64_t total = doff[ndev];
     SBV2_REQUIRE(total <= capacity, "PCM buffer too small: " + std::to_string(capacity) + " < " + std::to_string(total));
     sbv2_node::Dev& d0 = nd->devs[0];
     HIP_CHECK(hipSetDevice(d0.device));
@@ -476,20 +534,7 @@ int sbv2_node_synthesize(sbv2_node* nd, const sbv2_batch* batch, const int64_t* 
     }
     if (cnt[0] > 0)
         HIP_CHECK(hipMemcpyAsync(stage, d0.vits->m->pcm_device(), sizeof(float) * (size_t)cnt[0], hipMemcpyDeviceToDevice, d0.xfer));
-    // permutation table (src offset in stage, dst offset in utterance order, length)
-    std::vector<int64_t> tab((size_t)3 * n);
-    {
-        int e = 0;
-        for (int r = 0; r < ndev; ++r) {
-            int64_t so = doff[r];
-            for (size_t j = 0; j < sh[r].ids.size(); ++j, ++e) {
-                tab[3 * e] = so;
-                tab[3 * e + 1] = out_off[sh[r].ids[j]];
-                tab[3 * e + 2] = sh[r].lens[j];
-                so += sh[r].lens[j];
-            }
-        }
-    }
+    // permutation into the caller's utterance order (gather_plan's table)
     int64_t* d_tab = static_cast<int64_t*>(nd->table.get(sizeof(int64_t) * tab.size()));
     HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), sizeof(int64_t) * tab.size(), hipMemcpyHostToDevice, d0.xfer));
     copy_segments(stage, ordered, d_tab, n, d0.xfer);

@@ -302,6 +302,7 @@ VitsModel* VitsModel::clone() const {
     VitsModel* c = new VitsModel(*this);   // shares ws_ (device weights); Arena copies are empty
     c->stream_ = nullptr;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
+    c->after_ev_ = nullptr;   // created on first use PER CONTEXT: a copied handle would be destroyed twice (and waited on after its first destruction)
     c->pcm_ = nullptr;
     c->pcm_total_ = 0;
     c->pcm_lens_.clear();

@@ -296,13 +296,19 @@ class Node:
     def synthesize(self, b, out=None):
         """Runs the prepared batch; returns the list of PCM arrays in the caller's utterance order."""
         l = _lib.lib()
-        hop_guess = None
-        if out is None:
-            # capacity: exact when durations are forced, generous otherwise
-            cap = int(b.forced.sum()) * 512 if b.forced is not None else int(b.t_lens.sum()) * 512 * 64
+        grow = out is None
+        if grow:
+            # capacity: exact when durations are forced (hop = 512 for every JP-Extra checkpoint; a larger hop shows up as a capacity error and
+            # is retried below); with predicted durations ~8 frames per text symbol, grown on demand (the library refuses, it never overflows)
+            cap = int(b.forced.sum()) * 512 if b.forced is not None else int(b.t_lens.sum()) * 512 * 8
             out = np.empty(max(cap, 1), np.float32)
-        check(l.sbv2_node_synthesize(self.h, C.byref(b.c), b.ids.ctypes.data_as(i64p), b.s_lens.ctypes.data_as(i64p), b.w2p.ctypes.data_as(i64p),
-                                     b.lens.ctypes.data_as(i64p), out.ctypes.data_as(C.c_void_p), out.size))
+        for _ in range(4):
+            rc = l.sbv2_node_synthesize(self.h, C.byref(b.c), b.ids.ctypes.data_as(i64p), b.s_lens.ctypes.data_as(i64p), b.w2p.ctypes.data_as(i64p),
+                                        b.lens.ctypes.data_as(i64p), out.ctypes.data_as(C.c_void_p), out.size)
+            if rc == 0 or not grow or b"too small" not in l.sbv2_last_error():
+                break
+            out = np.empty(out.size * 4, np.float32)     # the shards are synthesised again: a rare path (unusually slow speech)
+        check(rc)
         n = int(b.lens.sum())
         return np.split(out[:n], np.cumsum(b.lens)[:-1])
 

@@ -242,7 +242,7 @@ def test_deberta_full_shape_mid_lengths_vs_oracle():
     rng = np.random.default_rng(7)
     seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (98, 20, 126, 63, 150)]
     batch = model.predict_batch(s, seqs)
-    for k in (0, 2):
+    for k in (0, 2, 4):     # 100 and 128 tokens: the tiled fused attention; 152 tokens: the grouped-GEMM + softmax path at the full shape
         ref = O.deberta_forward(W, cfg, seqs[k])
         np.testing.assert_allclose(batch[k], ref, atol=2e-4, rtol=0)
         np.testing.assert_array_equal(model.predict(s, seqs[k], np.ones_like(seqs[k])), batch[k])
@@ -663,6 +663,49 @@ def test_comm_world1_gather_through_rccl():
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def _ngpus():
+    return _lib.lib().sbv2_device_count()
+
+
+@pytest.mark.skipif(_lib.lib().sbv2_device_count() < 2, reason="needs >= 2 GPUs (RCCL between distinct devices)")
+def test_node_two_devices_equal_single_gpu_call():
+    """sbv2_node_synthesize on devices [0, 1] (ncclCommInitAll, grouped ncclSend / ncclRecv over xGMI) == one pipeline call of the whole
+    batch on one GPU, bit for bit, with predicted durations AND noise.  Skips on a one-GPU box (the same logic runs there with both shards
+    on one GPU: test_node_shards_equal_single_gpu_call)."""
+    bc, vc = O.DEBERTA_TINY, O.VITS_TINY
+    bb, vb = blob("bert", "tiny", 3), blob("vits", "tiny", 5)
+    utts = make_utts([7, 15, 4, 22, 9, 3, 11, 6, 18], bc, vc, seed0=151, with_bert=False)
+    bs, vs = model.load_model(bb, True), model.load_model(vb, False)
+    pipe = model.Pipeline(bs, vs)
+    node = model.Node(bb, vb, list(range(min(_ngpus(), 8))))
+    assert node.uses_rccl
+    for kw in (dict(forced=True), dict(sdp_ratio=0.3, length_scale=1.1, noise_scale=0.667, noise_scale_w=0.8, noise_seed=123)):
+        b = pipe.prepare(utts, **kw)
+        pipe.run(b)
+        ref = pipe.fetch(b)
+        got = node.synthesize(node.prepare(utts, **kw), out=np.empty(sum(len(r) for r in ref) + 7, np.float32))
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g, r)
+    node.close(); pipe.close(); bs.close(); vs.close()
+
+
+@pytest.mark.skipif(_lib.lib().sbv2_device_count() < 2, reason="needs >= 2 GPUs (RCCL between distinct devices)")
+def test_comm_two_ranks_gather_over_rccl(tmp_path):
+    """One process per GPU, world size 2 (tests/rccl_world2_check.py, two FRESH interpreters): ncclCommInitRank from a shared id,
+    the library's deal, every rank synthesises its shard, sbv2_comm_gather_pcm (all-gather of counts + ncclSend / ncclRecv + the chunked
+    device -> host copies on rank 0) == the rows of a single-GPU call of the whole batch, bit for bit."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    uid = str(tmp_path / "uid")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    ps = [subprocess.Popen([sys.executable, os.path.join(here, "rccl_world2_check.py"), str(r), "2", uid], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in ps]
+    for r, (p, o) in enumerate(zip(ps, outs)):
+        assert p.returncode == 0 and f"RCCL_WORLD2_RANK{r}_OK" in o, o[-3000:]
+
+
 def test_config3_b256_mixed_lengths_sharded_8_ways():
     """BASELINE configs[3]: batch 256 of mixed 32..512-phoneme utterances, utterance-sharded 8 ways.  One GPU is all a test box has, so the
     eight shards run on eight execution contexts of that GPU (the library's deal, threads, gather and permutation are the ones an 8-GPU
@@ -767,6 +810,17 @@ def test_config4_streaming_long_form_full_shapes():
     e6 = float(np.abs(got6 - ref).max())
     print(f"configs[4]: 600 symbols streamed vs oracle max-abs {e6:.3e}")
     assert e6 < 1e-3 and e6 < 5e-5
+    # predicted durations + both noise streams (seeded) at the full shape: the streamed decode equals the whole-sequence call of the same seed
+    kw = dict(sdp_ratio=0.2, noise_scale=0.667, noise_scale_w=0.8, noise_seed=1234)
+    un = synth.make_utterance(300, bc, vc, seed=992, chars=98)
+    bn = pipe.prepare([un], **kw)
+    pipe.run(bn)
+    whole_n = pipe.fetch(bn)[0]
+    got_n, (total_n, graph_n, _), _ = _stream_all(bs, vs, un, 256, **kw)
+    assert graph_n and total_n == whole_n.size == got_n.size
+    en = float(np.abs(got_n - whole_n).max())
+    print(f"configs[4]: 300 phonemes, predicted durations + noise, streamed vs whole-sequence max-abs {en:.3e}")
+    assert en <= 1e-5
     pipe.close(); bs.close(); vs.close()
 
 
@@ -788,6 +842,34 @@ def test_pipeline_tiny():
         ref = O.vits_forward(vw, vc, bert, u["phones"], u["tones"], u["langs"], 0, u["style"], forced_durations=u["forced_durations"])
         np.testing.assert_allclose(got, ref, atol=2e-4, rtol=0)
     pipe.close(); bs.close(); vs.close()
+
+
+def test_pipeline_contexts_do_not_share_events():
+    """Execution contexts cloned from sessions that have already run (an earlier Pipeline, a StreamHandle) own their stream-ordering
+    event: Pipeline -> run -> close -> Pipeline on the SAME sessions, and a stream followed by a Pipeline, keep working and keep their bits
+    (a cloned context used to copy the lazily created event and destroy it with the first pipeline)."""
+    bc, vc = O.DEBERTA_TINY, O.VITS_TINY
+    bs, vs = model.load_model(blob("bert", "tiny", 3), True), model.load_model(blob("vits", "tiny", 5), False)
+    utts = make_utts([7, 15, 4], bc, vc, seed0=51, with_bert=False)
+    outs = []
+    for _ in range(3):
+        pipe = model.Pipeline(bs, vs)
+        for _ in range(3):      # both execution contexts of the pipeline get used
+            b = pipe.prepare(utts, forced=True)
+            pipe.run(b)
+            outs.append(pipe.fetch(b))
+        pipe.close()
+    streamed = _stream_all(bs, vs, utts[1], 16, forced=True)[0]
+    pipe = model.Pipeline(bs, vs)
+    b = pipe.prepare(utts, forced=True)
+    pipe.run(b)
+    outs.append(pipe.fetch(b))
+    pipe.close()
+    for o in outs[1:]:
+        for x, y in zip(o, outs[0]):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_allclose(streamed, outs[0][1], atol=1e-5, rtol=0)
+    bs.close(); vs.close()
 
 
 def test_pipeline_shortest_and_ragged_inputs():

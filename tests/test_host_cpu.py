@@ -9,7 +9,8 @@ import socket
 import numpy as np
 import pytest
 
-from sbv2_api_amd import _lib, shard
+import gather_twin as shard
+from sbv2_api_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -84,10 +85,9 @@ def _worker(rank, world, port, q, lens=(5, 17, 1, 9, 12)):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbv2_api_amd import model
     lens = list(lens)
-    ids = shard.deal(lens, world)[rank]
-    pcm = [np.arange(lens[i], dtype=np.float32) + 100 * i for i in ids]
-    out = shard.gather_pcm(ids, pcm, len(lens), dist)
+    out = shard.gather_by_plan(model, lens, world, rank, dist, lambda i: np.arange(lens[i], dtype=np.float32) + 100 * i)
     if rank == 0:
         q.put([o.tolist() for o in out])
     dist.destroy_process_group()
