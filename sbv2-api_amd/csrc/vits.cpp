@@ -228,6 +228,15 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         sdp_cf_.push_back(cf);
     }
     w.set_cl_parts(gemm_parts);   // the flow only shapes the (continuous) latent: split-bf16 for its k = 5 FFN convs
+    // ... and for the 1x1 products of its attention layers (q | k | v and the output projection: 48 launches of a batch-32 step) through
+    // gemm_bfs.hip with pre-split operands (bf16x3, the arithmetic of its FFN convs and its attention).  SBV2_FLOW_1X1=f32 keeps them on
+    // the exact-f32 kernel; SBV2_GEMM=f32 does as well.
+    int flow_bfs = gemm_parts == 2 && (Hc & 15) == 0 ? 2 : 0;
+    if (const char* m = getenv("SBV2_FLOW_1X1")) {
+        SBV2_REQUIRE(std::string(m) == "bf16x3" || std::string(m) == "f32" || !*m, "SBV2_FLOW_1X1 must be f32 or bf16x3");
+        if (std::string(m) == "f32") flow_bfs = 0;
+    }
+    w.set_bfs_parts(flow_bfs);
     for (int i = 0; i < cfg_.flow_n; ++i) {
         const std::string p = "flow.flows." + std::to_string(2 * i) + ".";
         Coupling c;
@@ -240,6 +249,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     }
     // the k-major decoder weights stay exact f32 (SBV2_DECODER=f32 is the exact reference path); the bf16 decoder has its own packing
     w.set_cl_parts(0);
+    w.set_bfs_parts(0);
     dec_pre_ = w.conv("dec.conv_pre");
     w.expect(dec_pre_, "dec.conv_pre", cfg_.up_initial, Ic, dec_pre_.k);
     dec_cond_w_ = w.tensor("dec.cond.weight", {cfg_.up_initial, Gc});
@@ -365,11 +375,24 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     Plane Vp = QKV.rows(2 * H, H);
     fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);
     const float qscale = 1.0f / std::sqrt((float)dk);
+    // 1x1 products on pre-split operands (gemm_bfs.hip; the flow by default): the parts of x are written by the LayerNorm that produces x
+    // (by split_planes for the encoder's input and after the speaker vector is added), the parts of the attention output by split_planes
+    const int SP = fused ? e.layers[0].attn.qkv.bfs.parts : 0;
+    SplitPlanes Xs, Cs;
+    if (SP) {
+        Xs = alloc_split(ar, SP, H, N);
+        Cs = alloc_split(ar, SP, H, N);
+        split_planes(x, Xs, stream_);
+    }
     for (size_t i = 0; i < e.layers.size(); ++i) {
         const EncLayer& L = e.layers[i];
-        if ((int)i == cfg_.cond_layer_idx && spk_vec) add_segvec(x, spk_vec, H, lay.d_seg_of, 1, lay.d_mask, stream_);
+        if ((int)i == cfg_.cond_layer_idx && spk_vec) {
+            add_segvec(x, spk_vec, H, lay.d_seg_of, 1, lay.d_mask, stream_);
+            if (SP) split_planes(x, Xs, stream_);
+        }
         if (fused) {
-            conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
+            if (SP) conv_bfs(L.attn.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_);
+            else conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
             vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
                                  split_attn, stream_);
         } else {
@@ -381,7 +404,12 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             grouped_gemm(VT, H, pl.S, pl.lds, ctx.p, ctx.ld, pl.d_pv, pl.ng, dk, pl.maxT, 1.0f, pl.flops, stream_);
             vits_relv_add(pl.d_ag, pl.ng, pl.maxT, ctx.p, ctx.ld, dk, L.attn.erv, cfg_.window, pl.PW, stream_);
         }
-        conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
+        if (SP) {
+            split_planes(ctx, Cs, stream_);
+            conv_bfs(L.attn.o, Cs, &Y, nullptr, nullptr, 1, stream_, ACT_NONE, &x);
+        } else {
+            conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
+        }
         layernorm_ch(Y, x, L.n1g, L.n1b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
         const int k = L.ffn1.k;
         // FFN: conv_1 -> ReLU -> conv_2 (+ x).  On the matrix-core path the 768-channel intermediate stays channels-last and the ReLU is
@@ -393,7 +421,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             conv_plain(L.ffn1, x, F, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_RELU);
             conv_plain(L.ffn2, F, Y, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_NONE, 1.0f, &x);
         }
-        layernorm_ch(Y, x, L.n2g, L.n2b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_);
+        layernorm_ch(Y, x, L.n2g, L.n2b, 1e-5f, ACT_NONE, nullptr, 0, lay.d_mask, stream_, (SP && i + 1 < e.layers.size()) ? &Xs : nullptr);
     }
     ar.rewind(mk);
 }
