@@ -220,7 +220,8 @@ int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int
 /* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; the
  * default comes from SBV2_SKINNY_MAX).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
 int sbv2_debug_set_skinny_max(int workgroups);
-/* 1 (default): the ResBlocks of the wide decoder stages run on conv_clx.hip; 0: on conv_cl.hip (same bits).  Returns the previous value. */
+/* 1 (default): the ResBlocks of the wide decoder stages run on conv_clx.hip when the launch is large enough to pay for it; 2: always;
+   0: on conv_cl.hip (same bits in every case).  Returns the previous value. */
 int sbv2_debug_set_clx(int on);
 /* Same contract as sbv2_debug_conv1d_cl (mode 1) through conv_clx.hip: x is split into bf16 parts of lrelu(x, pre_slope) first (split_cl), the
    convolution reads the parts; y = (conv + bias + res) * beta; ys_sum (optional) = hi + lo of the parts of lrelu(y, 0.1) the epilogue emits. */

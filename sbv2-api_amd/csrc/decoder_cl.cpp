@@ -150,6 +150,10 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
 // conv_clx.hip for the wide stages' ResBlocks (SBV2_CLX=0 / sbv2_debug_set_clx(0): the conv_cl path, bit-identical, for A/B runs and the test)
 static std::atomic<int> g_clx{getenv("SBV2_CLX") ? atoi(getenv("SBV2_CLX")) : 1};
 bool clx_enabled() { return g_clx.load(std::memory_order_relaxed) != 0; }
+static int64_t clx_min_tiles() {
+    static const int64_t v = getenv("SBV2_CLX_MIN_TILES") ? atoll(getenv("SBV2_CLX_MIN_TILES")) : 1024;
+    return g_clx.load(std::memory_order_relaxed) == 2 ? 0 : v;   // set_clx(2): every size (the bit-equality test runs small batches)
+}
 int set_clx(int on) { return g_clx.exchange(on); }
 
 void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l,
@@ -237,7 +241,9 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
         int ushift = 0;
         while ((1 << ushift) < U) ++ushift;
-        bool clx = clx_enabled() && dec_mode_ == 1 && C >= 128 && (C & 63) == 0 && (1 << ushift) == U;
+        // (large launches only: a single utterance or a streaming window has too few tiles to pay for the extra split / halo launches; the two
+        // paths give the same bits, so the choice is free)
+        bool clx = clx_enabled() && dec_mode_ == 1 && C >= 128 && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
         for (int j = 0; j < nk && clx; ++j) {
             const ClBranch& rb = st.branches[j];
             if (!(rb.k == 3 || rb.k == 7 || rb.k == 11)) clx = false;

@@ -166,6 +166,7 @@ struct VitsConfig {
     }
 };
 
+constexpr int kStreamBurst = 4;   // windows per graph replay of the streaming decoder after an utterance's first chunk
 struct VitsBatch {
     int n = 0;
     const int64_t* t_lens = nullptr;   // [n]
@@ -204,7 +205,7 @@ class VitsModel {
     int64_t stream_begin(int chunk_frames);
     int64_t stream_chunk(int64_t f0, float* dst_host, int64_t capacity);
     bool stream_graph_captured() const { return chunk_ && chunk_->exec != nullptr; }
-    size_t stream_workspace_bytes() const { return chunk_ ? chunk_->ar.capacity() : 0; }
+    size_t stream_workspace_bytes() const { return (chunk_ ? chunk_->ar.capacity() : 0) + (burst_ ? burst_->ar.capacity() : 0); }
     // results of the last forward
     const std::vector<int64_t>& pcm_lens() const { return pcm_lens_; }
     const std::vector<int64_t>& pcm_offs() const { return pcm_offs_; }
@@ -294,7 +295,7 @@ class VitsModel {
     // fixed-shape decoder of the streaming path: own arena (never reset while the plan lives), persistent input / conditioning buffers
     // and the captured graph
     struct ChunkPlan {
-        int chunk = 0, W = 0;
+        int chunk = 0, W = 0, nwin = 1;   // nwin windows of W frames per replay
         Arena ar;
         SegLayout lay;
         Plane zin;
@@ -316,8 +317,10 @@ class VitsModel {
             }
         }
     };
-    void stream_enqueue(int64_t f0, int slot);
-    std::shared_ptr<ChunkPlan> chunk_;
+    void ensure_plan(std::shared_ptr<ChunkPlan>& slot, int chunk_frames, int nwin);
+    void stream_enqueue(ChunkPlan& c, int64_t f0, int slot);
+    bool stream_bursts_ = false;                 // the running stream uses burst_ behind its first chunk
+    std::shared_ptr<ChunkPlan> chunk_, burst_;   // one window (an utterance's first chunk) / kStreamBurst windows per replay (every later one)
     Plane z_{};              // flow output of the last forward (frame-rate plane, packed layout fl_)
 
     int device_;

@@ -319,6 +319,7 @@ VitsModel* VitsModel::clone() const {
     c->pcm_offs_.clear();
     c->traces_.clear();
     c->chunk_.reset();
+    c->burst_.reset();
     c->z_ = Plane{};
     c->trace_ = false;
     return c;
@@ -772,29 +773,33 @@ int VitsModel::stream_halo() const {
     return round_up((int)std::ceil(rf) + 1, 4);
 }
 
-int64_t VitsModel::stream_begin(int chunk_frames) {
-    HIP_CHECK(hipSetDevice(device_));
-    SBV2_REQUIRE(fl_.n == 1 && z_.p, "stream_begin needs a preceding forward of ONE utterance with skip_decoder");
-    SBV2_REQUIRE(chunk_frames >= 16 && chunk_frames <= (1 << 20), "chunk_frames must be in [16, 2^20]");
+// A decode plan = nwin windows of chunk + 2 * halo frames packed into one batch (the packed-batch layout: the gaps between the windows are
+// the zero padding of every convolution), its persistent input / conditioning buffers, its own arena and the graph captured for that shape.
+// chunk_ (one window) decodes the first chunk of an utterance: time to first PCM; burst_ (kStreamBurst windows per replay) every later
+// one: a 288-frame window is ~90 launches of mostly < 100 workgroups, i.e. launch-latency bound, and four windows per replay cost little
+// more than one (profiles/r03_longform_*.json).
+void VitsModel::ensure_plan(std::shared_ptr<ChunkPlan>& slot, int chunk_frames, int nwin) {
     static const bool no_graph = getenv("SBV2_STREAM_GRAPH") && atoi(getenv("SBV2_STREAM_GRAPH")) == 0;   // A/B knob
-    if (!chunk_ || chunk_->chunk != chunk_frames) {
-        chunk_.reset(new ChunkPlan);
-        ChunkPlan& c = *chunk_;
+    if (!slot || slot->chunk != chunk_frames || slot->nwin != nwin) {
+        slot.reset(new ChunkPlan);
+        ChunkPlan& c = *slot;
         c.chunk = chunk_frames;
+        c.nwin = nwin;
         c.W = chunk_frames + 2 * stream_halo();
-        c.lay = make_layout(std::vector<int>{c.W}, kFrameGap, c.ar, stream_);
+        c.lay = make_layout(std::vector<int>(nwin, c.W), kFrameGap, c.ar, stream_);
         c.zin = c.ar.plane(cfg_.inter, c.lay.L);
         fill_zero(c.zin.p, sizeof(float) * (size_t)c.zin.C * c.zin.ld, stream_);
-        c.cond = c.ar.array<float>((size_t)cfg_.up_initial);
+        c.cond = c.ar.array<float>((size_t)cfg_.up_initial * nwin);
         c.mark = c.ar.mark();
         for (int i = 0; i < 2; ++i) {
-            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.host[i]), sizeof(float) * (size_t)chunk_frames * cfg_.hop(), hipHostMallocDefault));
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.host[i]), sizeof(float) * (size_t)nwin * chunk_frames * cfg_.hop(), hipHostMallocDefault));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming));
         }
     }
-    ChunkPlan& c = *chunk_;
-    // the speaker conditioning vector of THIS utterance goes into the plan's persistent buffer (the captured launches read it there)
-    HIP_CHECK(hipMemcpyAsync(c.cond, dec_cond_vec_, sizeof(float) * (size_t)cfg_.up_initial, hipMemcpyDeviceToDevice, stream_));
+    ChunkPlan& c = *slot;
+    // the speaker conditioning vector of THIS utterance goes into the plan's persistent buffer (the captured launches read it there), once per window
+    for (int w = 0; w < nwin; ++w)
+        HIP_CHECK(hipMemcpyAsync(c.cond + (size_t)w * cfg_.up_initial, dec_cond_vec_, sizeof(float) * (size_t)cfg_.up_initial, hipMemcpyDeviceToDevice, stream_));
     if (!c.exec && !no_graph) {
         // warm-up pass (sizes the arena: no hipMalloc may happen under capture), then the same launch sequence under capture
         auto decode = [&]() {
@@ -826,21 +831,36 @@ int64_t VitsModel::stream_begin(int chunk_frames) {
         c.ar.reset_pinned();
     }
     c.slot_f0[0] = c.slot_f0[1] = -1;
-    stream_enqueue(0, 0);   // the first chunk starts right behind the flow
-    return fl_.len[0];
 }
 
-// window + decoder (graph replay) + device -> pinned-host copy of the window's centre, all asynchronous on the model's stream
-void VitsModel::stream_enqueue(int64_t f0, int slot) {
-    ChunkPlan& c = *chunk_;
+int64_t VitsModel::stream_begin(int chunk_frames) {
+    HIP_CHECK(hipSetDevice(device_));
+    SBV2_REQUIRE(fl_.n == 1 && z_.p, "stream_begin needs a preceding forward of ONE utterance with skip_decoder");
+    SBV2_REQUIRE(chunk_frames >= 16 && chunk_frames <= (1 << 20), "chunk_frames must be in [16, 2^20]");
+    static const int burst = getenv("SBV2_STREAM_BURST") ? std::max(1, std::min(16, atoi(getenv("SBV2_STREAM_BURST")))) : kStreamBurst;
+    const int64_t Tf = fl_.len[0];
+    ensure_plan(chunk_, chunk_frames, 1);
+    const bool want_burst = burst > 1 && Tf > chunk_frames;   // an utterance of one chunk never needs it
+    if (want_burst) ensure_plan(burst_, chunk_frames, burst);
+    stream_bursts_ = want_burst;
+    stream_enqueue(*chunk_, 0, 0);                            // the first chunk starts right behind the flow ...
+    if (want_burst) stream_enqueue(*burst_, chunk_frames, 0); // ... and the first burst right behind it
+    return Tf;
+}
+
+// windows + decoder (graph replay) + device -> pinned-host copies of the windows' centres, all asynchronous on the model's stream.
+// The plan's windows are the chunks starting at f0, f0 + chunk, ... (windows past the end of the utterance decode zeros and are not copied).
+void VitsModel::stream_enqueue(ChunkPlan& c, int64_t f0, int slot) {
     const int64_t Tf = fl_.len[0];
     const int hop = cfg_.hop(), halo = stream_halo();
-    const int64_t nsamp = std::min<int64_t>(c.chunk, Tf - f0) * hop;
-    // window = frames [f0 - halo, f0 - halo + W) of this utterance (fl_.start[0] is its first column in the packed plane)
+    // window w = frames [f0_w - halo, f0_w - halo + W) of this utterance (fl_.start[0] is its first column in the packed plane)
     Plane zu = z_;
     zu.p = z_.p + fl_.start[0];
     zu.L = (int)Tf;
-    window_cols(zu, (int)(f0 - halo), Plane{c.zin.p, c.zin.C, c.W, c.zin.ld}, c.lay.d_mask, stream_);
+    for (int w = 0; w < c.nwin; ++w) {
+        const int64_t fw = std::min<int64_t>(f0 + (int64_t)w * c.chunk, Tf + c.W);   // (past the end: an all-zero window)
+        window_cols(zu, (int)(fw - halo), Plane{c.zin.p + c.lay.start[w], c.zin.C, c.W, c.zin.ld}, c.lay.d_mask + c.lay.start[w], stream_);
+    }
     if (c.exec) {
         HIP_CHECK(hipGraphLaunch(c.exec, stream_));
     } else {
@@ -849,26 +869,51 @@ void VitsModel::stream_enqueue(int64_t f0, int slot) {
         else run_decoder(c.ar, c.zin, c.lay, c.cond);
         c.pcm = pcm_;
     }
-    HIP_CHECK(hipMemcpyAsync(c.host[slot], c.pcm + (size_t)halo * hop, sizeof(float) * (size_t)nsamp, hipMemcpyDeviceToHost, stream_));
+    int64_t total = 0;
+    for (int w = 0; w < c.nwin; ++w) {
+        const int64_t fw = f0 + (int64_t)w * c.chunk;
+        if (fw >= Tf) break;
+        const int64_t nsamp = std::min<int64_t>(c.chunk, Tf - fw) * hop;
+        HIP_CHECK(hipMemcpyAsync(c.host[slot] + (size_t)w * c.chunk * hop, c.pcm + ((size_t)w * c.W + halo) * hop, sizeof(float) * (size_t)nsamp,
+                                 hipMemcpyDeviceToHost, stream_));
+        total += nsamp;
+    }
     HIP_CHECK(hipEventRecord(c.ev[slot], stream_));
     c.slot_f0[slot] = f0;
-    c.slot_n[slot] = nsamp;
+    c.slot_n[slot] = total;
 }
 
 int64_t VitsModel::stream_chunk(int64_t f0, float* dst_host, int64_t capacity) {
     HIP_CHECK(hipSetDevice(device_));
     SBV2_REQUIRE(chunk_ && z_.p && fl_.n == 1, "stream_chunk without stream_begin");
-    ChunkPlan& c = *chunk_;
+    ChunkPlan& c1 = *chunk_;
     const int64_t Tf = fl_.len[0];
-    SBV2_REQUIRE(f0 >= 0 && f0 < Tf && f0 % c.chunk == 0, "chunk start out of range");
-    const int slot = (int)((f0 / c.chunk) & 1);
-    const int64_t nsamp = std::min<int64_t>(c.chunk, Tf - f0) * cfg_.hop();
+    SBV2_REQUIRE(f0 >= 0 && f0 < Tf && f0 % c1.chunk == 0, "chunk start out of range");
+    const int hop = cfg_.hop();
+    const int64_t nsamp = std::min<int64_t>(c1.chunk, Tf - f0) * hop;
     SBV2_REQUIRE(capacity >= nsamp, "PCM buffer too small for the chunk");
-    if (c.slot_f0[slot] != f0) stream_enqueue(f0, slot);                                  // (random access: not the streaming order)
-    if (f0 + c.chunk < Tf && c.slot_f0[slot ^ 1] != f0 + c.chunk) stream_enqueue(f0 + c.chunk, slot ^ 1);   // next chunk runs while this one is delivered
-    HIP_CHECK(hipEventSynchronize(c.ev[slot]));
-    std::memcpy(dst_host, c.host[slot], sizeof(float) * (size_t)nsamp);
-    c.slot_f0[slot] = -1;
+    const int64_t ci = f0 / c1.chunk;
+    const bool bursts = stream_bursts_ && burst_ && burst_->chunk == c1.chunk;
+    if (ci == 0 || !bursts) {
+        // the single-window plan: the utterance's first chunk (and everything when bursts are off); the next chunk runs while this one is delivered
+        const int slot = (int)(ci & 1);
+        if (c1.slot_f0[slot] != f0) stream_enqueue(c1, f0, slot);                                  // (random access: not the streaming order)
+        if (!bursts && f0 + c1.chunk < Tf && c1.slot_f0[slot ^ 1] != f0 + c1.chunk) stream_enqueue(c1, f0 + c1.chunk, slot ^ 1);
+        HIP_CHECK(hipEventSynchronize(c1.ev[slot]));
+        std::memcpy(dst_host, c1.host[slot], sizeof(float) * (size_t)nsamp);
+        c1.slot_f0[slot] = -1;
+        return nsamp;
+    }
+    ChunkPlan& cb = *burst_;
+    const int64_t bi = (ci - 1) / cb.nwin, within = (ci - 1) % cb.nwin;
+    const int64_t bf0 = (1 + bi * cb.nwin) * c1.chunk;      // first frame of this chunk's burst
+    const int slot = (int)(bi & 1);
+    if (cb.slot_f0[slot] != bf0) stream_enqueue(cb, bf0, slot);                                    // (random access)
+    // the following burst is decoded while this one is delivered (its slot was drained one burst ago)
+    const int64_t nf0 = bf0 + (int64_t)cb.nwin * c1.chunk;
+    if (within == 0 && nf0 < Tf && cb.slot_f0[slot ^ 1] != nf0) stream_enqueue(cb, nf0, slot ^ 1);
+    HIP_CHECK(hipEventSynchronize(cb.ev[slot]));
+    std::memcpy(dst_host, cb.host[slot] + (size_t)within * c1.chunk * hop, sizeof(float) * (size_t)nsamp);
     return nsamp;
 }
 

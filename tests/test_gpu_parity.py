@@ -386,7 +386,7 @@ def test_decoder_clx_path_same_bits_as_conv_cl_path():
     s = model.load_model(blob("vits", "full"), False)
     utts = make_utts([12, 31, 5], O.DEBERTA_FULL, cfg, seed0=77)
     lib = _lib.lib()
-    prev = lib.sbv2_debug_set_clx(1)
+    prev = lib.sbv2_debug_set_clx(2)      # 2 = conv_clx at every size (1, the default, leaves small launches to conv_cl)
     try:
         a = model.synthesize_batch(s, utts, forced=True)
         lib.sbv2_debug_set_clx(0)
