@@ -342,6 +342,7 @@ struct ResPairParams {
     const unsigned char* mask = nullptr;
     int mask_div = 1;
     int mask_shift = -1;   // set by launch_respair_cl
+    int alias_x2 = 1;      // set by launch_respair_cl: the intermediate window re-uses the conv1 window's LDS
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
 

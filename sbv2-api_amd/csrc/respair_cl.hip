@@ -59,12 +59,18 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
     char* wsm = smem;
     char* x1_hi = smem + wbytes;
     char* x1_lo = x1_hi + rows1 * 32;
-    char* x2_hi = x1_hi + rows1 * 32 * PARTS;                 // [chunk][kRpWin2Rows][32 B]
+    // The intermediate window ALIASES the conv1 window: it is written after the barrier that ends conv1's last MFMA block (every wave is done
+    // reading x1 by then), and the next tile's conv1 window is staged after conv2's last barrier.  LDS per workgroup: weights + max(x1, x2)
+    // instead of weights + x1 + x2, i.e. 49 instead of 67 KB at C = 32, k = 7: three workgroups per CU instead of two (the kernel is
+    // bound by its staging / barrier phases, MFMA busy 0.34: a third workgroup fills them).  The persistent variant prefetches the next
+    // tile's window into registers only, which does not touch LDS before the tile's last barrier either.
+    char* x2_hi = p.alias_x2 ? x1_hi : x1_hi + rows1 * 32 * PARTS;   // [chunk][kRpWin2Rows][32 B]
     char* x2_lo = x2_hi + nchunks * kRpWin2Rows * 32;
     // biases and the column-mask bytes of this tile, staged once: read from LDS by the two epilogues instead of three dependent
     // global round trips (~0.7-1 us each on a ~12 us workgroup in the clock-stamp timeline).  Placed behind everything the epilogue's
     // transpose tiles overlay.
-    const int main_bytes = wbytes + rows1 * 32 * PARTS + nchunks * kRpWin2Rows * 32 * PARTS;
+    const int main_bytes = p.alias_x2 ? wbytes + max(rows1 * 32 * PARTS, nchunks * kRpWin2Rows * 32 * PARTS)
+                                      : wbytes + rows1 * 32 * PARTS + nchunks * kRpWin2Rows * 32 * PARTS;
     float* bias_s = reinterpret_cast<float*>(smem + max(main_bytes, WM * 4 * 64 * 36 * 4));   // [0, 64): b1, [64, 128): b2
     unsigned char* mask_s = reinterpret_cast<unsigned char*>(bias_s + 128);                      // [kRpWin2Rows + 16]: rows of the intermediate
 
@@ -343,7 +349,8 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     constexpr int PARTS = PREC == PREC_BF16X3 ? 2 : 1;
     const int h1 = p.dil * (p.k - 1) / 2, h2 = (p.k - 1) / 2;
     const int rows1 = kRpNT + 2 * h1;
-    size_t lds = (size_t)p.k * WM * PARTS * 1024 + (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS;
+    size_t lds = (size_t)p.k * WM * PARTS * 1024 + (p.alias_x2 ? std::max((size_t)rows1 * 32 * PARTS, (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS)
+                                                               : (size_t)rows1 * 32 * PARTS + (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS);
     lds = std::max<size_t>(lds, (size_t)WM * 4 * 64 * 36 * sizeof(float));
     lds += 128 * sizeof(float) + kRpWin2Rows + 16;   // biases + mask bytes (kernel: bias_s, mask_s)
     lds = (lds + 15) / 16 * 16;
@@ -379,6 +386,8 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(!p.mask || (p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0), "respair: mask_div must be a power of two");
     p.mask_shift = 0;
     while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
+    static const int alias = getenv("SBV2_RESPAIR_ALIAS") ? atoi(getenv("SBV2_RESPAIR_ALIAS")) : 1;   // A/B knob: 0 = separate x1 / x2 windows
+    p.alias_x2 = alias;
     SBV2_REQUIRE(p.C == 16 || p.C == 32 || p.C == 64, "respair: only the 16-, 32- and 64-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");

@@ -34,6 +34,10 @@ def per_kernel(path, counters):
 
 
 shutil.copy(os.path.join(G, "final_bench.json"), P("bench.json"))
+for extra in ("mixed256", "b1_latency", "longform_c256", "longform_c256_burst1", "longform_c1024"):
+    src = os.path.join(G, f"final_{extra}.json")
+    if os.path.exists(src) and os.path.getsize(src) > 2:
+        shutil.copy(src, P(f"{extra}.json"))
 st = one("final_stats/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, P("bench_kernel_stats.csv"))
