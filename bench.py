@@ -223,8 +223,10 @@ def main():
     my_samples = max(sub_samples)
 
     dmode = l.sbv2_vits_decoder_mode(vs.handle)
-    dtype = {0: "f32", 1: "bf16x3-split (decoder convs: bf16 hi/lo MFMA, f32 accumulate/storage) + f32", 2: "bf16 (decoder convs) + f32",
-             3: "f16 (decoder convs: fp16 MFMA operands, f32 accumulate/storage) + f32"}[dmode]
+    dtype = {0: "f32", 1: "bf16x3-split (decoder + flow convs: bf16 hi/lo MFMA, f32 accumulate/storage)", 2: "bf16 (decoder convs)",
+             3: "f16 (decoder convs: fp16 MFMA operands, f32 accumulate/storage)"}[dmode]
+    dtype += {0: " + f32 (DeBERTa, text side)", 2: " + bf16x3 (DeBERTa GEMMs) + f32 (text side)",
+              3: " + bf16x6 (DeBERTa GEMMs: three bf16 parts per operand, f32-grade) + f32 (text side)"}.get(l.sbv2_bert_gemm_parts(bs.handle), "")
 
     comm, host, rccl_error = None, None, ""
     if world > 1:

@@ -26,6 +26,7 @@ SYMBOLS = {
     "sbv2_bert_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "sbv2_bert_destroy": (None, [C.c_void_p]),
     "sbv2_bert_hidden": (C.c_int64, [C.c_void_p]),
+    "sbv2_bert_gemm_parts": (C.c_int, [C.c_void_p]),
     "sbv2_bert_predict": (C.c_int, [C.c_void_p, i64p, i64p, C.c_int64, f32p]),
     "sbv2_bert_predict_batch": (C.c_int, [C.c_void_p, C.c_int64, i64p, i64p, i64p, f32p]),
     "sbv2_vits_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),

@@ -71,6 +71,7 @@ int sbv2_bert_create(const uint8_t* model, size_t model_len, int device, sbv2_be
 }
 void sbv2_bert_destroy(sbv2_bert* h) { delete h; }
 int64_t sbv2_bert_hidden(const sbv2_bert* h) { return h ? h->m->cfg().hidden : 0; }
+int sbv2_bert_gemm_parts(const sbv2_bert* h) { return h ? h->m->gemm_parts() : -1; }
 
 int sbv2_bert_predict_batch(sbv2_bert* h, int64_t n, const int64_t* token_ids, const int64_t* attention_mask, const int64_t* lens,
                             float* out) {

@@ -122,6 +122,7 @@ class BertModel {
     BertModel* clone() const;
     int device() const { return device_; }
     const BertConfig& cfg() const { return cfg_; }
+    int gemm_parts() const { return bfs_parts_; }   // 0 = exact-f32 products, 2 = bf16x3, 3 = bf16x6
     // ids/mask concatenated over utterances; result stays on the device (out_, layout_)
     void forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens);
     void copy_out(float* host);  // [sum S][hidden], utterances concatenated
