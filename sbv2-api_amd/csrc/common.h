@@ -304,6 +304,7 @@ struct SplitClPlanes {           // bf16 hi / lo of a channels-last activation, 
 size_t split_cl_bytes(int C, int64_t N);
 SplitClPlanes make_split_cl(void* mem, int C, int64_t N, hipStream_t stream);   // adopts `mem` (split_cl_bytes) and zeroes the halo rows
 void split_cl(const float* X, int ldx, int64_t N, int C, float slope, const SplitClPlanes& out, hipStream_t stream);   // out = split(lrelu(X))
+void split_cl_km(Plane x, float slope, const SplitClPlanes& out, hipStream_t stream);   // the same from a k-major plane [C][ld]
 struct ConvClxParams {
     SplitClPlanes X;            // operand: bf16 parts of the ACTIVATED input
     const void* W = nullptr;    // pack_cl fragments (split-bf16: parts = 2), nmt row tiles of 32
@@ -312,6 +313,10 @@ struct ConvClxParams {
     int shift0 = 0, shift_step = 1;   // tap t reads position + shift0 + t * shift_step
     float* Y = nullptr;         // f32 result [N][ldy] (optional)
     int ldy = 0;
+    float* Ykm = nullptr;       // ... or a k-major f32 result plane [M][ldykm] (then Y, Ys, R, accumulate are unused; Rkm is its residual plane)
+    int ldykm = 0;
+    const float* Rkm = nullptr;
+    int ldrkm = 0;
     SplitClPlanes Ys;           // bf16 parts of lrelu(result, ys_slope) (optional: p == nullptr)
     float ys_slope = 1.0f;
     const float* bias = nullptr;
@@ -326,6 +331,7 @@ struct ConvClxParams {
 bool conv_clx_usable(const ConvClxParams& p);
 bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
 int set_clx(int on);  // returns the previous setting
+bool clx_wanted(int64_t tiles, int64_t min_tiles);   // mode 1: launches of >= min_tiles tiles; mode 2: always; mode 0: never
 void launch_conv_clx(const ConvClxParams& p, hipStream_t stream);
 
 // One fused ResBlock1 step y' = beta * (conv2(lrelu(conv1(lrelu(y), dil) + b1)) + b2 + y) on a channels-last plane (respair_cl.hip)

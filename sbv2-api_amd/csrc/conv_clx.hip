@@ -305,6 +305,47 @@ __global__ __launch_bounds__(256 * WM) void conv_clx_kernel(const ClxKernelParam
     }
     __syncthreads();   // the epilogue re-uses the rings as its transpose tiles
 
+    // ---- k-major result (the flow's second FFN convolution: Y[m][n] = (conv + b + R[m][n]) * mask): one accumulator register of a half-wave
+    // is 32 consecutive positions of one channel = a 128-byte run of the plane; bias, mask and residual of a row tile are requested before its
+    // first store (conv_cl's k-major epilogue)
+    if (p.Ykm) {
+        int nn[2];
+        bool nok[2], keepn[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            nn[j] = n0 + wq * 64 + j * 32 + lcol;
+            nok[j] = nn[j] < N;
+            const int nc = min(nn[j], N - 1);
+            keepn[j] = !p.mask || p.mask[nc >> p.mask_shift] != 0;
+        }
+        clx_static_for<0, 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            float brow[16], rr[16][2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mc = min(m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+                brow[r] = p.bias ? p.bias[mc] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rr[r][j] = p.Rkm ? p.Rkm[(int64_t)mc * p.ldrkm + min(nn[j], N - 1)] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!nok[j]) continue;
+                    float v = acc[i][j][r] + brow[r];
+                    if (p.Rkm) v += rr[r][j];
+                    v *= p.beta;
+                    p.Ykm[(int64_t)m * p.ldykm + nn[j]] = keepn[j] ? v : 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        return;
+    }
+
     // ---- epilogue (conv_cl's channels-last epilogue): each wave transposes its 32 x 64 sub-tiles through a private LDS tile [64 positions][36]
     // so that 8 consecutive lanes hold one full 128-byte line of a row; everything read from global memory is requested before the first store.
     float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
@@ -391,6 +432,30 @@ __global__ __launch_bounds__(256) void k_split_cl(const float* __restrict__ X, i
         *reinterpret_cast<bf16x4*>(dst + plane) = l;
     }
 }
+// f32 k-major plane [C][ld] -> chunk-major bf16 parts of lrelu(x): a thread owns one position and 16 channels (the 16 loads of a wave are 256-byte
+// runs of 16 rows; its two 32-byte rows per part are contiguous with its neighbours')
+__global__ __launch_bounds__(256) void k_split_cl_km(const float* __restrict__ X, int ldx, int64_t N, int C, float slope, SplitClPlanes out) {
+    const int64_t plane = (int64_t)(out.front + out.N + out.back) * 32;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (n >= N) return;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = X[(int64_t)(chunk * 16 + c) * ldx + n];
+    bf16x8 h[2], l[2];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float x = v[c] >= 0.f ? v[c] : v[c] * slope;
+        const __bf16 hh = (__bf16)x;
+        h[c >> 3][c & 7] = hh;
+        l[c >> 3][c & 7] = (__bf16)(x - (float)hh);
+    }
+    char* dst = static_cast<char*>(out.p) + ((int64_t)chunk * 2) * plane + ((int64_t)out.front + n) * 32;
+    *reinterpret_cast<bf16x8*>(dst) = h[0];
+    *reinterpret_cast<bf16x8*>(dst + 16) = h[1];
+    *reinterpret_cast<bf16x8*>(dst + plane) = l[0];
+    *reinterpret_cast<bf16x8*>(dst + plane + 16) = l[1];
+}
 // zero halo rows in front of and behind every (chunk, part) plane: the zero padding of the convolutions at the ends of the batch
 __global__ __launch_bounds__(256) void k_clx_zero_halo(SplitClPlanes s) {
     const int64_t rows = (int64_t)s.front + s.N + s.back;
@@ -428,8 +493,15 @@ void split_cl(const float* X, int ldx, int64_t N, int C, float slope, const Spli
     HIP_CHECK(hipGetLastError());
 }
 
+void split_cl_km(Plane x, float slope, const SplitClPlanes& out, hipStream_t stream) {
+    SBV2_REQUIRE((x.C & 15) == 0 && out.C == x.C && out.N == x.L, "split_cl_km: shape mismatch");
+    hipLaunchKernelGGL(k_split_cl_km, dim3((unsigned)((x.L + 255) / 256), x.C >> 4), dim3(256), 0, stream, x.p, x.ld, (int64_t)x.L, x.C, slope, out);
+    HIP_CHECK(hipGetLastError());
+}
+
 bool conv_clx_usable(const ConvClxParams& p) {
-    if (!(p.ntaps == 3 || p.ntaps == 7 || p.ntaps == 11)) return false;
+    if (!(p.ntaps == 3 || p.ntaps == 5 || p.ntaps == 7 || p.ntaps == 11)) return false;
+    if (p.Ykm && (p.Y || p.Ys.p || p.accumulate || p.R)) return false;   // the k-major epilogue writes Ykm only
     if ((p.K & 15) || (p.M & 63) || p.K != p.X.C || p.nmt * 32 < p.M || (p.nmt & 1)) return false;
     const int span = (p.ntaps - 1) * std::abs(p.shift_step);
     if (span > kClxXR - kClxNT || p.shift0 < -kClxFront || p.shift0 + span > 64) return false;
@@ -476,16 +548,17 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     kp.sh0 = p.shift0 - smin;
     kp.sh_step = step;
     static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 1;   // experiments: 2 = 128-row workgroups (one per CU), 1 = 64-row (two per CU)
-    if (cfg == 2 && (p.M & 127) == 0) {
+    if (cfg == 2 && (p.M & 127) == 0 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
         else launch_clx<11, 2, 8, 3>(kp, stream);
-    } else if (cfg == 3) {
+    } else if (cfg == 3 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 1, 8, 2>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 1, 8, 2>(kp, stream);
         else launch_clx<11, 1, 8, 2>(kp, stream);
     } else {
         if (p.ntaps == 3) launch_clx<3, 1, 4, 3>(kp, stream);
+        else if (p.ntaps == 5) launch_clx<5, 1, 4, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 1, 4, 3>(kp, stream);
         else launch_clx<11, 1, 4, 3>(kp, stream);
     }

@@ -154,6 +154,10 @@ static int64_t clx_min_tiles() {
     static const int64_t v = getenv("SBV2_CLX_MIN_TILES") ? atoll(getenv("SBV2_CLX_MIN_TILES")) : 1024;
     return g_clx.load(std::memory_order_relaxed) == 2 ? 0 : v;   // set_clx(2): every size (the bit-equality test runs small batches)
 }
+bool clx_wanted(int64_t tiles, int64_t min_tiles) {
+    const int m = g_clx.load(std::memory_order_relaxed);
+    return m == 2 || (m == 1 && tiles >= min_tiles);
+}
 int set_clx(int on) { return g_clx.exchange(on); }
 
 void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l,

@@ -385,6 +385,16 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
         Cs = alloc_split(ar, SP, H, N);
         split_planes(x, Xs, stream_);
     }
+    // Large batches: the FFN pair on conv_clx.hip (pre-split chunk-major operands by LDS-DMA instead of conv_cl's transposing register staging):
+    // x is split once per layer from its k-major plane (split_cl_km), conv_1's epilogue writes relu(.) as conv_2's operand parts, conv_2 writes
+    // the k-major result + residual.  Same MFMA order as the conv_cl path: same bits, so small launches (a single utterance) may stay there.
+    const bool clx_ffn = Fcl && f1.cl.parts == 2 && f2.cl.parts == 2 && f1.k == 5 && f2.k == 5 && (H & 63) == 0 && (f1.cout & 63) == 0 &&
+                         clx_wanted((int64_t)(N / 256) * (H / 64), 192);
+    SplitClPlanes XsC, FsC;
+    if (clx_ffn) {
+        XsC = make_split_cl(ar.alloc(split_cl_bytes(H, N)), H, N, stream_);
+        FsC = make_split_cl(ar.alloc(split_cl_bytes(f1.cout, N)), f1.cout, N, stream_);
+    }
     for (size_t i = 0; i < e.layers.size(); ++i) {
         const EncLayer& L = e.layers[i];
         if ((int)i == cfg_.cond_layer_idx && spk_vec) {
@@ -416,7 +426,43 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
         // FFN: conv_1 -> ReLU -> conv_2 (+ x).  On the matrix-core path the 768-channel intermediate stays channels-last and the ReLU is
         // conv_2's pre-activation (leaky slope 0); otherwise (exact-f32 text side) both convs run on k-major planes.
         const int Fc = L.ffn1.cout;
-        if (Fcl && conv_km_to_cl(L.ffn1, x, Fcl, Fc, 1, (k - 1) / 2, lay.d_mask, 1, stream_)) {
+        if (clx_ffn) {
+            split_cl_km(x, 1.0f, XsC, stream_);
+            ConvClxParams p1;
+            p1.X = XsC;
+            p1.W = L.ffn1.cl.w;
+            p1.nmt = L.ffn1.cl.nmt;
+            p1.M = Fc;
+            p1.N = N;
+            p1.K = H;
+            p1.ntaps = k;
+            p1.shift0 = -(k - 1) / 2;
+            p1.shift_step = 1;
+            p1.Ys = FsC;
+            p1.ys_slope = 0.0f;     // ReLU
+            p1.bias = L.ffn1.bias;
+            p1.mask = lay.d_mask;
+            p1.mask_shift = 0;
+            launch_conv_clx(p1, stream_);
+            ConvClxParams p2;
+            p2.X = FsC;
+            p2.W = L.ffn2.cl.w;
+            p2.nmt = L.ffn2.cl.nmt;
+            p2.M = H;
+            p2.N = N;
+            p2.K = Fc;
+            p2.ntaps = k;
+            p2.shift0 = -(k - 1) / 2;
+            p2.shift_step = 1;
+            p2.Ykm = Y.p;
+            p2.ldykm = Y.ld;
+            p2.Rkm = x.p;
+            p2.ldrkm = x.ld;
+            p2.bias = L.ffn2.bias;
+            p2.mask = lay.d_mask;
+            p2.mask_shift = 0;
+            launch_conv_clx(p2, stream_);
+        } else if (Fcl && conv_km_to_cl(L.ffn1, x, Fcl, Fc, 1, (k - 1) / 2, lay.d_mask, 1, stream_)) {
             SBV2_REQUIRE(conv_cl_to_km(L.ffn2, Fcl, Fc, Y, 1, (k - 1) / 2, lay.d_mask, 1, stream_, 0.0f, &x), "FFN: conv_2 has no matrix-core path");
         } else {
             conv_plain(L.ffn1, x, F, 1, (k - 1) / 2, lay.d_mask, 1, stream_, ACT_RELU);

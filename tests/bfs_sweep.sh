@@ -1,5 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "decoder_cl_modes or vits_full or config2 or vits_tiny" 2>&1 | tail -4
-for m in 1 0 1 0; do echo "=== SBV2_RESPAIR_ALIAS=$m"; SBV2_RESPAIR_ALIAS=$m timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | python -c "
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "clx or vits_full or config2 or vits_e2e" 2>&1 | tail -4
+for m in 1 0 1 0; do echo "=== SBV2_CLX=$m"; SBV2_CLX=$m timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
