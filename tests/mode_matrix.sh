@@ -1,0 +1,11 @@
+# Builder tool (GPU box): the parity suite under the non-default arithmetic / kernel-selection knobs (every mode must stay green; under
+# bf16x3 the tests whose tolerance is written for f32-grade DeBERTa features are deselected: that mode is opt-in because it misses them).
+run() { echo "=== $*"; env "$@" timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x "${SEL[@]}" 2>&1 | tail -3; }
+SEL=()
+if [ "$1" != "x3only" ]; then
+run SBV2_CLX=0
+run SBV2_CLX=2
+run SBV2_BERT_GEMM=f32 SBV2_FLOW_1X1=f32
+fi
+SEL=(-k "not (deberta or pipeline or config or smoke or orchestrator or holder or streaming or edge or cpp_host or node or comm)")
+run SBV2_BERT_GEMM=bf16x3 SBV2_FLOW_1X1=bf16x3
