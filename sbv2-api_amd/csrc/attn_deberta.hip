@@ -341,7 +341,208 @@ __global__ __launch_bounds__(512) void k_deberta_attn128(const AttnGroup* groups
         }
     }
 }
+
+// ---- any length beyond 128 tokens (long-form text, BASELINE configs[4]): key-tile loop with an online softmax ----------------------------
+// One workgroup per (utterance, head, 32-query tile); its four waves take the key tiles jt = wave, wave + 4, ... and keep a private
+// running (max, sum, ctx) per query column, merged in wave order through LDS at the end (fixed order: results depend on T only).  Per
+// 32 x 32 score tile the arithmetic is that of k_deberta_attn128 (K^T Q, a 64-index piece of c2p^T and of p2c in the wave's 8.4 KB
+// scratch, gathered by bucket index); the query operand (the B side of K^T Q and of every c2p piece) stays in registers over the whole
+// loop, the key operand over the tile.  ctx = V P^T needs no transpose of P: k-step s of the MFMA takes P rows acc_row(s, kh), which is
+// exactly score register s of the lane, and the V tile (staged coalesced into the scratch once the gathers are done) is read at the same rows.
+constexpr int kDlScr = 64 * 33;   // floats of per-wave scratch
+
+__global__ __launch_bounds__(256) void k_deberta_attn_long(const AttnGroup* groups, const float* Q, const float* K, int ld, const float* V,
+                                                          const float* posk, const float* posq, int ldp, int win_lo, int wlen, const int* tab,
+                                                          int tab_center, int span, float inv_scale, const unsigned char* tok_mask, int dh,
+                                                          float* ctx, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) float dl_smem[];
+    float* scr = dl_smem;                                             // [4 waves][kDlScr]
+    float (*cm)[32] = reinterpret_cast<float (*)[32]>(scr + 4 * kDlScr);   // running max / sum of each wave, for the merge
+    float (*cl)[32] = cm + 4;
+    int* tab_s = reinterpret_cast<int*>(cl + 4);                      // [2 T - 1]
+    const AttnGroup g = groups[blockIdx.y];
+    const int T = g.T;
+    const int it = blockIdx.x;
+    if (it * 32 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int64_t hoff = (int64_t)g.head * dh;
+    const float* Qg = Q + hoff * ld + g.col0;
+    const float* Kg = K + hoff * ld + g.col0;
+    const float* Pk = posk + hoff * ldp + win_lo;
+    const float* Pq = posq + hoff * ldp + win_lo;
+    const float* Vg = V + hoff * ld + g.col0;
+    const int ns = dh >> 1;
+    const int hi = 2 * span - 1;
+    for (int e = tid; e < 2 * T - 1; e += 256) tab_s[e] = tab[tab_center - (T - 1) + e];   // tab_s[(i - j) + T - 1] = bucket(i - j)
+    __syncthreads();
+
+    // operand columns: lane (col, kh) holds x[d = 2 s + kh][c0 + col] for the 32 k-steps; columns outside [0, cmax) read as zero
+    auto load_col = [&](const float* base, int ldx, int c0, int cmax, float (&out)[32]) {
+        const int c = c0 + col;
+        const bool ok = c >= 0 && c < cmax;
+        const float* ptr = base + min(max(c, 0), cmax - 1);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float v = ptr[(int64_t)min(2 * s + kh, dh - 1) * ldx];
+            out[s] = ok ? v : 0.f;
+        }
+    };
+    auto prod = [&](const float (&a)[32], const float (&b)[32]) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            if (s < ns) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        return acc;
+    };
+    auto widx = [&](int rel, bool neg) {   // window index of bucket(rel) (c2p) or of -bucket(-rel) (p2c)
+        const int b = neg ? -tab_s[-rel + T - 1] : tab_s[rel + T - 1];
+        return min(max(b + span, 0), hi) - win_lo;
+    };
+
+    const int i = it * 32 + col;
+    const bool iok = i < T;
+    const int ic = min(i, T - 1);
+    const bool mi = tok_mask[g.col0 + ic] != 0;
+    float* my = scr + wave * kDlScr;
+    float bq[32];
+    load_col(Qg, ld, it * 32, T, bq);
+    f32x16 cacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[dt][r] = 0.f;
+    float m = -FLT_MAX, l = 0.f;
+    const int ntiles = (T + 31) >> 5;
+    for (int jt = wave; jt < ntiles; jt += 4) {
+        const int j0 = jt * 32;
+        float ak[32], op[32];
+        load_col(Kg, ld, j0, T, ak);
+        f32x16 a = prod(ak, bq);
+        // the V tile of these keys: requested now (lanes along the keys), parked in the scratch after the gathers
+        float vreg[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int dd = 2 * q + kh;   // (idx = lane + 64 q: dd = idx >> 5, key = idx & 31 = col)
+            vreg[q] = (dd < dh && j0 + col < T) ? Vg[(int64_t)min(dd, dh - 1) * ld + min(j0 + col, T - 1)] : 0.f;
+        }
+        const int rlo = max(it * 32 - min(j0 + 31, T - 1), -(T - 1));   // i - j over this tile pair starts here; the bucket index is monotone in it
+        const int rhi = min(it * 32 + 31, T - 1) - j0;
+        const int wb1 = widx(rlo, false), wb2 = widx(rlo, true);
+        // beyond the exact range of the bucket function (|i - j| > buckets / 2) a tile reaches fewer than 32 bucket indices: one 32-index
+        // piece instead of two (wave-uniform; the values gathered are the same products)
+        const bool one1 = widx(rhi, false) - wb1 < 32, one2 = widx(rhi, true) - wb2 < 32;
+        // c2p^T piece: [w - wb1][i] = sum_d posk[d][w] q[d][i]
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt) {
+            if (wt == 1 && one1) continue;
+            load_col(Pk, ldp, wb1 + wt * 32, wlen, op);
+            const f32x16 c = prod(op, bq);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[(wt * 32 + acc_row(r, kh)) * 33 + col] = c[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jc = min(j0 + acc_row(r, kh), T - 1);
+            const int d1 = min(max(widx(ic - jc, false) - wb1, 0), 63);
+            a[r] = a[r] * inv_scale + my[d1 * 33 + col] * inv_scale;
+        }
+        // p2c piece: [j][w - wb2] = sum_d k[d][j] posq[d][w]
+#pragma unroll
+        for (int wt = 0; wt < 2; ++wt) {
+            if (wt == 1 && one2) continue;
+            load_col(Pq, ldp, wb2 + wt * 32, wlen, op);
+            const f32x16 c = prod(ak, op);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[acc_row(r, kh) * 65 + wt * 32 + col] = c[r];
+        }
+        float mt = -FLT_MAX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jr = acc_row(r, kh), j = j0 + jr;
+            const int jc = min(j, T - 1);
+            const int d2 = min(max(widx(ic - jc, true) - wb2, 0), 63);
+            float v = a[r] + my[jr * 65 + d2] * inv_scale;
+            if (!(mi && tok_mask[g.col0 + jc])) v = -FLT_MAX;
+            a[r] = v;
+            if (j < T) mt = fmaxf(mt, v);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = j0 + acc_row(r, kh) < T ? expf(a[r] - mn) : 0.f;
+            a[r] = e;
+            ps += e;
+        }
+        {
+            const float other = __shfl_xor(ps, 32);
+            ps = kh ? other + ps : ps + other;   // (rows of half 0) + (rows of half 1) in both halves
+        }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+        // V tile -> scratch [dd][key] (the gathers above are done: LDS operations of one wave execute in order)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) my[(2 * q + kh) * 33 + col] = vreg[q];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            if (dt * 32 >= dh) continue;
+            const float* vrow = my + (dt * 32 + col) * 33;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[acc_row(s, kh)], a[s], cacc[dt], 0, 0, 0);
+        }
+    }
+    // ---- merge the four waves' (max, sum, ctx) in wave order ---------------------------------------------------------------------------------
+    if (kh == 0) {
+        cm[wave][col] = m;
+        cl[wave][col] = l;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[(dt * 16 + r) * 64 + lane] = cacc[dt][r];
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(cm[0][col], cm[1][col]), fmaxf(cm[2][col], cm[3][col]));
+    float f[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) f[w] = expf(cm[w][col] - mx);
+    const float sum = (cl[0][col] * f[0] + cl[1][col] * f[1]) + (cl[2][col] * f[2] + cl[3][col] * f[3]);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float* Cg = ctx + hoff * ldc + g.col0;
+    const int dt = wave >> 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 8 * (wave & 1) + q;
+        const int e = (dt * 16 + r) * 64 + lane;
+        const float v = (scr[e] * f[0] + scr[kDlScr + e] * f[1]) + (scr[2 * kDlScr + e] * f[2] + scr[3 * kDlScr + e] * f[3]);
+        const int d2 = dt * 32 + acc_row(r, kh);
+        if (d2 < dh && iok) Cg[(int64_t)d2 * ldc + i] = v * inv;
+    }
+}
 }  // namespace
+
+bool deberta_attention_long_fits(int T, int dh) { return T > kDbT && T <= 8192 && dh <= 64 && (dh & 1) == 0; }
+
+void deberta_attention_long(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, int ld, const float* V,
+                            const float* posk, const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span,
+                            float inv_scale, const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s) {
+    if (ngroups <= 0) return;
+    const size_t lds = sizeof(float) * (4 * kDlScr + 8 * 32) + sizeof(int) * (size_t)(2 * maxT);
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(k_deberta_attn_long), lds_allowed);
+    hipLaunchKernelGGL(k_deberta_attn_long, dim3((maxT + 31) / 32, ngroups), dim3(256), lds, s, groups, Q, K, ld, V, posk, posq, ldp, win_lo, wlen,
+                       tab, tab_center, span, inv_scale, tok_mask, dh, ctx, ldc);
+    HIP_CHECK(hipGetLastError());
+}
 
 // 65 .. 128 tokens: the tiled variant (any window length: pieces are cut per score tile)
 bool deberta_attention128_fits(int T, int dh) { return T > kDaT && T <= kDbT && dh <= 64 && (dh & 1) == 0; }

@@ -238,9 +238,11 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     arena_.upload(d_tab, tab.data(), sizeof(int) * tab.size(), stream_);
 
     // attention problem descriptors.  Utterances of <= 64 tokens (the usual sentence) take the fused kernel of attn_deberta.hip, 65 .. 128
-    // tokens its tiled variant (the reference's TensorRT profile allows 100 tokens: model.rs:15), longer ones the grouped-GEMM + softmax
-    // path; a batch may hold all three.  SBV2_BERT_ATTN=unfused sends everything down the second path.
+    // tokens its tiled variant (the reference's TensorRT profile allows 100 tokens: model.rs:15), longer ones its key-tile loop (long-form
+    // text); a batch may hold all three.  SBV2_BERT_ATTN=unfused sends everything down the grouped-GEMM + softmax path (five launches per
+    // layer; also what a head dimension the fused kernels do not cover falls back to), SBV2_BERT_ATTN=nolong only the > 128-token ones.
     static const bool want_fused = !(getenv("SBV2_BERT_ATTN") && std::string(getenv("SBV2_BERT_ATTN")) == "unfused");
+    static const bool want_long = !(getenv("SBV2_BERT_ATTN") && std::string(getenv("SBV2_BERT_ATTN")) == "nolong");
     // bucket window reachable by a short utterance (|i - j| <= 63)
     int win_lo_s = 0, wlen_s = 1;
     {
@@ -282,16 +284,18 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     }
     Plane E0{};   // the embedding output is ConvLayer's input (modeling_deberta_v2.py:664: self.conv(hidden_states, output_states, input_mask))
     if (cfg_.conv_k > 0) E0 = arena_.plane(H, N);
-    std::vector<AttnGroup> ag_s, ag_m, ag_l;
+    std::vector<AttnGroup> ag_s, ag_m, ag_f, ag_l;   // short / mid / long fused, grouped-GEMM path
     std::vector<GemmGroup> g_st, g_c2p, g_p2c, g_pv;
     int64_t s_off = 0, c_off = 0, p_off = 0;
-    int maxTL = 0;
+    int maxTL = 0, maxTF = 0;
     const int ldp = layers_[0].pos_k.ld;
     for (int u = 0; u < n; ++u) {
         const int T = L[u];
         const bool is_short = want_fused && deberta_attention_fits(T, wlen_s, d);
         const bool is_mid = want_fused && !is_short && deberta_attention128_fits(T, d);
-        if (!is_short && !is_mid) maxTL = std::max(maxTL, T);
+        const bool is_long = want_fused && want_long && !is_short && !is_mid && deberta_attention_long_fits(T, d);
+        if (is_long) maxTF = std::max(maxTF, T);
+        else if (!is_short && !is_mid) maxTL = std::max(maxTL, T);
         for (int h = 0; h < nh; ++h) {
             AttnGroup a;
             a.qk_off = (int64_t)h * d * X.ld + lay.start[u];
@@ -310,6 +314,10 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
                 ag_m.push_back(a);
                 continue;
             }
+            if (is_long) {
+                ag_f.push_back(a);
+                continue;
+            }
             ag_l.push_back(a);
             g_st.push_back(GemmGroup{a.qk_off, a.qk_off, s_off, 0, T, T, d, T});                                   // S^T = K^T Q
             g_c2p.push_back(GemmGroup{(int64_t)h * d * ldp + win_lo, a.qk_off, c_off, 0, wlen, T, d, T});          // posK^T Q
@@ -320,9 +328,13 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
             p_off += (int64_t)T * win_ld;
         }
     }
-    const int ngS = (int)ag_s.size(), ngM = (int)ag_m.size(), ngL = (int)ag_l.size();
+    const int ngS = (int)ag_s.size(), ngM = (int)ag_m.size(), ngF = (int)ag_f.size(), ngL = (int)ag_l.size();
     float *S = nullptr, *C2P = nullptr, *P2C = nullptr, *VT = nullptr;
-    AttnGroup *d_agS = nullptr, *d_agM = nullptr, *d_agL = nullptr;
+    AttnGroup *d_agS = nullptr, *d_agM = nullptr, *d_agF = nullptr, *d_agL = nullptr;
+    if (ngF) {
+        d_agF = arena_.array<AttnGroup>(ngF);
+        arena_.upload(d_agF, ag_f.data(), sizeof(AttnGroup) * ngF, stream_);
+    }
     if (ngM) {
         d_agM = arena_.array<AttnGroup>(ngM);
         arena_.upload(d_agM, ag_m.data(), sizeof(AttnGroup) * ngM, stream_);
@@ -400,6 +412,9 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         if (ngM)
             deberta_attention128(d_agM, ngM, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo_m, wlen_m, d_tab, maxT - 1, span, inv_scale,
                                  lay.d_mask, d, ctx.p, ctx.ld, stream_);
+        if (ngF)
+            deberta_attention_long(d_agF, ngF, maxTF, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo, wlen, d_tab, maxT - 1, span,
+                                   inv_scale, lay.d_mask, d, ctx.p, ctx.ld, stream_);
         if (ngL) {
             linear_tokmajor(Ly.v, X, VT, H, stream_);   // the grouped V P^T product wants V token-major
             grouped(Kp.p, Kp.ld, Q.p, Q.ld, S, lds, d_g, maxTL, maxTL, inv_scale, fl_tt);

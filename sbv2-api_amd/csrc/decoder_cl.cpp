@@ -247,7 +247,8 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         while ((1 << ushift) < U) ++ushift;
         // (large launches only: a single utterance or a streaming window has too few tiles to pay for the extra split / halo launches; the two
         // paths give the same bits, so the choice is free)
-        bool clx = clx_enabled() && dec_mode_ == 1 && C >= 128 && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
+        static const int clx_min_c = getenv("SBV2_CLX_MINC") ? atoi(getenv("SBV2_CLX_MINC")) : 128;   // A/B knob
+        bool clx = clx_enabled() && dec_mode_ == 1 && C >= clx_min_c && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
         for (int j = 0; j < nk && clx; ++j) {
             const ClBranch& rb = st.branches[j];
             if (!(rb.k == 3 || rb.k == 7 || rb.k == 11)) clx = false;

@@ -29,6 +29,10 @@ void dds_dw_ln_gelu(Plane in, Plane out, const float* w, const float* b, int dil
 // fused disentangled attention for short sequences (attn_deberta.hip); deberta_attention_fits says whether a batch qualifies
 bool deberta_attention_fits(int maxT, int wlen, int dh);
 // the tiled variant for 65 .. 128 tokens (same arguments; the window is the one reachable by the longest sequence of the batch)
+bool deberta_attention_long_fits(int T, int dh);   // > 128 tokens: key-tile loop with an online softmax, one workgroup per 32-query tile
+void deberta_attention_long(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, int ld, const float* V,
+                            const float* posk, const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span,
+                            float inv_scale, const unsigned char* tok_mask, int dh, float* ctx, int ldc, hipStream_t s);
 bool deberta_attention128_fits(int T, int dh);
 void deberta_attention128(const AttnGroup* groups, int ngroups, const float* Q, const float* K, int ld, const float* V, const float* posk,
                           const float* posq, int ldp, int win_lo, int wlen, const int* tab, int tab_center, int span, float inv_scale,

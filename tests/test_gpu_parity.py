@@ -224,7 +224,7 @@ def test_deberta_conv_layer_batch_and_guard():
 def test_deberta_batch_equals_single(bert_tiny):
     cfg, W = weights("bert", "tiny", 3)
     rng = np.random.default_rng(0)
-    # 72 / 100 / 128 tokens take the tiled fused kernel (65 .. 128), 130 and 200 the grouped-GEMM path: the batch mixes all three
+    # 72 / 100 / 128 tokens take the tiled fused kernel (65 .. 128), 130 and 200 its key-tile loop (> 128): the batch mixes all three
     seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (1, 7, 30, 70, 18, 3, 62, 128, 98, 126, 63, 198)]
     batch = model.predict_batch(bert_tiny, seqs)
     for ids, got in zip(seqs, batch):
@@ -242,10 +242,34 @@ def test_deberta_full_shape_mid_lengths_vs_oracle():
     rng = np.random.default_rng(7)
     seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (98, 20, 126, 63, 150)]
     batch = model.predict_batch(s, seqs)
-    for k in (0, 2, 4):     # 100 and 128 tokens: the tiled fused attention; 152 tokens: the grouped-GEMM + softmax path at the full shape
+    for k in (0, 2, 4):     # 100 and 128 tokens: the tiled fused attention; 152 tokens: the key-tile loop (attn_deberta.hip, > 128) at the full shape
         ref = O.deberta_forward(W, cfg, seqs[k])
         np.testing.assert_allclose(batch[k], ref, atol=2e-4, rtol=0)
         np.testing.assert_array_equal(model.predict(s, seqs[k], np.ones_like(seqs[k])), batch[k])
+    s.close()
+
+def test_deberta_long_attention_key_tile_loop(bert_tiny):
+    """> 128 tokens (long-form text, BASELINE configs[4]): the fused attention's key-tile loop with an online softmax, against the oracle:
+    lengths that end inside a tile / on a tile edge / with idle waves (fewer than four key tiles per query tile is impossible here, more
+    than four per wave at 515), a masked tail, packing next to short and mid neighbours without changing a bit, and the full shape
+    (16 heads x 64, 256 log buckets: relative distances beyond the exact range of the bucket function) at 300 tokens."""
+    cfg, W = weights("bert", "tiny", 3)
+    rng = np.random.default_rng(21)
+    seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (127, 158, 513, 40, 254, 100)]   # 129, 160, 515, 42, 256, 102
+    batch = model.predict_batch(bert_tiny, seqs)
+    for ids, got in zip(seqs, batch):
+        single = model.predict(bert_tiny, ids, np.ones_like(ids))
+        np.testing.assert_allclose(single, O.deberta_forward(W, cfg, ids), atol=5e-5, rtol=0)
+        np.testing.assert_array_equal(got, single)
+    ids = seqs[2]
+    mask = np.ones_like(ids); mask[-70:] = 0     # two whole key tiles and a part of a third masked
+    got = model.predict(bert_tiny, ids, mask)
+    ref = O.deberta_forward(W, cfg, ids, mask)
+    np.testing.assert_allclose(got[:-70], ref[:-70], atol=5e-5, rtol=0)
+    cfgf, Wf = weights("bert", "full")
+    s = model.load_model(blob("bert", "full"), True)
+    ids = np.concatenate([[1], np.random.default_rng(22).integers(3, cfgf["vocab_size"], 298), [2]])
+    np.testing.assert_allclose(model.predict(s, ids, np.ones_like(ids)), O.deberta_forward(Wf, cfgf, ids), atol=2e-4, rtol=0)
     s.close()
 
 
