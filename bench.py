@@ -226,7 +226,8 @@ def main():
     dtype = {0: "f32", 1: "bf16x3-split (decoder + flow convs: bf16 hi/lo MFMA, f32 accumulate/storage)", 2: "bf16 (decoder convs)",
              3: "f16 (decoder convs: fp16 MFMA operands, f32 accumulate/storage)"}[dmode]
     dtype += {0: " + f32 (DeBERTa, text side)", 2: " + bf16x3 (DeBERTa GEMMs) + f32 (text side)",
-              3: " + bf16x6 (DeBERTa GEMMs: three bf16 parts per operand, f32-grade) + f32 (text side)"}.get(l.sbv2_bert_gemm_parts(bs.handle), "")
+              3: " + bf16x6 (DeBERTa GEMMs: three bf16 parts per operand, f32-grade) + f32 (text side)",
+              4: " + f16x3 (DeBERTa GEMMs, flow 1x1: f16 hi + scaled f16 lo per operand, 22 mantissa bits, f32 accumulate) + f32 (text side)"}.get(l.sbv2_bert_gemm_parts(bs.handle), "")
 
     comm, host, rccl_error = None, None, ""
     if world > 1:
@@ -343,6 +344,7 @@ def main():
                         "respair_cl<C=64>": ("respair_cl_kernel<1, false, 2>",),
                         "gemm_bfs<bf16x3>": ("gemm_bfs_kernel<2,",),
                         "gemm_bfs<bf16x6>": ("gemm_bfs_kernel<3,",),
+                        "gemm_bfs<f16x3>": ("true>(sbv2::BfsKernelParams)",),
                         "gemm_skinny<16x16x4>": ("gemm_skinny",)}.get(dom["kernel"])
                 if want is None and dom["kernel"].startswith("conv_gemm<"):
                     want = ("conv_gemm_kernel<" + dom["kernel"][len("conv_gemm<"):-1].replace(",", ", "),)

@@ -38,7 +38,8 @@ int sbv2_device_count(void);
 int sbv2_bert_create(const uint8_t* model, size_t model_len, int device, sbv2_bert** out);
 void sbv2_bert_destroy(sbv2_bert* h);
 int64_t sbv2_bert_hidden(const sbv2_bert* h); /* 1024 for deberta-v2-large */
-/* arithmetic of the handle's Linear products: 0 = exact f32 MFMA, 2 = bf16x3 (two bf16 parts per operand), 3 = bf16x6 (three parts: f32-grade) */
+/* arithmetic of the handle's Linear products: 0 = exact f32 MFMA, 2 = bf16x3 (two bf16 parts per operand), 3 = bf16x6 (three parts: f32-grade),
+   4 = f16x3 (f16 hi + scaled f16 lo: 22 mantissa bits, three MFMAs per product; the default, SBV2_BERT_GEMM=f32|bf16x3|bf16x6|f16x3) */
 int sbv2_bert_gemm_parts(const sbv2_bert* h);
 
 /* ---- bert::predict(session, token_ids, attention_masks) -> Array2<f32>[S, 1024]  crates/sbv2_core/src/bert.rs:6-24

@@ -659,14 +659,14 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
                         int parts, int act, int split_out, int64_t iters, float* y, float* ms) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
-    SBV2_REQUIRE((parts == 2 || parts == 3) && x && w && y && M >= 1 && N >= 4 && (N & 3) == 0 && (K & 15) == 0, "bad arguments");
+    SBV2_REQUIRE((parts == 2 || parts == 3 || parts == kPartsF16x3) && x && w && y && M >= 1 && N >= 4 && (N & 3) == 0 && (K & 15) == 0, "bad arguments");
     Blob b = one_conv_blob(w, bias, {M, K, 1}, M);
     WeightStore ws(b);
     ws.set_bfs_parts(parts);
     PackedConv pc = ws.conv("c");
     const int ld = round_up((int)N, 64);
     Plane X{nullptr, (int)K, (int)N, ld}, Y{nullptr, (int)M, (int)N, ld}, R{nullptr, (int)M, (int)N, ld};
-    DevBuf dx((size_t)K * ld), dy((size_t)M * ld), dr((size_t)M * ld), dxs((size_t)parts * K * ld / 2 + 16), dys((size_t)3 * M * ld / 2 + 16);
+    DevBuf dx((size_t)K * ld), dy((size_t)M * ld), dr((size_t)M * ld), dxs((size_t)split_nplanes(parts) * K * ld / 2 + 16), dys((size_t)3 * M * ld / 2 + 16);
     X.p = dx.p;
     Y.p = dy.p;
     R.p = dr.p;
@@ -675,7 +675,8 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     if (res) HIP_CHECK(hipMemcpy2D(R.p, sizeof(float) * ld, res, sizeof(float) * N, sizeof(float) * N, M, hipMemcpyHostToDevice));
     SplitPlanes xs;
     xs.p = dxs.p;
-    xs.parts = parts;
+    xs.parts = split_nplanes(parts);
+    xs.f16 = parts == kPartsF16x3;
     xs.C = (int)K;
     xs.L = (int)N;
     xs.ld = ld;
@@ -683,7 +684,8 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     split_planes(X, xs, nullptr);
     SplitPlanes ys;
     ys.p = dys.p;
-    ys.parts = split_out;
+    ys.parts = split_nplanes(split_out);
+    ys.f16 = split_out == kPartsF16x3;
     ys.C = (int)M;
     ys.L = (int)N;
     ys.ld = ld;
@@ -708,12 +710,20 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     }
     HIP_CHECK(hipMemcpy2D(y, sizeof(float) * N, Y.p, sizeof(float) * ld, sizeof(float) * N, M, hipMemcpyDeviceToHost));
     if (split_out) {
-        std::vector<uint16_t> hs((size_t)split_out * M * ld);
+        const int np = ys.parts;
+        std::vector<uint16_t> hs((size_t)np * M * ld);
         HIP_CHECK(hipMemcpy(hs.data(), ys.p, hs.size() * 2, hipMemcpyDeviceToHost));
         for (int64_t m = 0; m < M; ++m)
             for (int64_t n = 0; n < N; ++n) {
                 float acc = 0.f;
-                for (int pp = split_out - 1; pp >= 0; --pp) {
+                if (ys.f16) {
+                    _Float16 hi, lo;
+                    memcpy(&hi, &hs[(size_t)m * ld + n], 2);
+                    memcpy(&lo, &hs[((size_t)M + m) * ld + n], 2);
+                    y[(size_t)m * N + n] = (float)hi + (float)lo * (1.0f / kF16LoScale);
+                    continue;
+                }
+                for (int pp = np - 1; pp >= 0; --pp) {
                     const uint32_t u = (uint32_t)hs[((size_t)pp * M + m) * ld + n] << 16;
                     float f;
                     memcpy(&f, &u, 4);

@@ -13,9 +13,12 @@
 
 namespace sbv2 {
 
-// Default arithmetic of DeBERTa's GEMMs.  bf16x6 is f32-grade (it changes the integer durations no more often than a re-ordered f32
-// sum does: profiles/r03_flip_rate.json) at 6/16 of the f32 MFMA's cost.
-int default_bert_bfs_parts() { return 3; }
+// Default arithmetic of DeBERTa's GEMMs: f16x3 (f16 hi + scaled f16 lo per operand, 22 mantissa bits, three MFMAs per product; common.h).
+// Like bf16x6 (three bf16 parts, six MFMAs) it changes the integer durations no more often than a re-ordered f32 sum does (1 flip in
+// 205 600 symbols each, the f32-vs-f32 control 2: profiles/r03_flip_rate_bert.json) and its products are as close to f64 as numpy's f32
+// (profiles/r03e_gemm_bfs_probe.txt), at half of bf16x6's matrix work.  Its exponent range is f16's (+-65504 saturates; DeBERTa's GEMM
+// inputs are LayerNorm / GELU / attention outputs, and the reference's own fp16 BERT option, model.rs:11-17, has the same range).
+int default_bert_bfs_parts() { return kPartsF16x3; }
 
 // modeling_deberta_v2.py:57-69 (float32 arithmetic like torch)
 std::vector<int> BertModel::bucket_table(int maxS, int buckets, int max_rel) {
@@ -88,7 +91,8 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
         if (v == "f32") bfs_parts_ = 0;
         else if (v == "bf16x3") bfs_parts_ = 2;
         else if (v == "bf16x6") bfs_parts_ = 3;
-        else SBV2_REQUIRE(v.empty(), "SBV2_BERT_GEMM must be f32, bf16x3 or bf16x6");
+        else if (v == "f16x3") bfs_parts_ = kPartsF16x3;
+        else SBV2_REQUIRE(v.empty(), "SBV2_BERT_GEMM must be f32, bf16x3, bf16x6 or f16x3");
     }
     if ((cfg_.hidden & 15) || (cfg_.inter & 15)) bfs_parts_ = 0;   // the split kernel wants 16-deep chunks
     ws_.reset(new WeightStore(blob, gemm_parts));

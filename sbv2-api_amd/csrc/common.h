@@ -246,10 +246,19 @@ void launch_conv_cl_diag(const ConvClParams& p, int abl, unsigned long long* sta
 // six MFMAs, the dropped terms are 2^-24: f32-grade, "bf16x6").  The activation parts are written by the producer of the plane (LayerNorm,
 // the previous product's epilogue, split_planes), so the GEMM loop has no conversion: both tiles go L2 -> LDS by LDS-DMA.
 // ---------------------------------------------------------------------------------------------
-struct SplitPlanes {        // [part][C][ld] bf16, the column axis contiguous; same column indexing as the f32 plane it mirrors
+// A third operand format, "f16x3" (parts code 4): two f16 planes, hi = f16(x) and lo = f16((x - hi) * 2^11) (the residual scaled back into the
+// normal range, so the pair carries 22 mantissa bits whatever x's magnitude), three MFMAs per product: hi*hi into the accumulator,
+// lo*hi + hi*lo into a second one that the epilogue adds with the factor 2^-11.  Dropped term 2^-22 relative; exponent range of f16
+// (values beyond +-65504 saturate: the reference's own fp16 BERT option, model.rs:11-17, has the same range).
+constexpr int kPartsF16x3 = 4;                 // parts CODE (set_bfs_parts, alloc_split, SBV2_BERT_GEMM): 2 = bf16x3, 3 = bf16x6, 4 = f16x3
+constexpr float kF16LoScale = 2048.0f;
+inline int split_nplanes(int code) { return code == kPartsF16x3 ? 2 : code; }
+struct SplitPlanes {        // [part][C][ld] 16-bit, the column axis contiguous; same column indexing as the f32 plane it mirrors
     void* p = nullptr;
-    int parts = 0, C = 0, L = 0, ld = 0;
+    int parts = 0, C = 0, L = 0, ld = 0;   // parts = number of planes
+    int f16 = 0;            // 0: bf16 parts (each the rounding of what the previous ones left), 1: the f16 hi / scaled-lo pair
     int64_t pstride = 0;    // elements from one part to the next
+    int code() const { return f16 ? kPartsF16x3 : parts; }
     SplitPlanes rows(int c0, int n) const {
         SplitPlanes s = *this;
         s.p = static_cast<char*>(p) + (size_t)c0 * ld * 2;
@@ -257,8 +266,10 @@ struct SplitPlanes {        // [part][C][ld] bf16, the column axis contiguous; s
         return s;
     }
 };
-inline SplitPlanes alloc_split(Arena& ar, int parts, int C, int L) {   // same pitch rule as Arena::plane
+inline SplitPlanes alloc_split(Arena& ar, int code, int C, int L) {   // same pitch rule as Arena::plane; code as in set_bfs_parts
     SplitPlanes s;
+    const int parts = split_nplanes(code);
+    s.f16 = code == kPartsF16x3;
     s.parts = parts;
     s.C = C;
     s.L = L;
@@ -270,6 +281,7 @@ inline SplitPlanes alloc_split(Arena& ar, int parts, int C, int L) {   // same p
 struct BfsWeights {         // W as MFMA A fragments: [K / 16][nmt][parts][64 lanes][8] bf16 (lane l: row 32 mt + (l & 31), k = 16 c + 8 (l >> 5) + j)
     void* w = nullptr;
     int nmt = 0, parts = 0, M = 0, K = 0;
+    int f16 = 0;            // as SplitPlanes::f16
 };
 struct GemmBfsParams {
     BfsWeights W;
@@ -288,7 +300,51 @@ struct GemmBfsParams {
 };
 bool gemm_bfs_usable(const GemmBfsParams& p);
 void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream);
-void split_planes(Plane in, SplitPlanes out, hipStream_t stream);   // out parts = bf16 split of `in` (same columns)
+void split_planes(Plane in, SplitPlanes out, hipStream_t stream);   // out parts = split of `in` (same columns)
+#if defined(__HIPCC__)
+// device side: the parts of four consecutive values of a row -> the planes of sp at element offset off (8-byte stores)
+__device__ __forceinline__ void split_store4(const SplitPlanes& sp, int64_t off, const float (&v)[4]) {
+    typedef __bf16 sp_bf16x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
+    if (sp.f16) {
+        sp_f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
+            h[e] = (_Float16)c;
+            l[e] = (_Float16)((c - (float)h[e]) * kF16LoScale);
+        }
+        *reinterpret_cast<sp_f16x4*>(static_cast<_Float16*>(sp.p) + off) = h;
+        *reinterpret_cast<sp_f16x4*>(static_cast<_Float16*>(sp.p) + sp.pstride + off) = l;
+    } else {
+        float res[4] = {v[0], v[1], v[2], v[3]};
+        for (int pp = 0; pp < sp.parts; ++pp) {
+            sp_bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (__bf16)res[e];
+                res[e] -= (float)h[e];
+            }
+            *reinterpret_cast<sp_bf16x4*>(static_cast<__bf16*>(sp.p) + (int64_t)pp * sp.pstride + off) = h;
+        }
+    }
+}
+__device__ __forceinline__ void split_store1(const SplitPlanes& sp, int64_t off, float v) {
+    if (sp.f16) {
+        const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)c;
+        static_cast<_Float16*>(sp.p)[off] = h;
+        static_cast<_Float16*>(sp.p)[sp.pstride + off] = (_Float16)((c - (float)h) * kF16LoScale);
+    } else {
+        float r = v;
+        for (int pp = 0; pp < sp.parts; ++pp) {
+            const __bf16 h = (__bf16)r;
+            static_cast<__bf16*>(sp.p)[(int64_t)pp * sp.pstride + off] = h;
+            r -= (float)h;
+        }
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // conv_clx.hip: the ResBlock convolutions of the wide decoder stages on pre-split, pre-activated operands (LDS-DMA only, no staging registers)

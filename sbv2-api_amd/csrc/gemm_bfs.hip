@@ -5,6 +5,8 @@
 //   PARTS = 2 ("bf16x3"): lo*hi + hi*lo + hi*hi, three MFMAs per product, dropped term 2^-16 relative.
 //   PARTS = 3 ("bf16x6"): lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi, six MFMAs; the dropped terms (mid*lo, lo*mid, lo*lo) are
 //                         2^-24 relative, i.e. the rounding of an f32 product: f32-grade results at 6/16 of the f32 MFMA's cost.
+//   F16 ("f16x3", PARTS = 2): f16 hi + f16 lo' with lo' = (x - hi) 2^11 (common.h): hi*hi into the accumulator, lo'*hi + hi*lo' into a second
+//                         accumulator added with 2^-11 by the epilogue; three v_mfma_f32_32x32x16_f16, dropped term 2^-22 relative.
 //
 // What the reference does here: nothing -- these are the MatMul / Gemm / 1x1 Conv nodes ONNX Runtime executes inside `session.run`
 // (crates/sbv2_core/src/bert.rs:11, model.rs:91); the reference itself offers reduced precision for them (TensorRT fp16 for BERT,
@@ -30,6 +32,7 @@ namespace sbv2 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -80,8 +83,9 @@ __device__ __forceinline__ int bfs_swz(int k) {
     return 0;
 }
 
-template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT>
-__global__ __launch_bounds__(256) void gemm_bfs_kernel(const BfsKernelParams kp) {
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM * TN >= 4 ? 2 : 1))) void gemm_bfs_kernel(const BfsKernelParams kp) {
+    static_assert(!F16 || PARTS == 2, "f16x3 has two planes");
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN, RB = NT * 2;
     constexpr int NMT = MT / 32;
@@ -181,12 +185,16 @@ __global__ __launch_bounds__(256) void gemm_bfs_kernel(const BfsKernelParams kp)
     };
 
     f32x16 acc[TM][TN];
+    f32x16 accx[F16 ? TM : 1][F16 ? TN : 1];   // f16x3: the cross terms (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (F16) accx[i][j][r] = 0.f;
+            }
     // MFMA n of a chunk: term-major (every accumulator takes term t before any takes t + 1: TM * TN independent MFMAs between two that
     // share an accumulator); the terms in ascending magnitude
     constexpr int NT_ = PARTS == 2 ? 3 : 6, NM = NT_ * TM * TN;
@@ -195,7 +203,13 @@ __global__ __launch_bounds__(256) void gemm_bfs_kernel(const BfsKernelParams kp)
         constexpr int t = n / (TM * TN), i = (n % (TM * TN)) / TN, j = n % TN;
         constexpr int pa = PARTS == 2 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 2 || t == 3 ? 1 : 0));
         constexpr int pb = PARTS == 2 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4 ? 1 : 0));
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], frag_b(f, j, pb), acc[i][j], 0, 0, 0);
+        if constexpr (F16) {
+            const f16x8 a = __builtin_bit_cast(f16x8, f.a[i][pa]), b = __builtin_bit_cast(f16x8, frag_b(f, j, pb));
+            if constexpr (t == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+            else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, accx[i][j], 0, 0, 0);
+        } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], frag_b(f, j, pb), acc[i][j], 0, 0, 0);
+        }
     };
 
     // ---- ring of NSLOT slots of KSUB chunks.  Chunk c lives at LDS offset (c / KSUB % NSLOT) * SLOT + (c % KSUB) * CH.
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(256) void gemm_bfs_kernel(const BfsKernelParams kp)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lcol] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r)
+                tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lcol] = F16 ? acc[i][j][r] + accx[i][j][r] * (1.0f / kF16LoScale) : acc[i][j][r];
             const int n = n0 + (wn * TN + j) * 32 + c4;
             const int mb = m0 + (wm * TM + i) * 32 + lrow;
             f32x4v av[4], rr[4];
@@ -343,18 +358,7 @@ __global__ __launch_bounds__(256) void gemm_bfs_kernel(const BfsKernelParams kp)
                     v[e] = keep[e] ? x : 0.f;
                 }
                 if (p.Y) *reinterpret_cast<f32x4v*>(p.Y + (int64_t)m * p.ldy + n) = f32x4v{v[0], v[1], v[2], v[3]};
-                if (p.Ys.parts) {
-                    float res[4] = {v[0], v[1], v[2], v[3]};
-                    for (int pp = 0; pp < p.Ys.parts; ++pp) {
-                        bf16x4 h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            h[e] = (__bf16)res[e];
-                            res[e] -= (float)h[e];
-                        }
-                        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.Ys.p) + (int64_t)pp * p.Ys.pstride + (int64_t)m * p.Ys.ld + n) = h;
-                    }
-                }
+                if (p.Ys.parts) split_store4(p.Ys, (int64_t)m * p.Ys.ld + n, v);
             }
         }
 }
@@ -367,21 +371,13 @@ __global__ __launch_bounds__(256) void k_split_planes(Plane in, SplitPlanes out)
         const int c = (int)(q / lq), j = (int)(q - (int64_t)c * lq) * 4;
         if (j >= out.ld) continue;
         const f32x4v v = *reinterpret_cast<const f32x4v*>(in.p + (int64_t)c * in.ld + j);
-        float res[4] = {v[0], v[1], v[2], v[3]};
-        for (int pp = 0; pp < out.parts; ++pp) {
-            bf16x4 h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[e] = (__bf16)res[e];
-                res[e] -= (float)h[e];
-            }
-            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out.p) + (int64_t)pp * out.pstride + (int64_t)c * out.ld + j) = h;
-        }
+        const float res[4] = {v[0], v[1], v[2], v[3]};
+        split_store4(out, (int64_t)c * out.ld + j, res);
     }
 }
 
 void split_planes(Plane in, SplitPlanes out, hipStream_t stream) {
-    SBV2_REQUIRE(in.C == out.C && out.parts >= 1 && out.parts <= 3 && (in.ld & 3) == 0 && (out.ld & 3) == 0 && out.ld <= in.ld + 63,
+    SBV2_REQUIRE(in.C == out.C && out.parts >= 1 && out.parts <= 3 && (!out.f16 || out.parts == 2) && (in.ld & 3) == 0 && (out.ld & 3) == 0 && out.ld <= in.ld + 63,
                  "split_planes: shape mismatch");
     const int64_t nq = (int64_t)in.C * (in.ld >> 2);
     const int grid = (int)std::min<int64_t>((nq + 255) / 256, 2048);
@@ -391,11 +387,12 @@ void split_planes(Plane in, SplitPlanes out, hipStream_t stream) {
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
 bool gemm_bfs_usable(const GemmBfsParams& p) {
-    return p.W.w && (p.W.parts == 2 || p.W.parts == 3) && p.X.p && p.X.parts == p.W.parts && (p.K & 15) == 0 && p.K >= 16 && (p.N & 3) == 0 &&
+    return p.W.w && (p.W.parts == 2 || p.W.parts == 3) && p.X.p && p.X.parts == p.W.parts && p.X.f16 == p.W.f16 && (!p.W.f16 || p.W.parts == 2) &&
+           (p.K & 15) == 0 && p.K >= 16 && (p.N & 3) == 0 &&
            (p.X.ld & 7) == 0 && (!p.Y || (p.ldy & 3) == 0) && (!p.R || (p.ldr & 3) == 0) && (!p.Ys.parts || (p.Ys.ld & 3) == 0) && p.N >= 4;
 }
 
-template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT>
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false>
 static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream) {
     constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN;
     constexpr int SLOT = KSUB * ((MT / 32) * PARTS * 1024 + PARTS * 16 * NT * 2);
@@ -404,7 +401,7 @@ static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream) {
     kp.gn = (p.N + NT - 1) / NT;
     kp.total = kp.gm * kp.gn;
     const size_t lds = std::max<size_t>((size_t)NSLOT * SLOT, 4 * 32 * 36 * sizeof(float));
-    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT>;
+    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT, F16>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -418,7 +415,7 @@ static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(PARTS == 2 ? 24 : 25, 2.0 * p.M * (double)p.N * p.K, e0, e1);
+        conv_prof_add(F16 ? 27 : (PARTS == 2 ? 24 : 25), 2.0 * p.M * (double)p.N * p.K, e0, e1);
     }
 }
 
@@ -443,7 +440,11 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
     const bool lone = blocks(128, 128) <= 256;
     const bool k32 = (p.K & 31) == 0;
     // configuration id (SBV2_BFS_SLOTS, experiments): tens = chunks per slot, units = slots
-    if (p.W.parts == 2) {
+    if (p.W.f16) {   // the ring shapes of bf16x3 (same bytes per chunk), two accumulator sets
+        if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
+        else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4, true>(kp, stream);
+        else launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5, true>(kp, stream);
+    } else if (p.W.parts == 2) {
         if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8>(kp, stream);
         else if (slots == 15) launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5>(kp, stream);
         else if (slots == 19) launch_bfs_cfg<2, 2, 2, 2, 2, 1, 9>(kp, stream);

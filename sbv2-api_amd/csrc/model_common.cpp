@@ -59,12 +59,14 @@ static inline float bfs_bf16_f32(uint16_t h) {
     return f;
 }
 
-BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts) {
-    SBV2_REQUIRE((parts == 2 || parts == 3) && (K & 15) == 0 && M >= 1, "pack_bfs: bad shape");
+BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int code) {
+    SBV2_REQUIRE((code == 2 || code == 3 || code == kPartsF16x3) && (K & 15) == 0 && M >= 1, "pack_bfs: bad shape");
     BfsWeights b;
     b.M = M;
     b.K = K;
+    const int parts = split_nplanes(code);
     b.parts = parts;
+    b.f16 = code == kPartsF16x3;
     b.nmt = round_up((M + 31) / 32, 4);   // whole 128-row tiles: a tile's fragment blocks of a chunk are one contiguous DMA source
     const int nchunks = K / 16;
     std::vector<uint16_t> h((size_t)nchunks * b.nmt * parts * 512, 0);
@@ -76,6 +78,13 @@ BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts) {
                 if (m >= M) continue;
                 for (int j = 0; j < 8; ++j) {
                     float r = w[(size_t)m * K + ch * 16 + 8 * (l >> 5) + j];
+                    if (b.f16) {   // hi = f16(x), lo = f16((x - hi) 2^11): common.h
+                        const float c = std::min(std::max(r, -65504.f), 65504.f);
+                        const _Float16 hi = (_Float16)c, lo = (_Float16)((c - (float)hi) * kF16LoScale);
+                        memcpy(&blk[l * 8 + j], &hi, 2);
+                        memcpy(&blk[512 + l * 8 + j], &lo, 2);
+                        continue;
+                    }
                     for (int p = 0; p < parts; ++p) {
                         const uint16_t q = bfs_bf16_rne(r);
                         blk[p * 512 + l * 8 + j] = q;
@@ -325,7 +334,7 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 // 1x1 product on the bf16 matrix cores with pre-split operands (gemm_bfs.hip); y and / or ys receive the result.
 void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
               hipStream_t s, int act, const Plane* res, float alpha, float beta) {
-    SBV2_REQUIRE(w.bfs.parts && w.k == 1 && xs.C == w.cin && xs.parts == w.bfs.parts, "conv_bfs: operands were not prepared for the split-bf16 kernel");
+    SBV2_REQUIRE(w.bfs.parts && w.k == 1 && xs.C == w.cin && xs.parts == w.bfs.parts && xs.f16 == w.bfs.f16, "conv_bfs: operands were not prepared for the split-bf16 kernel");
     GemmBfsParams p;
     p.W = w.bfs;
     p.X = xs;

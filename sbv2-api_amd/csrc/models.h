@@ -122,7 +122,7 @@ class BertModel {
     BertModel* clone() const;
     int device() const { return device_; }
     const BertConfig& cfg() const { return cfg_; }
-    int gemm_parts() const { return bfs_parts_; }   // 0 = exact-f32 products, 2 = bf16x3, 3 = bf16x6
+    int gemm_parts() const { return bfs_parts_; }   // 0 = exact-f32 products, 2 = bf16x3, 3 = bf16x6, 4 = f16x3
     // ids/mask concatenated over utterances; result stays on the device (out_, layout_)
     void forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens);
     void copy_out(float* host);  // [sum S][hidden], utterances concatenated
@@ -140,7 +140,7 @@ class BertModel {
     };
     int device_;
     BertConfig cfg_;
-    int bfs_parts_ = 0;   // 0 = exact-f32 products, 2 = bf16x3, 3 = bf16x6 (gemm_bfs.hip)
+    int bfs_parts_ = 0;   // parts code: 0 = exact-f32 products, 2 = bf16x3, 3 = bf16x6, 4 = f16x3 (gemm_bfs.hip)
     std::shared_ptr<WeightStore> ws_;
     float *emb_, *emb_g_, *emb_b_;
     PackedConv conv_;                       // encoder.conv.conv (k = conv_k)

@@ -132,15 +132,7 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     // the result, and (sp.parts != 0) its bf16 parts for the split-bf16 products that read this plane (gemm_bfs.hip)
     auto put = [&](int c, float v) {
         out.p[(size_t)c * out.ld + n] = v;
-        if (sp.parts) {
-            __bf16* q = static_cast<__bf16*>(sp.p) + (size_t)c * sp.ld + n;
-            float r = v;
-            for (int pp = 0; pp < sp.parts; ++pp) {
-                const __bf16 h = (__bf16)r;
-                q[(size_t)pp * sp.pstride] = h;
-                r -= (float)h;
-            }
-        }
+        if (sp.parts) split_store1(sp, (int64_t)c * sp.ld + n, v);
     };
     auto emit = [&](int c, float x) {
         float v = (x - mean) * rstd * gamma[c] + beta[c];

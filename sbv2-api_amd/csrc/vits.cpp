@@ -229,12 +229,16 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     }
     w.set_cl_parts(gemm_parts);   // the flow only shapes the (continuous) latent: split-bf16 for its k = 5 FFN convs
     // ... and for the 1x1 products of its attention layers (q | k | v and the output projection: 48 launches of a batch-32 step) through
-    // gemm_bfs.hip with pre-split operands (bf16x3, the arithmetic of its FFN convs and its attention).  SBV2_FLOW_1X1=f32 keeps them on
+    // gemm_bfs.hip with pre-split operands.  SBV2_FLOW_1X1=f32 keeps them on
     // the exact-f32 kernel; SBV2_GEMM=f32 does as well.
-    int flow_bfs = gemm_parts == 2 && (Hc & 15) == 0 ? 2 : 0;
+    // Operand format: f16x3 (f16 hi + scaled f16 lo: 22 mantissa bits, common.h) costs the same three MFMAs per product as bf16x3 and is
+    // 20x closer to the f32 product on these shapes (tests/bfs_probe.py), so it is the default; SBV2_FLOW_1X1=bf16x3 keeps the two-bf16 split.
+    int flow_bfs = gemm_parts == 2 && (Hc & 15) == 0 ? kPartsF16x3 : 0;
     if (const char* m = getenv("SBV2_FLOW_1X1")) {
-        SBV2_REQUIRE(std::string(m) == "bf16x3" || std::string(m) == "f32" || !*m, "SBV2_FLOW_1X1 must be f32 or bf16x3");
-        if (std::string(m) == "f32") flow_bfs = 0;
+        const std::string v(m);
+        SBV2_REQUIRE(v == "f16x3" || v == "bf16x3" || v == "f32" || v.empty(), "SBV2_FLOW_1X1 must be f32, bf16x3 or f16x3");
+        if (v == "f32") flow_bfs = 0;
+        else if (v == "bf16x3" && flow_bfs) flow_bfs = 2;
     }
     w.set_bfs_parts(flow_bfs);
     for (int i = 0; i < cfg_.flow_n; ++i) {
@@ -378,7 +382,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     const float qscale = 1.0f / std::sqrt((float)dk);
     // 1x1 products on pre-split operands (gemm_bfs.hip; the flow by default): the parts of x are written by the LayerNorm that produces x
     // (by split_planes for the encoder's input and after the speaker vector is added), the parts of the attention output by split_planes
-    const int SP = fused ? e.layers[0].attn.qkv.bfs.parts : 0;
+    const int SP = !fused ? 0 : (e.layers[0].attn.qkv.bfs.f16 ? kPartsF16x3 : e.layers[0].attn.qkv.bfs.parts);   // parts code
     SplitPlanes Xs, Cs;
     if (SP) {
         Xs = alloc_split(ar, SP, H, N);

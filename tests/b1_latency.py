@@ -22,4 +22,4 @@ print(f"B=1 U128: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms pe
 print(json.dumps({"config": "BASELINE configs[1] shape: batch 1, 128 phonemes (T_text 257, 66 BERT tokens, 897 frames = 10.414 s), full model shapes, "
                             "forced durations, un-pipelined, PCM copied to pinned host memory inside the call", "calls": n,
                   "median_ms_per_call": round(float(np.median(ts)) * 1e3, 3), "min_ms_per_call": round(min(ts) * 1e3, 3),
-                  "real_time_factor": round(float(np.median(ts)) / 10.414, 6), "bert_gemm": os.environ.get("SBV2_BERT_GEMM", "default (bf16x6)")}), flush=True)
+                  "real_time_factor": round(float(np.median(ts)) / 10.414, 6), "bert_gemm": os.environ.get("SBV2_BERT_GEMM", "default (f16x3)")}), flush=True)

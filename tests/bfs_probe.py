@@ -25,12 +25,13 @@ for (kk, m, n) in shapes:
     ms32 = C.c_float()
     _lib.check(l.sbv2_debug_time_conv1d(0, kk, m, 1, n, 1, 20, C.byref(ms32)))
     line = f"K={kk:5d} M={m:5d} N={n:6d}: f32 {ms32.value*1e3:7.1f} us ({fl/ms32.value/1e9:6.1f} TF)"
-    for parts in (2, 3):
+    for parts in (2, 3, 4):
         y = np.empty((m, n), np.float32)
         ms = C.c_float()
         _lib.check(l.sbv2_debug_gemm_bfs(0, P(x), P(w), P(b), P(r), m, n, kk, parts, 0, 0, 20, P(y), C.byref(ms)))
         err = float(np.abs(y - ref).max())
-        line += f"   x{3 if parts == 2 else 6} {ms.value*1e3:7.1f} us ({fl/ms.value/1e9:6.1f} TF alg) err {err:.1e}"
+        tag = {2: "x3", 3: "x6", 4: "h3"}[parts]
+        line += f"   {tag} {ms.value*1e3:7.1f} us ({fl/ms.value/1e9:6.1f} TF alg) err {err:.1e}"
     # f32 reference error for scale
     y32 = (w @ x + b[:, None] + r).astype(np.float32)
     line += f"   [numpy f32 err {float(np.abs(y32 - ref).max()):.1e}]"

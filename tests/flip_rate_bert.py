@@ -47,7 +47,7 @@ res = {}
 f32 = features("f32")
 d0, l0 = durations(f32)
 out = {"symbols": int(d0.size), "utterances": N_UTT, "phones_per_utterance": PHONES}
-for mode in ("bf16x6", "bf16x3"):
+for mode in ("bf16x6", "f16x3", "bf16x3"):
     f = features(mode)
     d, l = durations(f)
     out[f"flips_{mode}_vs_f32"] = int((d != d0).sum())

@@ -9,3 +9,5 @@ run SBV2_BERT_GEMM=f32 SBV2_FLOW_1X1=f32
 fi
 SEL=(-k "not (deberta or pipeline or config or smoke or orchestrator or holder or streaming or edge or cpp_host or node or comm)")
 run SBV2_BERT_GEMM=bf16x3 SBV2_FLOW_1X1=bf16x3
+SEL=()
+run SBV2_BERT_GEMM=bf16x6

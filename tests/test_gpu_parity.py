@@ -98,6 +98,9 @@ def test_gemm_bfs_kernel(K, M, N):
     y6 = _gemm_bfs(x, w, b, r, 3)
     assert float(np.abs(y3 - ref).max()) < 1e-4
     assert float(np.abs(y6 - ref).max()) < max(4 * err32, 2e-5)
+    # f16x3 (parts code 4): f16 hi + scaled f16 lo, 22 mantissa bits per operand, dropped term 2^-22: f32-grade within a small factor
+    yh = _gemm_bfs(x, w, b, r, 4)
+    assert float(np.abs(yh - ref).max()) < max(8 * err32, 2e-5)
     # GELU epilogue without bias / residual; the result re-emitted as bf16 parts (what the next product reads) loses nothing at 3 parts
     g = O.gelu(w.astype(np.float64) @ x.astype(np.float64)) if hasattr(O, "gelu") else None
     if g is not None:
@@ -107,6 +110,8 @@ def test_gemm_bfs_kernel(K, M, N):
         assert float(np.abs(y6s - y6g).max()) <= 1e-7 * max(1.0, float(np.abs(y6g).max()))
         y3s = _gemm_bfs(x, w, None, None, 2, act=2, split_out=2)
         assert float(np.abs(y3s - g).max()) < 1e-4
+        yhs = _gemm_bfs(x, w, None, None, 4, act=2, split_out=4)     # ... and as the f16 pair: 2^-22 relative
+        assert float(np.abs(yhs - g).max()) < max(8 * err32, 2e-5)
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,L", [(1024, 1024, 1, 1, 66), (1024, 3072, 1, 1, 130), (4096, 1024, 1, 1, 66), (1024, 4096, 1, 1, 35),
