@@ -405,6 +405,7 @@ struct ResPairParams {
     int mask_div = 1;
     int mask_shift = -1;   // set by launch_respair_cl
     int alias_x2 = 1;      // set by launch_respair_cl: the intermediate window re-uses the conv1 window's LDS
+    int abl = 0;           // diagnostics (SBV2_RESPAIR_ABL, wrong results): 1 = every global read hits the same few cache-hot rows, 2 = no global stores
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
 

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = min(tid + i * T, nxf4 - 1);
-            const int pos = min(max(wstart + (idx >> 2), 0), NB - 1);
+            const int pos = (p.abl & 1) ? ((idx >> 2) & 63) : min(max(wstart + (idx >> 2), 0), NB - 1);
             const float* src = p.X + ((int64_t)pos << lc) + (WM == 1 ? 0 : pair * 32) + (idx & 3) * 4;
             rx[i] = *reinterpret_cast<const f32x4v*>(src);
             rx1[i] = *reinterpret_cast<const f32x4v*>(nchunks > 1 ? src + 16 : src);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
         const int c4r = min(wm * 32 + (lane & 7) * 4, C - 4);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int64_t posr = min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
+            const int64_t posr = (p.abl & 1) ? (it * 8 + (lane >> 3)) : min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
             rres[it] = *reinterpret_cast<const f32x4v*>(p.X + (posr << lc) + c4r);
         }
     }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
         const int c4o = min(c4, C - 4);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int64_t po = min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
+            const int64_t po = (p.abl & 1) ? (it * 8 + (lane >> 3)) : min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
             rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + (po << lc) + c4o);
         }
     }
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
             for (int e = 0; e < 4; ++e) v[e] += rold[it][e];
         }
         if (!mask_s[o + h2]) v = f32x4v{0.f, 0.f, 0.f, 0.f};   // position n0 + o = intermediate row o + h2
+        if (p.abl & 2) continue;
         *dst = v;
     }
     if (!next_tile) break;
@@ -388,6 +389,8 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
     static const int alias = getenv("SBV2_RESPAIR_ALIAS") ? atoi(getenv("SBV2_RESPAIR_ALIAS")) : 1;   // A/B knob: 0 = separate x1 / x2 windows
     p.alias_x2 = alias;
+    static const int abl = getenv("SBV2_RESPAIR_ABL") ? atoi(getenv("SBV2_RESPAIR_ABL")) : 0;
+    p.abl = abl;
     SBV2_REQUIRE(p.C == 16 || p.C == 32 || p.C == 64, "respair: only the 16-, 32- and 64-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
