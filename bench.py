@@ -331,7 +331,8 @@ def main():
                 pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))[-1]
                 # sbv2_prof_end's kernel name -> prefixes of the rocprofv3 kernel names it covers (the CSV is sorted by total time: the
                 # first match is the variant that dominates)
-                want = {"conv_clx<split-bf16>": ("conv_clx_kernel<",),
+                want = {"conv_clx<split-bf16>": ("conv_clx_kernel<11,", "conv_clx_kernel<7,", "conv_clx_kernel<3,"),
+                        "conv_clx_ffn<split-bf16>": ("conv_clx_kernel<5,",),
                         "conv_cl<2,split-bf16>": ("conv_cl_kernel<2, 1, false, false",),
                         "conv_cl<1,split-bf16>": ("conv_cl_kernel<1, 1, false, false",),
                         "conv_cl<2,bf16>": ("conv_cl_kernel<2, 0, false, false",),

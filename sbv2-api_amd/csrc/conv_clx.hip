@@ -532,7 +532,7 @@ static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(26, 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
+        conv_prof_add(p.Ykm || p.ntaps == 5 ? 28 : 26, 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);   // 28: the flow's FFN convs
     }
 }
 

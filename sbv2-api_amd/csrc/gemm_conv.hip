@@ -482,8 +482,8 @@ const char* kCfgNames[] = {"conv_gemm<16,1,4,1,4,16>", "conv_gemm<32,1,2,1,4,16>
                            "respair_cl<C<=32>",        "respair_cl<C=64>",         "resblock_cl",
                            "conv_cl<2,f16>",           "conv_cl<1,f16>",           "conv_cl_km<2,f16>",        "conv_cl_km<1,f16>",
                            "gemm_skinny<16x16x4>",     "gemm_bfs<bf16x3>",         "gemm_bfs<bf16x6>",
-                           "conv_clx<split-bf16>",     "gemm_bfs<f16x3>"};
-constexpr int kNumCfg = 28;
+                           "conv_clx<split-bf16>",     "gemm_bfs<f16x3>",          "conv_clx_ffn<split-bf16>"};
+constexpr int kNumCfg = 29;
 constexpr int cfg_id(int MF, int TM, int TN, int WM) {
     return MF == 16 ? 0 : (WM == 1 ? (TM == 1 ? (TN == 2 ? 1 : 2) : 5) : (TM == 2 ? (TN == 4 ? 3 : 4) : (TN == 2 ? 6 : 7)));
 }
