@@ -1,5 +1,5 @@
 """Builder experiment (GPU box): how many INTEGER durations change when DeBERTa's GEMMs leave the exact-f32 matrix pipe?
-SBV2_BERT_GEMM = f32 (gemm_conv.hip) | bf16x6 (gemm_bfs.hip, three bf16 parts per operand: f32-grade, the library default) | bf16x3 (two parts,
+SBV2_BERT_GEMM = f32 (gemm_conv.hip) | bf16x6 (gemm_bfs.hip, three bf16 parts per operand: f32-grade) | f16x3 (f16 hi + scaled f16 lo: 22 bits, the library default) | bf16x3 (two parts,
 2^-16 per product, opt-in) on the SAME synthetic weights and >= 2e5 symbols (N utterances of 128 phones = 257 symbols, 66 BERT tokens);
 the text encoder + duration predictors stay on their exact-f32 kernels, so every difference comes from the BERT features.  The control is
 the whole exact-f32 GPU path (DeBERTa + text side) against the C / OpenMP oracle, another f32 implementation with another summation order,
