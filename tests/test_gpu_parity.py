@@ -114,6 +114,26 @@ def test_gemm_bfs_kernel(K, M, N):
         assert float(np.abs(yhs - g).max()) < max(8 * err32, 2e-5)
 
 
+def test_gemm_bfs_f16x3_range():
+    """The f16 pair saturates instead of overflowing (common.h split_store*: values beyond +-65504 are clamped before the split, so nothing
+    turns into inf / NaN), keeps 22 bits down to f16's subnormals (the scaled lo part), and bf16x6 carries the full f32 exponent range."""
+    rng = np.random.default_rng(5)
+    K, M, N = 64, 32, 8
+    x = rng.standard_normal((K, N)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / 8).astype(np.float32)
+    x[3, 2] = 3.0e5                      # beyond f16
+    x[5, :] *= 1e-6                      # far below f16's normal range (6e-5)
+    ref = w.astype(np.float64) @ x.astype(np.float64)
+    y6 = _gemm_bfs(x, w, None, None, 3)
+    np.testing.assert_allclose(y6, ref, rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+    yh = _gemm_bfs(x, w, None, None, 4)
+    assert np.isfinite(yh).all()
+    xs = x.copy(); xs[3, 2] = 65504.0    # what the split saturates to
+    np.testing.assert_allclose(yh, w.astype(np.float64) @ xs.astype(np.float64), rtol=0, atol=2e-6 * 65504.0 / 8)
+    cols = [c for c in range(N) if c != 2]      # columns the huge value does not touch: full accuracy, the tiny row included
+    np.testing.assert_allclose(yh[:, cols], ref[:, cols], rtol=0, atol=1e-5)
+
+
 @pytest.mark.parametrize("cin,cout,k,dil,L", [(1024, 1024, 1, 1, 66), (1024, 3072, 1, 1, 130), (4096, 1024, 1, 1, 66), (1024, 4096, 1, 1, 35),
                                               (192, 576, 1, 1, 897), (768, 192, 1, 1, 897), (192, 29, 1, 1, 300), (96, 192, 1, 1, 4), (1024, 192, 1, 1, 130),
                                               (64, 50, 1, 1, 19), (192, 768, 3, 1, 257), (768, 192, 3, 1, 257), (256, 256, 3, 1, 130), (192, 192, 5, 1, 61),
