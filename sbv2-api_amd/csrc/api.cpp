@@ -460,6 +460,7 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
 
 int sbv2_debug_set_skinny_max(int workgroups) { return set_skinny_max(workgroups); }
 int sbv2_debug_set_clx(int on) { return set_clx(on); }
+int sbv2_debug_set_flash_parts(int on) { return set_flash_parts(on); }
 
 int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const float* bias, const float* res, int64_t cin, int64_t cout, int64_t k,
                           int64_t L, int64_t dilation, float pre_slope, float beta, int64_t iters, float* y, float* ys_sum, float* ms) {

@@ -19,6 +19,7 @@
 //
 // Summation order is fixed (no atomics, no scheduling dependence): a column's result does not depend on which other utterances share
 // the batch, as the packed-batch contract requires.
+#include <atomic>
 #include <cfloat>
 
 #include "common.h"
@@ -436,7 +437,284 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
         }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same split-bf16 attention on PRE-SPLIT keys and values (round 3).  k_vits_flash_x3 converts every K / V tile f32 -> bf16 hi / lo while
+// staging it, once per 128-query workgroup: T / 128 times per layer (110 times at 14 001 frames), 24 conversions + 48 two-byte LDS stores per
+// thread and 32-key tile.  Here the parts exist in HBM (written next to the f32 plane by the q | k | v product's epilogue: the same
+// hi = bf16(x), lo = bf16(x - hi)), a staged tile is 64 keys (two 32-key softmax steps per barrier pair: the arithmetic and its order are
+// those of k_vits_flash_x3, bit for bit), moved with 8-byte loads and 8-byte LDS stores, and both tiles keep the k-major shape of the planes:
+//   K image [part][d][64 keys] (row pitch 160 B): the A fragment of S^T = K^T Q (key row = lane & 31, 8 consecutive d) is two transposing
+//           reads (ds_read_b64_tr_b16), conflict free at this pitch (rows 8 banks apart, 4 x 8-byte columns per row);
+//   V image [part][d][64 keys] (row pitch 136 B): the A fragment of ctx += V P (channel row = lane & 31) takes the keys in the order the score
+//           registers hold them, 16 sp + 4 h + {0..3, 8..11}: two 8-byte reads (34-dword pitch: 16 rows on 16 distinct bank pairs).
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef short fa_s16x4 __attribute__((ext_vector_type(4)));
+typedef short fa_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) fa_s16x4 fa_lds_s16x4;
+constexpr int kFpKeys = 64;
+constexpr int kFpKS = 160;   // bytes per d row of the K image
+constexpr int kFpVS = 136;   // ... of the V image
+
+template <int DT>
+__global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_vits_flash_x3p(
+    const AttnGroup* groups, const float* Q, int ld, const __bf16* Kp, const __bf16* Vp, int64_t pstride, int ldp, float* ctx, int ldc, int dk,
+    const float* erk, const float* erv, int w, float qscale) {
+    constexpr int DR = DT * 32;
+    constexpr int KS = DR / 16;            // bf16 k-steps over the (padded) head dimension
+    constexpr int NL = DR / 16;            // 8-byte pieces per thread, part and matrix of one 64-key tile (16 rows per pass)
+    extern __shared__ __attribute__((aligned(16))) char fp_smem[];
+    char* kt = fp_smem;                                   // [2][DR][kFpKS]
+    char* vt = kt + 2 * DR * kFpKS;                       // [2][DR][kFpVS]
+    float* erk_s = reinterpret_cast<float*>(vt + 2 * DR * kFpVS);   // [kFaBand][DR]
+    float* erv_s = erk_s + kFaBand * DR;
+    float (*rk_s)[kFaBand][32] = reinterpret_cast<float (*)[kFaBand][32]>(erv_s + kFaBand * DR);
+    float (*band_s)[kFaBand][32] = rk_s + 4;
+
+    const AttnGroup g = groups[blockIdx.y];
+    const int T = g.T;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < T;
+    const int i = i0 + col;
+    const int ic = min(i, T - 1);
+    const float* Qg = Q + (int64_t)g.head * dk * ld + g.col0;
+    const int64_t poff = (int64_t)g.head * dk * ldp + g.col0;
+    const int nb = 2 * w + 1;
+    const float qs2 = qscale * 1.4426950408889634f;   // base-2 logits, as in k_vits_flash_x3
+
+    for (int idx = tid; idx < kFaBand * DR; idx += kFaThreads) {
+        const int r = idx / DR, d = idx - r * DR;
+        const bool in = r < nb && d < dk;
+        erk_s[idx] = in ? erk[r * dk + d] : 0.f;
+        erv_s[idx] = in ? erv[r * dk + d] : 0.f;
+    }
+    // staging: thread (tx, ty) moves keys 4 tx .. 4 tx + 3 of rows ty + 16 p
+    const int tx = tid & 15, ty = tid >> 4;
+    uint2 kreg[2][NL], vreg[2][NL];
+    auto load_tile = [&](int j0) {
+        const int jq = j0 + 4 * tx;
+        const int jc = min(jq, (T - 1) & ~3);          // an aligned quad that starts inside the utterance (its tail may lie behind T: in the row)
+#pragma unroll
+        for (int p = 0; p < NL; ++p) {
+            const int d = min(ty + 16 * p, dk - 1);
+            const int64_t o = poff + (int64_t)d * ldp + jc;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                kreg[part][p] = *reinterpret_cast<const uint2*>(Kp + part * pstride + o);
+                vreg[part][p] = *reinterpret_cast<const uint2*>(Vp + part * pstride + o);
+            }
+        }
+    };
+    auto store_tile = [&](int j0) {
+        // keys beyond the utterance and rows beyond dk: zero operands (their scores are masked anyway, V must not carry garbage)
+        const int nv = min(max(T - (j0 + 4 * tx), 0), 4);
+        const unsigned m0 = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
+        const unsigned m1 = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);
+#pragma unroll
+        for (int p = 0; p < NL; ++p) {
+            const int d = ty + 16 * p;
+            const bool din = d < dk;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                uint2 kv = kreg[part][p], vv = vreg[part][p];
+                kv.x = din ? kv.x & m0 : 0u; kv.y = din ? kv.y & m1 : 0u;
+                vv.x = din ? vv.x & m0 : 0u; vv.y = din ? vv.y & m1 : 0u;
+                *reinterpret_cast<uint2*>(kt + (part * DR + d) * kFpKS + 8 * tx) = kv;
+                *reinterpret_cast<uint2*>(vt + (part * DR + d) * kFpVS + 8 * tx) = vv;
+            }
+        }
+    };
+    load_tile(0);
+    __syncthreads();   // erk_s / erv_s
+
+    {   // relative-key logits (f32, as in k_vits_flash)
+        float part[kFaBand];
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
+#pragma unroll 2
+        for (int s = 0; s < DR / 2; ++s) {
+            const int d = 2 * s + kh;
+            const float qd = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+#pragma unroll
+            for (int r = 0; r < kFaBand; ++r) part[r] += qd * erk_s[r * DR + d];
+        }
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) {
+            const float other = __shfl_xor(part[r], 32);
+            const float lo = kh ? other : part[r];
+            const float hi = kh ? part[r] : other;
+            rk_s[wave][r][col] = (lo + hi) * qs2;
+            band_s[wave][r][col] = kFaNegBig;
+        }
+    }
+    fa_bf16x8 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = 16 * s + 8 * kh + t;
+            v[t] = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+        }
+        fa_split8(v, qh[s], ql[s]);
+    }
+
+    f32x16 cacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[dt][r] = 0.f;
+    float m = kFaNegBig, l = 0.f;
+
+    // fragment addresses inside a tile image (LDS byte offsets)
+    const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const unsigned kt0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)kt);
+    const unsigned kfrag = kt0 + (8 * (g16 >> 1) + q4) * kFpKS + (16 * (g16 & 1) + 4 * p4) * 2;   // + 16 s rows + 64 h2 bytes (+ 4 rows: the upper half)
+    const char* vfrag = vt + col * kFpVS + 8 * kh;                                              // + dt 32 rows + (32 sp + 64 h2) bytes (+ 16: keys + 8)
+    auto k_frag = [&](int part, int s, int h2) {
+        const unsigned a = kfrag + (part * DR + 16 * s) * kFpKS + 64 * h2;
+        const fa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_s16x4*)(uintptr_t)a);
+        const fa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fa_lds_s16x4*)(uintptr_t)(a + 4 * kFpKS));
+        const fa_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(fa_bf16x8, v);
+    };
+    auto v_frag = [&](int part, int dt, int sp, int h2) {
+        const char* a = vfrag + (part * DR + dt * 32) * kFpVS + 32 * sp + 64 * h2;
+        const uint2 x = *reinterpret_cast<const uint2*>(a), y = *reinterpret_cast<const uint2*>(a + 16);
+        const uint4 v = {x.x, x.y, y.x, y.y};
+        return __builtin_bit_cast(fa_bf16x8, v);
+    };
+
+    const int ntiles = (T + kFpKeys - 1) / kFpKeys;
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int jbase = jt * kFpKeys;
+        store_tile(jbase);
+        __syncthreads();
+        if (jt + 1 < ntiles) load_tile(jbase + kFpKeys);
+        if (active) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int j0 = jbase + 32 * h2;
+                if (j0 >= T) break;   // (wave-uniform: the 32-key step k_vits_flash_x3 would not have run either)
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const fa_bf16x8 ah = k_frag(0, s, h2), al = k_frag(1, s, h2);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sacc, 0, 0, 0);
+                }
+                const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
+                float mt = kFaNegBig;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    float sv = sacc[r] * qs2;
+                    if (diag) {
+                        const int rr = j - i + w;
+                        if (rr >= 0 && rr < nb && j < T) {
+                            sv += rk_s[wave][rr][col];
+                            band_s[wave][rr][col] = sv;
+                        }
+                    }
+                    sv = j < T ? sv : kFaNegBig;
+                    sacc[r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                const float mn = fmaxf(m, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[r] - mn);
+                    sacc[r] = e;
+                    ps += e;
+                }
+                {
+                    const float other = __shfl_xor(ps, 32);
+                    const float lo = kh ? other : ps;
+                    const float hi = kh ? ps : other;
+                    l = l * alpha + (lo + hi);
+                }
+                m = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    float pv8[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) pv8[t] = sacc[8 * sp + t];
+                    fa_bf16x8 ph, pl;
+                    fa_split8(pv8, ph, pl);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const fa_bf16x8 vh = v_frag(0, dt, sp, h2), vl = v_frag(1, dt, sp, h2);
+                        cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, cacc[dt], 0, 0, 0);
+                        cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, cacc[dt], 0, 0, 0);
+                        cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, cacc[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+
+    const float inv = 1.0f / l;
+    float pb[kFaBand];
+#pragma unroll
+    for (int r = 0; r < kFaBand; ++r) pb[r] = __builtin_amdgcn_exp2f(band_s[wave][r][col] - m) * inv;
+    float* Cg = ctx + (int64_t)g.head * dk * ldc + g.col0;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = cacc[dt][r] * inv;
+#pragma unroll
+            for (int b = 0; b < kFaBand; ++b) v += pb[b] * erv_s[b * DR + d];
+            if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
+        }
+}
+
+template <int DT>
+void launch_flash_x3p(dim3 grid, const AttnGroup* groups, const float* Q, int ld, const SplitPlanes& kv, int k_row0, int v_row0, float* ctx, int ldc,
+                      int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
+    constexpr int DR = DT * 32;
+    constexpr size_t lds = 2 * DR * (kFpKS + kFpVS) + sizeof(float) * (2 * kFaBand * DR + 2 * 4 * kFaBand * 32);
+    auto kern = k_vits_flash_x3p<DT>;
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
+    const __bf16* base = static_cast<const __bf16*>(kv.p);
+    hipLaunchKernelGGL(kern, grid, dim3(kFaThreads), lds, s, groups, Q, ld, base + (int64_t)k_row0 * kv.ld, base + (int64_t)v_row0 * kv.ld, kv.pstride,
+                       kv.ld, ctx, ldc, dk, erk, erv, window, qscale);
+}
 }  // namespace
+
+// keys / values from bf16 hi / lo planes (rows k_row0 .. + heads dk and v_row0 .. of kv: two bf16 parts, the columns of Q's plane)
+void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
+                                int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
+                                hipStream_t s) {
+    SBV2_REQUIRE(window <= kFaMaxWin, "relative attention window larger than the compiled maximum");
+    SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
+    SBV2_REQUIRE(kv.parts == 2 && !kv.f16 && (kv.ld & 3) == 0, "flash attention: keys / values must be two bf16 parts");
+    if (ngroups <= 0 || maxT <= 0) return;
+    const dim3 grid((maxT + 127) / 128, ngroups);
+    if (dk <= 32) launch_flash_x3p<1>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+    else if (dk <= 64) launch_flash_x3p<2>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+    else launch_flash_x3p<3>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+    HIP_CHECK(hipGetLastError());
+}
 
 void vits_flash_attention(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, const float* V, int ld, float* ctx,
                           int ldc, int dk, const float* erk, const float* erv, int window, float qscale, bool split_bf16, hipStream_t s) {

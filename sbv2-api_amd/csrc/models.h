@@ -107,6 +107,8 @@ void linear_tokmajor(const PackedConv& w, Plane x, float* y, int ldy, hipStream_
 
 // the library-wide default arithmetic of DeBERTa's 1x1 products (bert.cpp documents the choice): bf16 parts per operand, 0 = exact f32
 int default_bert_bfs_parts();
+bool flash_parts_enabled();   // vits.cpp: the flow's attention reads pre-split keys / values
+int set_flash_parts(int on);
 struct BertConfig {
     int vocab, hidden, layers, heads, inter, buckets, max_rel;
     float eps;

@@ -46,6 +46,9 @@ void deberta_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, c
 void vits_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, const float* Q, int ldq, int dk,
                   const float* erk, int window, float qscale, float* pwin, hipStream_t s);
 // fused QK^T + relative-key term + online softmax + PV + relative-value term (attn_flash.hip); Q, K, V, ctx: k-major planes
+void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
+                                int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
+                                hipStream_t s);   // keys / values pre-split into two bf16 parts (rows of kv); same bits as the split variant below
 void vits_flash_attention(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, const float* V, int ld, float* ctx,
                           int ldc, int dk, const float* erk, const float* erv, int window, float qscale, bool split_bf16, hipStream_t s);
 void vits_relv_add(const AttnGroup* groups, int ngroups, int maxT, float* ctx, int ldc, int dk, const float* erv,

@@ -11,9 +11,17 @@
 #include <cstring>
 #include <memory>
 
+#include <atomic>
 #include "models.h"
 
 namespace sbv2 {
+
+// keys / values of the flow's attention as pre-split bf16 planes for long sequences (SBV2_FLASH_PARTS = 1: from SBV2_FLASH_PARTS_MIN_T frames,
+// 2: at every length, 0: never = converted per key tile inside the attention kernel; bit-identical; sbv2_debug_set_flash_parts for the test)
+static std::atomic<int> g_flash_parts{getenv("SBV2_FLASH_PARTS") ? atoi(getenv("SBV2_FLASH_PARTS")) : 1};
+bool flash_parts_enabled() { return g_flash_parts.load(std::memory_order_relaxed) != 0; }
+static int flash_parts_mode() { return g_flash_parts.load(std::memory_order_relaxed); }
+int set_flash_parts(int on) { return g_flash_parts.exchange(on); }
 
 static const int kTextGap = 16;   // >= 9: DDSConv depthwise dilation 3^2 with k=3
 static const int kFrameGap = 4;   // >= 25/8 frames: widest decoder tap offset (k=11, d=5) at the first upsampled rate
@@ -383,12 +391,21 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     // 1x1 products on pre-split operands (gemm_bfs.hip; the flow by default): the parts of x are written by the LayerNorm that produces x
     // (by split_planes for the encoder's input and after the speaker vector is added), the parts of the attention output by split_planes
     const int SP = !fused ? 0 : (e.layers[0].attn.qkv.bfs.f16 ? kPartsF16x3 : e.layers[0].attn.qkv.bfs.parts);   // parts code
-    SplitPlanes Xs, Cs;
+    SplitPlanes Xs, Cs, QKVs;
     if (SP) {
         Xs = alloc_split(ar, SP, H, N);
         Cs = alloc_split(ar, SP, H, N);
         split_planes(x, Xs, stream_);
     }
+    // the split-bf16 attention reads its keys / values as bf16 hi / lo planes written by the q | k | v product's epilogue next to the f32
+    // plane (attn_flash.hip, k_vits_flash_x3p: no conversion per key tile; the same bits as converting while staging)
+    // Measured (one MI355X, same box): at 897 frames x 32 utterances the pre-split kernel is SLOWER (138 against 124 us per launch, + 4 us for the
+    // product's extra parts: step 87.1 against 86.6 ms); at 14 001 frames it wins (first PCM of the 2000-phoneme stream 44.3 -> 41.9 ms, whole
+    // sequence 78.5 -> 76.9 ms): what it saves, one conversion of every key tile per 128-query workgroup, grows with T / 128.  The bits are the
+    // same, so the choice is made by length (SBV2_FLASH_PARTS_MIN_T, default 4096 frames; set_flash_parts(2) = every length, for the test).
+    static const int parts_min_t = getenv("SBV2_FLASH_PARTS_MIN_T") ? atoi(getenv("SBV2_FLASH_PARTS_MIN_T")) : 4096;
+    const bool kv_parts = SP && split_attn && flash_parts_enabled() && (pl.maxT >= parts_min_t || flash_parts_mode() == 2);
+    if (kv_parts) QKVs = alloc_split(ar, 2, 3 * H, N);
     // Large batches: the FFN pair on conv_clx.hip (pre-split chunk-major operands by LDS-DMA instead of conv_cl's transposing register staging):
     // x is split once per layer from its k-major plane (split_cl_km), conv_1's epilogue writes relu(.) as conv_2's operand parts, conv_2 writes
     // the k-major result + residual.  Same MFMA order as the conv_cl path: same bits, so small launches (a single utterance) may stay there.
@@ -406,10 +423,14 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             if (SP) split_planes(x, Xs, stream_);
         }
         if (fused) {
-            if (SP) conv_bfs(L.attn.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_);
+            if (SP) conv_bfs(L.attn.qkv, Xs, &QKV, kv_parts ? &QKVs : nullptr, nullptr, 1, stream_);
             else conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
-            vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
-                                 split_attn, stream_);
+            if (kv_parts)
+                vits_flash_attention_parts(pl.d_ag, pl.ng, pl.maxT, Q.p, Q.ld, QKVs, H, 2 * H, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window,
+                                           qscale, stream_);
+            else
+                vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
+                                     split_attn, stream_);
         } else {
             conv_plain(L.attn.q, x, Q, 1, 0, nullptr, 1, stream_);
             conv_plain(L.attn.k, x, K, 1, 0, nullptr, 1, stream_);
