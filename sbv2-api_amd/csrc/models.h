@@ -169,7 +169,7 @@ struct VitsConfig {
     }
 };
 
-constexpr int kStreamBurst = 4;   // windows per graph replay of the streaming decoder after an utterance's first chunk
+constexpr int kStreamBurst = 8;   // windows per graph replay of the streaming decoder after an utterance's first chunk
 struct VitsBatch {
     int n = 0;
     const int64_t* t_lens = nullptr;   // [n]
