@@ -404,7 +404,11 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     // sequence 78.5 -> 76.9 ms): what it saves, one conversion of every key tile per 128-query workgroup, grows with T / 128.  The bits are the
     // same, so the choice is made by length (SBV2_FLASH_PARTS_MIN_T, default 4096 frames; set_flash_parts(2) = every length, for the test).
     static const int parts_min_t = getenv("SBV2_FLASH_PARTS_MIN_T") ? atoi(getenv("SBV2_FLASH_PARTS_MIN_T")) : 4096;
-    const bool kv_parts = SP && split_attn && flash_parts_enabled() && (pl.maxT >= parts_min_t || flash_parts_mode() == 2);
+    // ... and by grid size: a launch of <= 64 workgroups (a single utterance: 16) is a serial chain of key tiles per workgroup, where half the
+    // barriers and no conversion in the chain win as well (12.67 -> 12.52 ms per call for one 128-phoneme utterance).
+    static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 64;
+    const int64_t attn_wgs = (int64_t)((pl.maxT + 127) / 128) * pl.ng;
+    const bool kv_parts = SP && split_attn && flash_parts_enabled() && (pl.maxT >= parts_min_t || attn_wgs <= parts_max_wgs || flash_parts_mode() == 2);
     if (kv_parts) QKVs = alloc_split(ar, 2, 3 * H, N);
     // Large batches: the FFN pair on conv_clx.hip (pre-split chunk-major operands by LDS-DMA instead of conv_cl's transposing register staging):
     // x is split once per layer from its k-major plane (split_cl_km), conv_1's epilogue writes relu(.) as conv_2's operand parts, conv_2 writes
