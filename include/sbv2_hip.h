@@ -238,6 +238,12 @@ int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const floa
    d s_memrealtime x 100 (median over workgroups), ms per launch, shader cycles of a workgroup's chunk loop, workgroups stamped}.
    abl: 0 = the kernel, 1 = without its MFMAs, 2 = its MFMAs only, 3 = staging + barriers only. */
 int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4);
+/* Diagnostics: one fused ResBlock step (respair_cl.hip, split-bf16, C = 16 / 32 / 64) on random data, `seconds` of back-to-back launches,
+   then out[0] = in-kernel clock (MHz, median over workgroups), out[1] = ms per launch, out[2] = workgroups stamped, out[2 + i] = median shader
+   cycles from a workgroup's entry to phase stamp i (1 = conv1 window staged, 7 / 8 / 9 / 10 = first chunk's MFMAs / barrier / next chunk staged /
+   barrier, 2 = conv1 done, 3 = intermediate written, 4 = barrier, 5 = conv2 done, 6 = stores issued).  variant 0 = the stamped instantiation
+   (abl bits: 1 cache-hot reads, 2 no stores, 4 no MFMAs, 8 no window conversion, 16 no intermediate epilogue), 1 = the product kernel (time only). */
+int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int variant, int abl, double seconds, double* out, int nout);
 /* y[M][N] = act(w[M][K] x[K][N] + bias) (+ res) through the split-bf16 1x1 GEMM (gemm_bfs.hip; parts 2 = bf16x3, 3 = bf16x6).  split_out != 0:
    the result is also emitted as that many bf16 parts and y returns their sum.  iters > 0: average launch time in *ms.  Test hook. */
 int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,

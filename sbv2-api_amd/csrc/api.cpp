@@ -656,6 +656,102 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     API_END
 }
 
+int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int variant, int abl, double seconds, double* out, int nout) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(out && nout >= 17 && (C == 16 || C == 32 || C == 64) && k >= 1 && k <= kMaxTaps && (k & 1) && L >= 256, "bad arguments");
+    std::vector<float> w1((size_t)C * C * k), w2((size_t)C * C * k), bias((size_t)C, 0.1f), x((size_t)L * C);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() {
+        float a = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            a += (float)((st >> 40) * (1.0 / 16777216.0)) - 0.5f;
+        }
+        return a * 1.7320508f;
+    };
+    for (auto& v : w1) v = rnd() / std::sqrt((float)(C * k));
+    for (auto& v : w2) v = rnd() / std::sqrt((float)(C * k));
+    for (auto& v : x) v = rnd();
+    Blob b = one_conv_blob(w1.data(), bias.data(), {C, C, k}, C);
+    WeightStore ws(b);
+    ClConv c1 = pack_cl(ws, w1.data(), (int)C, (int)C, (int)k, 2, bias.data());
+    ClConv c2 = pack_cl(ws, w2.data(), (int)C, (int)C, (int)k, 2, bias.data());
+    DevBuf dx(x.size()), dy(x.size());
+    HIP_CHECK(hipMemcpy(dx.p, x.data(), sizeof(float) * x.size(), hipMemcpyHostToDevice));
+    ResPairParams rp;
+    rp.X = dx.p;
+    rp.Y = dy.p;
+    rp.W1 = c1.w;
+    rp.W2 = c2.w;
+    rp.b1 = c1.bias;
+    rp.b2 = c2.bias;
+    rp.C = (int)C;
+    rp.N = (int)L;
+    rp.k = (int)k;
+    rp.dil = (int)dilation;
+    rp.split = 1;
+    rp.abl = abl;
+    const int nto = 256 - (int)(k - 1);
+    const int nwg = (int)((L + nto - 1) / nto);
+    unsigned long long* d_st = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 16 * nwg));
+    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 16 * nwg));
+    rp.stamps = d_st;
+    auto launch = [&]() {
+        if (variant == 0) launch_respair_cl_diag(rp, nullptr);
+        else launch_respair_cl(rp, nullptr);   // the product kernel (no stamps: clock and phases read 0)
+    };
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    launch();
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 20; ++i) launch();
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t20 = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t20, e0, e1));
+    const int reps = std::max(20, (int)(seconds * 1e3 / std::max(t20 / 20.f, 1e-3f)));
+    for (int i = 0; i < reps; ++i) launch();
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 50; ++i) launch();
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t50 = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t50, e0, e1));
+    std::vector<unsigned long long> hs((size_t)16 * nwg);
+    HIP_CHECK(hipMemcpy(hs.data(), d_st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(d_st);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (int i = 0; i < nout; ++i) out[i] = 0.0;
+    out[1] = t50 / 50.0;
+    std::vector<double> mhz;
+    std::vector<std::vector<double>> ph(14);
+    for (int g = 0; g < nwg; ++g) {
+        const unsigned long long* h = hs.data() + (size_t)16 * g;   // low words of the counters: differences modulo 2^32
+        const unsigned dr = (unsigned)h[15] - (unsigned)h[14], dt = (unsigned)h[6] - (unsigned)h[0];
+        if (h[15] != 0 && dr > 0 && dt > 0) {
+            mhz.push_back((double)dt / (double)dr * 100.0);
+            for (int i = 1; i < 14; ++i)
+                if (h[i] != 0) ph[i].push_back((double)((unsigned)h[i] - (unsigned)h[0]));
+        }
+    }
+    if (!mhz.empty()) {
+        std::sort(mhz.begin(), mhz.end());
+        out[0] = mhz[mhz.size() / 2];
+        out[2] = (double)mhz.size();
+        for (int i = 1; i < 14 && 2 + i < nout; ++i)
+            if (!ph[i].empty()) {
+                std::sort(ph[i].begin(), ph[i].end());
+                out[2 + i] = ph[i][ph[i].size() / 2];   // median cycles from the workgroup's entry to stamp i
+            }
+    }
+    API_END
+}
+
 int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
                         int parts, int act, int split_out, int64_t iters, float* y, float* ms) {
     API_BEGIN

@@ -405,8 +405,10 @@ struct ResPairParams {
     int mask_div = 1;
     int mask_shift = -1;   // set by launch_respair_cl
     int alias_x2 = 1;      // set by launch_respair_cl: the intermediate window re-uses the conv1 window's LDS
-    int abl = 0;           // diagnostics (SBV2_RESPAIR_ABL, wrong results): 1 = every global read hits the same few cache-hot rows, 2 = no global stores
+    int abl = 0;           // diagnostics (wrong results): 1 = every global read hits the same few cache-hot rows, 2 = no global stores; diag kernel only: 4 = no MFMAs, 8 = no conv1 window conversion, 16 = no intermediate epilogue
+    unsigned long long* stamps = nullptr;   // diag kernel only: 16 per workgroup
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
+void launch_respair_cl_diag(const ResPairParams& p, hipStream_t stream);
 
 }  // namespace sbv2

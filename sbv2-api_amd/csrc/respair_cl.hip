@@ -39,8 +39,26 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
 
 // WM = 32-row tiles of the output channels, one group of four waves each: 1 for C = 16 / 32 (256 threads), 2 for C = 64 (512 threads: the
 // 134 KB of LDS at k = 11 allow one workgroup per CU, so the second wave per SIMD has to come from inside the workgroup)
-template <int PREC, bool PERSIST, int WM>
+template <int PREC, bool PERSIST, int WM, int DG = -1>   // DG >= 0: the diagnostic instantiation with the compile-time ablation mask DG
 __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu(PERSIST ? 1 : (WM > 1 ? 2 : 3)))) void respair_cl_kernel(const ResPairParams p) {
+    constexpr bool DIAG = DG >= 0;
+    constexpr int ABL = DIAG ? DG : 0;
+    // DIAG (sbv2_debug_respair_clock only): the phase boundaries of the workgroup's first tile are stamped with s_memtime into scalar registers and
+    // written to p.stamps[16 per workgroup] by thread 0 at the very end (a store in the middle would hold back every later load: one in-order vmcnt)
+    unsigned st_[16];   // low words (a workgroup lives < 2^32 cycles); 64-bit stamps pushed the kernel over its SGPR budget into scratch
+    auto stamp = [&](auto ic) {
+        if constexpr (DIAG) {
+            constexpr int i = decltype(ic)::value;
+            st_[i] = (unsigned)(i >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime());
+        }
+    };
+#define RP_STAMP(i) stamp(std::integral_constant<int, i>{})
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st_[i] = 0;
+    }
+    RP_STAMP(0);
+    RP_STAMP(14);
     constexpr int T = kRpThreads * WM;
     constexpr bool SPLIT = PREC == PREC_BF16X3;
     using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
@@ -117,13 +135,14 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = min(tid + i * T, nxf4 - 1);
-            const int pos = (p.abl & 1) ? ((idx >> 2) & 63) : min(max(wstart + (idx >> 2), 0), NB - 1);
+            const int pos = ((ABL & 1) != 0) ? ((idx >> 2) & 63) : min(max(wstart + (idx >> 2), 0), NB - 1);
             const float* src = p.X + ((int64_t)pos << lc) + (WM == 1 ? 0 : pair * 32) + (idx & 3) * 4;
             rx[i] = *reinterpret_cast<const f32x4v*>(src);
             rx1[i] = *reinterpret_cast<const f32x4v*>(nchunks > 1 ? src + 16 : src);
         }
     };
     auto store_x = [&](int chunk) {
+        if ((ABL & 8) != 0) return;   // no conversion / LDS stores of the conv1 window (stale LDS)
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * T;
@@ -167,6 +186,11 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
             if (SPLIT) f.al = *reinterpret_cast<const ex8*>(blk + 1024);
         };
         auto mfma_frags = [&](const Frags& f) {
+            if ((ABL & 4) != 0) {   // no MFMAs: the fragments are consumed by one VALU op each so that their reads stay
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j][0] += (float)f.bh[j][0] + (float)f.ah[0] + (SPLIT ? (float)f.bl[j][0] + (float)f.al[0] : 0.f);
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (SPLIT) {
@@ -210,18 +234,24 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
             if (tid + h * T < kRpWin2Rows + 16) mask_s[tid + h * T] = mval[h];
     }
     __syncthreads();
+    RP_STAMP(1);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
         load_w(more ? p.W1 : p.W2, more ? chunk + 1 : 0);   // the next weights: conv1's next chunk, then conv2's first
         if (WM > 1 && (chunk & 1) && more) load_x((chunk + 1) >> 1);   // C = 64: the second 32-channel group (its registers are free now)
         mfma_chunk(x1_hi, x1_lo, p.dil);
+        if (chunk == 0) RP_STAMP(7);
         __syncthreads();
+        if (chunk == 0) RP_STAMP(8);
         if (more) {
             store_w();
             store_x(chunk + 1);
+            if (chunk == 0) RP_STAMP(9);
             __syncthreads();
+            if (chunk == 0) RP_STAMP(10);
         }
     }
+    RP_STAMP(2);
     {
         bool keepj[TN];   // the column mask depends on the position only: once per column, not once per channel quad
 #pragma unroll
@@ -232,7 +262,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co = wm * 32 + 8 * q + 4 * lh;
-            if (co >= C) continue;
+            if (co >= C || ((ABL & 16) != 0)) continue;
             const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bias_s + co);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -259,6 +289,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    RP_STAMP(3);
     store_w();   // conv2 chunk 0 (requested before the last conv1 MFMA block)
     zero_acc();
     const int n0_cur = n0;
@@ -270,6 +301,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
         load_x(0);
     }
     __syncthreads();
+    RP_STAMP(4);
 
     // the residual rows of the epilogue are requested now (branch-free, clamped) and land behind conv2's MFMAs; they were fetched
     // for the conv1 window a moment ago, so these are L2 hits, but still a dependent ~1 us round trip if left to the epilogue
@@ -278,7 +310,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
         const int c4r = min(wm * 32 + (lane & 7) * 4, C - 4);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int64_t posr = (p.abl & 1) ? (it * 8 + (lane >> 3)) : min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
+            const int64_t posr = ((ABL & 1) != 0) ? (it * 8 + (lane >> 3)) : min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
             rres[it] = *reinterpret_cast<const f32x4v*>(p.X + (posr << lc) + c4r);
         }
     }
@@ -296,6 +328,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
         }
     }
 
+    RP_STAMP(5);
     // ---- epilogue: + b2 + y, beta, accumulate, mask; full 128-byte lines through a per-wave LDS transpose ---------------------
     float* ttile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
 #pragma unroll
@@ -314,7 +347,7 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
         const int c4o = min(c4, C - 4);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int64_t po = (p.abl & 1) ? (it * 8 + (lane >> 3)) : min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
+            const int64_t po = ((ABL & 1) != 0) ? (it * 8 + (lane >> 3)) : min((int64_t)n0_cur + wn0 + it * 8 + (lane >> 3), (int64_t)NB - 1);
             rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + (po << lc) + c4o);
         }
     }
@@ -335,8 +368,16 @@ __global__ __launch_bounds__(kRpThreads * WM) __attribute__((amdgpu_waves_per_eu
             for (int e = 0; e < 4; ++e) v[e] += rold[it][e];
         }
         if (!mask_s[o + h2]) v = f32x4v{0.f, 0.f, 0.f, 0.f};   // position n0 + o = intermediate row o + h2
-        if (p.abl & 2) continue;
+        if ((ABL & 2) != 0) continue;
         *dst = v;
+    }
+    RP_STAMP(6);
+    RP_STAMP(15);
+    if constexpr (DIAG) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 16 + i] = st_[i];
+        }
     }
     if (!next_tile) break;
     zero_acc();
@@ -380,6 +421,50 @@ static void launch_rp(const ResPairParams& p, hipStream_t stream) {
     }
 }
 
+// diagnostics (sbv2_debug_respair_clock): the split-bf16 kernel with phase stamps and the ablations of p.abl
+void launch_respair_cl_diag(const ResPairParams& p0, hipStream_t stream) {
+    ResPairParams p = p0;
+    p.mask_shift = 0;
+    while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
+    p.alias_x2 = 1;
+    SBV2_REQUIRE(p.split && p.stamps && (p.C == 16 || p.C == 32 || p.C == 64), "respair diag: split-bf16 only");
+    constexpr int PARTS = 2;
+    const int WM = p.C == 64 ? 2 : 1;
+    const int h1 = p.dil * (p.k - 1) / 2, h2 = (p.k - 1) / 2;
+    const int rows1 = kRpNT + 2 * h1;
+    size_t lds = (size_t)p.k * WM * PARTS * 1024 + std::max((size_t)rows1 * 32 * PARTS, (size_t)(p.C >> 4) * kRpWin2Rows * 32 * PARTS);
+    lds = std::max<size_t>(lds, (size_t)WM * 4 * 64 * 36 * sizeof(float));
+    lds += 128 * sizeof(float) + kRpWin2Rows + 16;
+    lds = (lds + 15) / 16 * 16;
+    const int nto = kRpNT - 2 * h2;
+    const int ntiles = (p.N + nto - 1) / nto;
+    auto go = [&](auto ablc) {
+        constexpr int A = decltype(ablc)::value;
+        if (WM == 2) {
+            auto kern = respair_cl_kernel<PREC_BF16X3, false, 2, A>;
+            static std::atomic<uint64_t> a2{0};
+            allow_full_lds(reinterpret_cast<const void*>(kern), a2);
+            hipLaunchKernelGGL(kern, dim3(ntiles), dim3(512), lds, stream, p);
+        } else {
+            auto kern = respair_cl_kernel<PREC_BF16X3, false, 1, A>;
+            static std::atomic<uint64_t> a1{0};
+            allow_full_lds(reinterpret_cast<const void*>(kern), a1);
+            hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, stream, p);
+        }
+    };
+    switch (p.abl) {
+        case 0: go(std::integral_constant<int, 0>{}); break;
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 8: go(std::integral_constant<int, 8>{}); break;
+        case 16: go(std::integral_constant<int, 16>{}); break;
+        case 28: go(std::integral_constant<int, 28>{}); break;
+        case 31: go(std::integral_constant<int, 31>{}); break;
+        default: SBV2_REQUIRE(false, "respair diag: ablation mask not instantiated");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     ResPairParams p = p0;
     // the column mask is indexed by position / upsampling factor; only powers of two are supported here (a shift: the 64-bit integer
@@ -389,8 +474,7 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
     static const int alias = getenv("SBV2_RESPAIR_ALIAS") ? atoi(getenv("SBV2_RESPAIR_ALIAS")) : 1;   // A/B knob: 0 = separate x1 / x2 windows
     p.alias_x2 = alias;
-    static const int abl = getenv("SBV2_RESPAIR_ABL") ? atoi(getenv("SBV2_RESPAIR_ABL")) : 0;
-    p.abl = abl;
+    p.abl = 0;   // (ablations exist in the diagnostic instantiation only: launch_respair_cl_diag)
     SBV2_REQUIRE(p.C == 16 || p.C == 32 || p.C == 64, "respair: only the 16-, 32- and 64-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
