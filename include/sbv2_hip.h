@@ -238,11 +238,19 @@ int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const floa
    d s_memrealtime x 100 (median over workgroups), ms per launch, shader cycles of a workgroup's chunk loop, workgroups stamped}.
    abl: 0 = the kernel, 1 = without its MFMAs, 2 = its MFMAs only, 3 = staging + barriers only. */
 int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4);
+/* 1 (default, SBV2_RESPAIR_CLX): the fused ResBlock steps of the <= 64-channel decoder stages run on respair_clx.hip (split-bf16, k in {3, 7, 11});
+   0: on respair_cl.hip (same bits).  Returns the previous value. */
+int sbv2_debug_set_respair_clx(int on);
+/* One fused ResBlock1 step y' = beta (conv2(lrelu(conv1(lrelu(x), dilation) + b1)) + b2 + x) [+ y when accumulate], masked by mask[n / mask_div] (may be
+   null), channels-last x / y [N][C], w [C][C][k], split-bf16, through respair_cl.hip (variant 0) or respair_clx.hip (variant 1).  Test hook. */
+int sbv2_debug_respair(int device, const float* x, const float* w1, const float* w2, const float* b1, const float* b2, int64_t C, int64_t N, int64_t k,
+                       int64_t dilation, const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, float* y);
 /* Diagnostics: one fused ResBlock step (respair_cl.hip, split-bf16, C = 16 / 32 / 64) on random data, `seconds` of back-to-back launches,
    then out[0] = in-kernel clock (MHz, median over workgroups), out[1] = ms per launch, out[2] = workgroups stamped, out[2 + i] = median shader
    cycles from a workgroup's entry to phase stamp i (1 = conv1 window staged, 7 / 8 / 9 / 10 = first chunk's MFMAs / barrier / next chunk staged /
-   barrier, 2 = conv1 done, 3 = intermediate written, 4 = barrier, 5 = conv2 done, 6 = stores issued).  variant 0 = the stamped instantiation
-   (abl bits: 1 cache-hot reads, 2 no stores, 4 no MFMAs, 8 no window conversion, 16 no intermediate epilogue), 1 = the product kernel (time only). */
+   barrier, 2 = conv1 done, 3 = intermediate written, 4 = barrier, 5 = conv2 done, 6 = stores issued).  variant 0 = the stamped instantiation of
+   respair_cl (abl bits: 1 cache-hot reads, 2 no stores, 4 no MFMAs, 8 no window conversion, 16 no intermediate epilogue), 1 = the product respair_cl
+   (time only), 2 = respair_clx stamped, 3 = the product respair_clx (time only). */
 int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int variant, int abl, double seconds, double* out, int nout);
 /* y[M][N] = act(w[M][K] x[K][N] + bias) (+ res) through the split-bf16 1x1 GEMM (gemm_bfs.hip; parts 2 = bf16x3, 3 = bf16x6).  split_out != 0:
    the result is also emitted as that many bf16 parts and y returns their sum.  iters > 0: average launch time in *ms.  Test hook. */

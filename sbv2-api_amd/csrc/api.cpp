@@ -656,6 +656,61 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     API_END
 }
 
+int sbv2_debug_set_respair_clx(int on) { return set_respair_clx(on); }
+
+int sbv2_debug_respair(int device, const float* x, const float* w1, const float* w2, const float* b1, const float* b2, int64_t C, int64_t N, int64_t k,
+                       int64_t dilation, const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, float* y) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(x && w1 && w2 && b1 && b2 && y && (C == 16 || C == 32 || C == 64) && N >= 1 && k >= 1 && k <= kMaxTaps && (k & 1) && mask_div >= 1, "bad arguments");
+    Blob b = one_conv_blob(w1, b1, {C, C, k}, C);
+    WeightStore ws(b);
+    ClConv c1 = pack_cl(ws, w1, (int)C, (int)C, (int)k, 2, b1);
+    ClConv c2 = pack_cl(ws, w2, (int)C, (int)C, (int)k, 2, b2);
+    DevBuf dx((size_t)N * C), dy((size_t)N * C);
+    HIP_CHECK(hipMemcpy(dx.p, x, sizeof(float) * N * C, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dy.p, y, sizeof(float) * N * C, hipMemcpyHostToDevice));   // (the previous contents matter when accumulate is set)
+    unsigned char* dm = nullptr;
+    const size_t nm = (size_t)((N + mask_div - 1) / mask_div);
+    if (mask) {
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dm), nm));
+        HIP_CHECK(hipMemcpy(dm, mask, nm, hipMemcpyHostToDevice));
+    }
+    ResPairParams rp;
+    rp.X = dx.p;
+    rp.Y = dy.p;
+    rp.W1 = c1.w;
+    rp.W2 = c2.w;
+    if (C == 16) {
+        rp.W1p = pack_cl_pairs(ws, w1, (int)k);
+        rp.W2p = pack_cl_pairs(ws, w2, (int)k);
+    }
+    rp.b1 = c1.bias;
+    rp.b2 = c2.bias;
+    rp.C = (int)C;
+    rp.N = (int)N;
+    rp.k = (int)k;
+    rp.dil = (int)dilation;
+    rp.split = 1;
+    rp.beta = beta;
+    rp.accumulate = accumulate;
+    rp.mask = dm;
+    rp.mask_div = (int)mask_div;
+    const int prev = set_respair_clx(variant ? 1 : 0);   // 0 = respair_cl, 1 = respair_clx
+    try {
+        launch_respair_cl(rp, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+    } catch (...) {
+        set_respair_clx(prev);
+        if (dm) (void)hipFree(dm);
+        throw;
+    }
+    set_respair_clx(prev);
+    HIP_CHECK(hipMemcpy(y, dy.p, sizeof(float) * N * C, hipMemcpyDeviceToHost));
+    if (dm) (void)hipFree(dm);
+    API_END
+}
+
 int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int variant, int abl, double seconds, double* out, int nout) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
@@ -684,6 +739,10 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
     rp.Y = dy.p;
     rp.W1 = c1.w;
     rp.W2 = c2.w;
+    if (C == 16) {
+        rp.W1p = pack_cl_pairs(ws, w1.data(), (int)k);
+        rp.W2p = pack_cl_pairs(ws, w2.data(), (int)k);
+    }
     rp.b1 = c1.bias;
     rp.b2 = c2.bias;
     rp.C = (int)C;
@@ -692,15 +751,17 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
     rp.dil = (int)dilation;
     rp.split = 1;
     rp.abl = abl;
-    const int nto = 256 - (int)(k - 1);
-    const int nwg = (int)((L + nto - 1) / nto);
+    const int nto = 128 - (int)(k - 1);          // (the smallest tile any variant uses: respair_clx at C = 64)
+    const int nwg = (int)((L + nto - 1) / nto) + 8;
     unsigned long long* d_st = nullptr;
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 16 * nwg));
     HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 16 * nwg));
     rp.stamps = d_st;
+    const int prev_rpx = set_respair_clx(variant == 3 ? 1 : 0);
     auto launch = [&]() {
         if (variant == 0) launch_respair_cl_diag(rp, nullptr);
-        else launch_respair_cl(rp, nullptr);   // the product kernel (no stamps: clock and phases read 0)
+        else if (variant == 2) launch_respair_clx_diag(rp, nullptr);
+        else launch_respair_cl(rp, nullptr);   // the product kernels (no stamps: clock and phases read 0): 1 = respair_cl, 3 = respair_clx
     };
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
@@ -726,6 +787,7 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
     (void)hipFree(d_st);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    set_respair_clx(prev_rpx);
     for (int i = 0; i < nout; ++i) out[i] = 0.0;
     out[1] = t50 / 50.0;
     std::vector<double> mhz;

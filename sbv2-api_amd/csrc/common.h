@@ -396,6 +396,8 @@ struct ResPairParams {
     float* Y = nullptr;         // y' [N][C] (may be a different buffer; += when accumulate)
     const void* W1 = nullptr;   // conv_cl fragment blocks (tm = 1)
     const void* W2 = nullptr;
+    const void* W1p = nullptr;  // C = 16 only: the same weights packed as tap pairs for v_mfma_f32_16x16x32_bf16 (pack_cl_pairs; respair_clx.hip)
+    const void* W2p = nullptr;
     const float* b1 = nullptr;
     const float* b2 = nullptr;
     int C = 0, N = 0, k = 1, dil = 1, split = 1, f16 = 0;
@@ -410,5 +412,10 @@ struct ResPairParams {
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
 void launch_respair_cl_diag(const ResPairParams& p, hipStream_t stream);
+// respair_clx.hip: the same step, split-bf16, k in {3, 7, 11}, rebuilt around its instruction count (round 4); bit-identical to respair_cl
+bool respair_clx_usable(const ResPairParams& p);          // p.mask_shift set
+void launch_respair_clx(const ResPairParams& p, hipStream_t stream);
+void launch_respair_clx_diag(const ResPairParams& p, hipStream_t stream);
+int set_respair_clx(int on);   // returns the previous setting (default: SBV2_RESPAIR_CLX, 1)
 
 }  // namespace sbv2

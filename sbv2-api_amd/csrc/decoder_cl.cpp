@@ -79,11 +79,32 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
     return c;
 }
 
+// 16 -> 16 channel convolution as A fragments of v_mfma_f32_16x16x32_bf16 whose 32-deep K dimension carries two taps: block (pair tp, part), lane l
+// holds W[row = l & 15][channel 8 (g & 1) + j][tap 2 tp + (g >> 1)], g = l >> 4 (zero for the phantom tap of an odd kernel size); bf16 hi / lo parts.
+void* pack_cl_pairs(WeightStore& ws, const float* w, int k) {
+    const int np = (k + 1) / 2;
+    std::vector<uint16_t> h((size_t)np * 2 * 512, 0);
+    for (int tp = 0; tp < np; ++tp)
+        for (int l = 0; l < 64; ++l) {
+            const int row = l & 15, g = l >> 4, tap = 2 * tp + (g >> 1);
+            if (tap >= k) continue;
+            for (int j = 0; j < 8; ++j) {
+                const float v = w[((size_t)row * 16 + 8 * (g & 1) + j) * k + tap];
+                const uint16_t hi = f32_to_bf16_rne(v);
+                h[((size_t)tp * 2) * 512 + l * 8 + j] = hi;
+                h[((size_t)tp * 2 + 1) * 512 + l * 8 + j] = f32_to_bf16_rne(v - bf16_to_f32(hi));
+            }
+        }
+    return ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
+}
+
 void VitsModel::load_decoder_cl(const Blob& blob) {
     auto conv = [&](const std::string& prefix) {
         const HostTensor& t = blob.get(prefix + ".weight");
         const float* b = blob.has(prefix + ".bias") ? blob.get(prefix + ".bias").data : nullptr;
-        return pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], dec_mode_ == 1 ? 2 : (dec_mode_ == 2 ? 1 : 3), b);
+        ClConv c = pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], dec_mode_ == 1 ? 2 : (dec_mode_ == 2 ? 1 : 3), b);
+        if (dec_mode_ == 1 && t.dims[0] == 16 && t.dims[1] == 16) c.wp = pack_cl_pairs(*ws_, t.data, (int)t.dims[2]);
+        return c;
     };
     cl_pre_ = conv("dec.conv_pre");
     int C = cfg_.up_initial;
@@ -327,6 +348,8 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                     rp.Y = yn;
                     rp.W1 = rb.c1[q].w;
                     rp.W2 = rb.c2[q].w;
+                    rp.W1p = rb.c1[q].wp;
+                    rp.W2p = rb.c2[q].wp;
                     rp.b1 = rb.c1[q].bias;
                     rp.b2 = rb.c2[q].bias;
                     rp.C = C;

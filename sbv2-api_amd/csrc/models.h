@@ -11,6 +11,7 @@ namespace sbv2 {
 // A convolution packed for conv_cl.hip (bf16 MFMA fragment blocks); parts = 2 keeps a bf16 hi and a bf16 lo copy.
 struct ClConv {
     void* w = nullptr;
+    void* wp = nullptr;    // 16 x 16 convolutions of the fused ResBlock step: tap-pair fragments [pair][part][64 lanes][8] (pack_cl_pairs), else null
     float* bias = nullptr;
     int M = 0, K = 0, k = 1, nmt = 0, tm = 1, parts = 0;
 };
@@ -58,6 +59,7 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
 class WeightStore;
 // w is [M][K][k] (Conv1d layout); K is zero-padded to a multiple of 16
 ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
+void* pack_cl_pairs(WeightStore& ws, const float* w, int k);   // w [16][16][k] -> tap-pair fragments (split-bf16) for respair_clx's 16-channel kernel
 // w is [M][K] (Linear / 1x1 conv): bf16 parts (2 = hi + lo, 3 = hi + mid + lo) as MFMA A fragments; K must be a multiple of 16
 BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts);
 

@@ -465,6 +465,9 @@ void launch_respair_cl_diag(const ResPairParams& p0, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
+static std::atomic<int> g_rpx{getenv("SBV2_RESPAIR_CLX") ? atoi(getenv("SBV2_RESPAIR_CLX")) : 1};
+int set_respair_clx(int on) { return g_rpx.exchange(on); }
+
 void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     ResPairParams p = p0;
     // the column mask is indexed by position / upsampling factor; only powers of two are supported here (a shift: the 64-bit integer
@@ -479,6 +482,7 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
     if (p.N <= 0) return;
+    if (g_rpx.load(std::memory_order_relaxed) && respair_clx_usable(p)) return launch_respair_clx(p, stream);   // the round-4 kernel (same bits)
     static const int persist = getenv("SBV2_RESPAIR_PERSIST") ? atoi(getenv("SBV2_RESPAIR_PERSIST")) : 0;
     SBV2_REQUIRE(!(p.split && p.f16), "respair: split and f16 are exclusive");
     if (p.C == 64) {

@@ -69,6 +69,48 @@ def test_conv1d_clx_kernel_same_bits_as_conv_cl(C, k, dil, L):
     np.testing.assert_array_equal(got2, ((ref + r) * np.float32(1.0 / 3)).astype(np.float32))
 
 
+def _respair(x, w1, w2, b1, b2, k, dil, mask, mask_div, beta, prev, variant):
+    N, C = x.shape
+    y = np.ascontiguousarray(prev, np.float32).copy() if prev is not None else np.zeros((N, C), np.float32)
+    P = lambda a: a.ctypes.data_as(f32p)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    _lib.check(_lib.lib().sbv2_debug_respair(0, P(x), P(w1), P(w2), P(b1), P(b2), C, N, k, dil, None if m is None else m.ctypes.data, mask_div,
+                                             float(beta), 1 if prev is not None else 0, variant, P(y)))
+    return y
+
+
+@pytest.mark.parametrize("C,k,dil,N", [(16, 3, 1, 700), (16, 7, 3, 1024), (16, 11, 5, 300), (32, 3, 5, 257), (32, 7, 1, 2000), (32, 11, 3, 740), (64, 3, 3, 130),
+                                       (64, 7, 5, 1111), (64, 11, 1, 512), (32, 11, 5, 31), (16, 7, 1, 246 * 9), (64, 11, 5, 118 * 17 + 3)])
+def test_respair_clx_kernel_same_bits_as_respair_cl(C, k, dil, N):
+    """respair_clx.hip (round 4: templated taps / channels, LDS-DMA weight groups, 128-position tiles at C = 64, XCD-contiguous tile order) gives the
+    SAME bits as respair_cl.hip for one fused ResBlock1 step at C = 32 / 64: plain, with a column mask (edges of packed utterances: mask_div 4), and with
+    beta + accumulate (the last step of a branch); and both agree with the numpy oracle's resblock step.  C = 16 runs two taps per 32-deep MFMA
+    (v_mfma_f32_16x16x32_bf16): another summation order, so it is held to f32-grade closeness (1e-5) instead of bit equality."""
+    same = np.testing.assert_array_equal if C != 16 else (lambda a, b: np.testing.assert_allclose(a, b, atol=1e-5, rtol=1e-5))
+    rng = np.random.default_rng(C * 1000 + k * 10 + dil + N)
+    x = rng.standard_normal((N, C)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b1, b2 = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    ref = _respair(x, w1, w2, b1, b2, k, dil, None, 1, 1.0, None, 0)
+    got = _respair(x, w1, w2, b1, b2, k, dil, None, 1, 1.0, None, 1)
+    same(got, ref)
+    xt = x.T.copy()
+    t = O.conv1d_same(O.leaky_relu(xt, 0.1), w1, b1, dil)
+    want = O.conv1d_same(O.leaky_relu(t, 0.1), w2, b2, 1) + xt
+    np.testing.assert_allclose(got.T, want, atol=1e-4, rtol=1e-5)
+    mask = (rng.random((N + 3) // 4) > 0.15).astype(np.uint8)
+    xm = x * np.repeat(mask, 4)[:N, None]                      # (a masked column holds zeros in the real planes)
+    prev = rng.standard_normal((N, C)).astype(np.float32)
+    ref = _respair(xm, w1, w2, b1, b2, k, dil, mask, 4, 1.0 / 3, prev, 0)
+    got = _respair(xm, w1, w2, b1, b2, k, dil, mask, 4, 1.0 / 3, prev, 1)
+    same(got, ref)
+    ref = _respair(xm, w1, w2, b1, b2, k, dil, mask, 4, 1.0, None, 0)
+    got = _respair(xm, w1, w2, b1, b2, k, dil, mask, 4, 1.0, None, 1)
+    same(got, ref)
+    assert not np.any(got[np.repeat(mask, 4)[:N] == 0])
+
+
 def _gemm_bfs(x, w, b, r, parts, act=0, split_out=0):
     m, k = w.shape
     n = x.shape[1]
@@ -444,6 +486,26 @@ def test_decoder_clx_path_same_bits_as_conv_cl_path():
         lib.sbv2_debug_set_clx(prev)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+    s.close()
+
+
+def test_decoder_respair_clx_path_same_bits_as_respair_cl_path():
+    """Full JP-Extra shape: the fused ResBlock steps of the 64- / 32- / 16-channel decoder stages on respair_clx.hip (the default) against the same
+    stages on respair_cl.hip (sbv2_debug_set_respair_clx(0)).  The 64- and 32-channel kernels give the same bits; the 16-channel kernel sums two taps per
+    MFMA (another order): the waveforms agree to 2e-6 (peak ~0.1; the oracle tolerance of the decoder tests is 5e-5)."""
+    cfg, W = weights("vits", "full")
+    s = model.load_model(blob("vits", "full"), False)
+    utts = make_utts([12, 31, 5], O.DEBERTA_FULL, cfg, seed0=78)
+    lib = _lib.lib()
+    prev = lib.sbv2_debug_set_respair_clx(1)
+    try:
+        a = model.synthesize_batch(s, utts, forced=True)
+        lib.sbv2_debug_set_respair_clx(0)
+        b = model.synthesize_batch(s, utts, forced=True)
+    finally:
+        lib.sbv2_debug_set_respair_clx(prev)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, atol=2e-6, rtol=0)
     s.close()
 
 
