@@ -208,8 +208,11 @@ def main():
         nsub = max(1, -(-max(per_rank) // 65536))
     order = sorted(range(len(utts)), key=lambda i: -frames([utts[i]]))
     groups = [[utts[i] for i in order[g::nsub]] for g in range(nsub)]
-    if not utts:
-        raise SystemExit(f"bench.py: rank {rank} was dealt no utterance (world {world} > utterances): use fewer ranks for this config")
+    # decided identically on EVERY rank (from the deal / the batch size, not from this rank's own shard): a single rank leaving before the rendezvous
+    # would leave the others waiting in the collectives
+    empty = [q for q in range(world) if not any(r == q for r in rank_of)] if args.config != "u128" else (list(range(world)) if args.batch <= 0 else [])
+    if empty:
+        raise SystemExit(f"bench.py: ranks {empty} would be dealt no utterance (world {world}): use fewer ranks for this config")
     batches = [pipe.prepare(g, forced=True) for g in groups if g]   # benchmark mode: blank 1 frame, phone 6 frames
     sub_samples = [frames(g) * hop for g in groups if g]
     # a rank with fewer sub-batches than the others repeats its last one so that every rank makes the same number of collective calls; the
@@ -301,7 +304,8 @@ def main():
         _lib.check(l.sbv2_prof_begin())
         for bb in batches:
             pipe.run(bb)
-        pipe.sync()
+            pipe.sync()     # one sub-batch at a time: consecutive runs alternate between two execution contexts, and kernels of two sub-batches in
+                            # flight together would stretch each other's event durations (mixed256: 8 sub-batches; u128 has one)
         buf = C.create_string_buffer(1 << 16)
         _lib.check(l.sbv2_prof_end(buf, len(buf)))
         prof = json.loads(buf.value.decode())

@@ -238,6 +238,11 @@ int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const floa
    d s_memrealtime x 100 (median over workgroups), ms per launch, shader cycles of a workgroup's chunk loop, workgroups stamped}.
    abl: 0 = the kernel, 1 = without its MFMAs, 2 = its MFMAs only, 3 = staging + barriers only. */
 int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4);
+/* Diagnostics for the f16x3 operand format (DeBERTa's and the flow's 1x1 products): the split of an activation into the f16 hi / scaled-lo pair clamps
+   finite values beyond +-65504 (NaN and infinities propagate).  enable = 1 / 0 switches the device-side counter of clamped values on / off for planes
+   allocated from then on (-1: leave as is; the SBV2_F16X3_SATCOUNT=1 environment variable switches it on from the start); *count (optional) receives the
+   number of clamped values since the last call, on `device`.  A non-zero count on a real checkpoint means: run with SBV2_BERT_GEMM=bf16x6. */
+int sbv2_debug_f16x3_saturation(int device, int enable, uint64_t* count);
 /* 1 (default, SBV2_RESPAIR_CLX): the fused ResBlock steps of the <= 64-channel decoder stages run on respair_clx.hip (split-bf16, k in {3, 7, 11});
    0: on respair_cl.hip (same bits).  Returns the previous value. */
 int sbv2_debug_set_respair_clx(int on);

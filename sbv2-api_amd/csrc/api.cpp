@@ -656,6 +656,14 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     API_END
 }
 
+int sbv2_debug_f16x3_saturation(int device, int enable, uint64_t* count) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    if (enable >= 0) f16x3_sat_enable(enable);
+    if (count) *count = f16x3_sat_read(true);
+    API_END
+}
+
 int sbv2_debug_set_respair_clx(int on) { return set_respair_clx(on); }
 
 int sbv2_debug_respair(int device, const float* x, const float* w1, const float* w2, const float* b1, const float* b2, int64_t C, int64_t N, int64_t k,
@@ -836,6 +844,7 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     xs.p = dxs.p;
     xs.parts = split_nplanes(parts);
     xs.f16 = parts == kPartsF16x3;
+    xs.sat = xs.f16 ? f16x3_sat_counter() : nullptr;
     xs.C = (int)K;
     xs.L = (int)N;
     xs.ld = ld;

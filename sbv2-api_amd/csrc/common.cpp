@@ -1,6 +1,8 @@
 // Arena, weight-blob parser, error plumbing (host only).
 #include "common.h"
 
+#include <mutex>
+
 #include <dlfcn.h>
 
 #include <cstring>
@@ -229,6 +231,36 @@ std::vector<std::vector<int>> json_int_array2(const std::string& js, const std::
         }
     }
     return out;
+}
+
+
+// ---- f16x3 saturation counter (diagnostics; common.h) ----------------------------------------------------------------------------------
+static std::atomic<int> g_sat_on{getenv("SBV2_F16X3_SATCOUNT") ? atoi(getenv("SBV2_F16X3_SATCOUNT")) : 0};
+static std::mutex g_sat_mu;
+static std::map<int, unsigned long long*> g_sat_ctr;   // per device
+static unsigned long long* sat_ptr(bool create) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_sat_mu);
+    auto it = g_sat_ctr.find(dev);
+    if (it != g_sat_ctr.end()) return it->second;
+    if (!create) return nullptr;
+    unsigned long long* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, sizeof(unsigned long long));
+    g_sat_ctr[dev] = p;
+    return p;
+}
+unsigned long long* f16x3_sat_counter() { return g_sat_on.load(std::memory_order_relaxed) ? sat_ptr(true) : nullptr; }
+int f16x3_sat_enable(int on) { return g_sat_on.exchange(on); }
+unsigned long long f16x3_sat_read(bool reset) {
+    unsigned long long* p = sat_ptr(false);
+    if (!p) return 0;
+    unsigned long long v = 0;
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset) HIP_CHECK(hipMemset(p, 0, sizeof(v)));
+    return v;
 }
 
 }  // namespace sbv2

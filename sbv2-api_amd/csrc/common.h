@@ -258,6 +258,7 @@ struct SplitPlanes {        // [part][C][ld] 16-bit, the column axis contiguous;
     int parts = 0, C = 0, L = 0, ld = 0;   // parts = number of planes
     int f16 = 0;            // 0: bf16 parts (each the rounding of what the previous ones left), 1: the f16 hi / scaled-lo pair
     int64_t pstride = 0;    // elements from one part to the next
+    unsigned long long* sat = nullptr;   // f16 pair only, diagnostics (SBV2_F16X3_SATCOUNT=1 / sbv2_debug_f16x3_saturation): counts values the split clamped
     int code() const { return f16 ? kPartsF16x3 : parts; }
     SplitPlanes rows(int c0, int n) const {
         SplitPlanes s = *this;
@@ -266,10 +267,17 @@ struct SplitPlanes {        // [part][C][ld] 16-bit, the column axis contiguous;
         return s;
     }
 };
+// Device counter of f16x3 saturations for the current device, or null when counting is off (the default).  The f16 pair has f16's exponent range:
+// a finite value beyond +-65504 is clamped by the split (NaN / Inf propagate as on the f32 path); with synthetic O(1) weights it never happens, a real
+// DeBERTa checkpoint with outlier channels should be run once with SBV2_F16X3_SATCOUNT=1 (fallback: SBV2_BERT_GEMM=bf16x6, bf16's range).
+unsigned long long* f16x3_sat_counter();
+int f16x3_sat_enable(int on);                        // returns the previous setting
+unsigned long long f16x3_sat_read(bool reset);       // current device
 inline SplitPlanes alloc_split(Arena& ar, int code, int C, int L) {   // same pitch rule as Arena::plane; code as in set_bfs_parts
     SplitPlanes s;
     const int parts = split_nplanes(code);
     s.f16 = code == kPartsF16x3;
+    s.sat = s.f16 ? f16x3_sat_counter() : nullptr;
     s.parts = parts;
     s.C = C;
     s.L = L;
@@ -310,9 +318,15 @@ __device__ __forceinline__ void split_store4(const SplitPlanes& sp, int64_t off,
         sp_f16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
+            // finite values beyond f16's range saturate; NaN stays NaN and an infinity stays one (fmaxf / fminf alone would turn a NaN into 65504)
+            const float c = (v[e] != v[e] || fabsf(v[e]) == __builtin_inff()) ? v[e] : fminf(fmaxf(v[e], -65504.f), 65504.f);
             h[e] = (_Float16)c;
             l[e] = (_Float16)((c - (float)h[e]) * kF16LoScale);
+        }
+        if (sp.sat) {   // (uniform branch; diagnostics only)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (fabsf(v[e]) > 65504.f && fabsf(v[e]) != __builtin_inff()) atomicAdd(sp.sat, 1ull);
         }
         *reinterpret_cast<sp_f16x4*>(static_cast<_Float16*>(sp.p) + off) = h;
         *reinterpret_cast<sp_f16x4*>(static_cast<_Float16*>(sp.p) + sp.pstride + off) = l;
@@ -331,7 +345,8 @@ __device__ __forceinline__ void split_store4(const SplitPlanes& sp, int64_t off,
 }
 __device__ __forceinline__ void split_store1(const SplitPlanes& sp, int64_t off, float v) {
     if (sp.f16) {
-        const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+        const float c = (v != v || fabsf(v) == __builtin_inff()) ? v : fminf(fmaxf(v, -65504.f), 65504.f);
+        if (sp.sat && fabsf(v) > 65504.f && fabsf(v) != __builtin_inff()) atomicAdd(sp.sat, 1ull);
         const _Float16 h = (_Float16)c;
         static_cast<_Float16*>(sp.p)[off] = h;
         static_cast<_Float16*>(sp.p)[sp.pstride + off] = (_Float16)((c - (float)h) * kF16LoScale);

@@ -173,7 +173,7 @@ int sbv2_deal(int64_t n, const int64_t* costs, int world, int32_t* rank_of) {
 
 int sbv2_gather_plan(int64_t n, const int64_t* pcm_lens, const int32_t* rank_of, int world, int64_t* counts, int64_t* table) {
     API_BEGIN
-    SBV2_REQUIRE(n >= 0 && world >= 1 && counts && (n == 0 || (pcm_lens && rank_of && table)), "bad arguments");
+    SBV2_REQUIRE(n >= 0 && n <= 0x7FFFFFFF && world >= 1 && counts && (n == 0 || (pcm_lens && rank_of && table)), "bad arguments");
     std::vector<int> ro(rank_of, rank_of + n);
     std::vector<int64_t> c, t;
     gather_plan((int)n, pcm_lens, ro.data(), world, c, t);
@@ -283,13 +283,14 @@ int sbv2_comm_gather_pcm(sbv2_comm* c, sbv2_pipeline* p, int64_t ticket, int roo
     if (c->rank == root) {
         // The serial part of an N-GPU step is this rank's device -> host traffic (N x 59 MB at batch 32 x U128 over one PCIe link), so it starts
         // as early as it can: the root's own block goes to the host straight from the run's buffer while the peers' blocks are still on
-        // their xGMI links, and the peers are received in groups of `per` (SBV2_GATHER_GROUP, default 2: each peer has its own link, a
-        // group's receives run in parallel) whose copies to the host overlap the next group's receives.
+        // their xGMI links.  The peers' receives are ONE ncclGroup by default (the shape every RCCL user runs); SBV2_GATHER_GROUP=n posts them in groups
+        // of n whose copies to the host overlap the next group's receives: that variant has never executed with a real peer (no >= 2-GPU box was
+        // available to this build), so it stays opt-in until test_comm_two_ranks_gather_over_rccl has run it.
         float* st = static_cast<float*>(c->stage.get(sizeof(float) * (size_t)std::max<int64_t>(total, 1)));
         std::vector<int64_t> offs(c->world + 1, 0);
         for (int r = 0; r < c->world; ++r) offs[r + 1] = offs[r] + counts[r];
         const bool fits = total <= capacity;
-        static const int per = std::max(1, getenv("SBV2_GATHER_GROUP") ? atoi(getenv("SBV2_GATHER_GROUP")) : 2);
+        static const int per = getenv("SBV2_GATHER_GROUP") && atoi(getenv("SBV2_GATHER_GROUP")) > 0 ? atoi(getenv("SBV2_GATHER_GROUP")) : 1 << 20;
         HIP_CHECK(hipEventRecord(c->gev[c->world], c->stream));          // (the run has finished: c->stream waited for it above)
         HIP_CHECK(hipStreamWaitEvent(c->copy, c->gev[c->world], 0));
         if (fits && mine > 0)

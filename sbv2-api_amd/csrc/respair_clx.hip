@@ -13,7 +13,9 @@
 //     window of an interior tile is one contiguous byte range read with base + immediate offsets, no integer division / 64-bit VALU address math.
 //   * Weights go L2 -> LDS by LDS-DMA (global_load_lds, no staging registers, no ds_write) in groups of <= 4 taps, double buffered: the next group
 //     lands while the current one is multiplied; one barrier per group.
-//   * C = 64 runs 128-position tiles on 4 waves (70 KB of LDS: two workgroups per CU whose phases interleave) instead of 256 positions on 8.
+//   * C = 64 runs 128-position tiles on 4 waves (52 KB of LDS: three workgroups per CU whose phases interleave) instead of 256 positions on 8.
+//   * C = 16 multiplies two taps per MFMA (v_mfma_f32_16x16x32_bf16, weights packed as tap pairs at load): no half-empty A tiles.
+//   * The fragment reads of the next tap are dealt one per gap between the current tap's MFMAs (sched_barrier pins them).
 //   * Tiles are dealt to the XCDs in contiguous ranges (neighbouring tiles share their halo rows through one L2).
 // Fragment reads, window writes and the waits that cover them are inline asm: with an LDS-DMA pending hipcc puts s_waitcnt vmcnt(0) in front of every
 // LDS access it can see, which would serialise the weight stream with the MFMAs (conv_clx.hip has the same note).
@@ -567,7 +569,9 @@ bool respair_clx_usable(const ResPairParams& p) {
 
 template <int DG>
 static void launch_rpx_any(const ResPairParams& p, hipStream_t stream) {
-    static const int g64 = getenv("SBV2_RPX_G64") ? atoi(getenv("SBV2_RPX_G64")) : 4;   // experiments: taps per weight group at C = 64 (2: 52 KB of LDS, three workgroups per CU)
+    // taps per weight group at C = 64: 2 (default) = 52 KB of LDS, three workgroups per CU; 4 = 70 KB, two per CU and half the barriers
+    // (same box: 11.75 vs 12.3 ms per step for the stage, profiles/r04b_*)
+    static const int g64 = getenv("SBV2_RPX_G64") ? atoi(getenv("SBV2_RPX_G64")) : 2;
 #define RPX_CASE(CC, KK) \
     if (p.C == CC && p.k == KK) return launch_rpx<CC, KK, DG, 4>(p, stream);
     if (p.C == 64 && g64 == 2) {

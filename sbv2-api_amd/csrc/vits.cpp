@@ -916,7 +916,17 @@ int64_t VitsModel::stream_begin(int chunk_frames) {
     const int64_t Tf = fl_.len[0];
     ensure_plan(chunk_, chunk_frames, 1);
     const bool want_burst = burst > 1 && Tf > chunk_frames;   // an utterance of one chunk never needs it
-    if (want_burst) ensure_plan(burst_, chunk_frames, burst);
+    if (want_burst) {
+        // windows per replay: no more than the chunks that follow the first one (a 2-chunk utterance does not decode 7 all-zero windows, nor pay
+        // their workspace: 256 MiB per window at 256-frame chunks), from {2, 4, 8, 16} so that utterances of different lengths share few captures;
+        // a larger plan of the same chunk size that this handle already holds is reused as it is
+        const int64_t rest = (Tf - 1) / chunk_frames;
+        int nw = 2;
+        while (nw < burst && nw < rest) nw *= 2;
+        nw = std::min(nw, burst);
+        if (burst_ && burst_->chunk == chunk_frames && burst_->nwin >= nw) nw = burst_->nwin;
+        ensure_plan(burst_, chunk_frames, nw);
+    }
     stream_bursts_ = want_burst;
     stream_enqueue(*chunk_, 0, 0);                            // the first chunk starts right behind the flow ...
     if (want_burst) stream_enqueue(*burst_, chunk_frames, 0); // ... and the first burst right behind it

@@ -1,6 +1,8 @@
 """BASELINE configs[4] (streaming long-form, >= 2000 phonemes) measurement: whole-sequence synthesis vs the chunked decoder replaying its
 captured hipGraph; prints one JSON line (kept under profiles/ as r02_longform*.json).
-usage: python tests/long_form_check.py [n_phones] [chunk_frames]         env SBV2_STREAM_GRAPH=0 -> eager chunk decode (A/B)"""
+The DeBERTa input has the front end's own length (one token per character: n_phones // 2 tokens, 1000 for 2000 phonemes; the reference itself
+splits on newlines, tts.rs:290-321, and its TensorRT profile caps BERT at 100 tokens, model.rs:14-16: pass a third argument to cap the characters).
+usage: python tests/long_form_check.py [n_phones] [chunk_frames] [chars]         env SBV2_STREAM_GRAPH=0 -> eager chunk decode (A/B)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,11 +12,12 @@ from sbv2_api_amd import model, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+chars = int(sys.argv[3]) if len(sys.argv) > 3 else None
 bc, bw = weights("bert", "full")
 vc, vw = weights("vits", "full")
 bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
 pipe = model.Pipeline(bs, vs)
-u = synth.make_utterance(n, bc, vc, seed=4242, chars=98)
+u = synth.make_utterance(n, bc, vc, seed=4242, chars=chars)
 b = pipe.prepare([u], forced=True)
 pipe.run(b); pipe.sync()
 t = time.perf_counter(); pipe.run(b); whole = pipe.fetch(b)[0]; t_whole = time.perf_counter() - t
@@ -46,7 +49,7 @@ stream()                                  # first use of this chunk size: warm-u
 # passes, the median by total time is reported and all totals are kept.
 runs = sorted((stream() for _ in range(5)), key=lambda r: r[3])
 got, t_begin, t_first, t_all, (graph, ws), nchunks = runs[2]
-out = {"phones": n, "T_text": int(u["T_text"]), "frames": whole.shape[0] // 512, "audio_s": round(audio, 2), "chunk_frames": chunk, "chunks": nchunks,
+out = {"phones": n, "T_text": int(u["T_text"]), "bert_tokens": int(u["S"]), "frames": whole.shape[0] // 512, "audio_s": round(audio, 2), "chunk_frames": chunk, "chunks": nchunks,
        "whole_sequence_ms": round(t_whole * 1e3, 1), "whole_sequence_rtf": round(t_whole / audio, 6),
        "stream_text_and_flow_ms": round(t_begin * 1e3, 1), "stream_time_to_first_chunk_ms": round(t_first * 1e3, 1),
        "stream_total_ms": round(t_all * 1e3, 1), "stream_total_ms_all_passes": [round(r[3] * 1e3, 1) for r in runs], "stream_rtf": round(t_all / audio, 6),

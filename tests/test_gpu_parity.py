@@ -174,6 +174,21 @@ def test_gemm_bfs_f16x3_range():
     np.testing.assert_allclose(yh, w.astype(np.float64) @ xs.astype(np.float64), rtol=0, atol=2e-6 * 65504.0 / 8)
     cols = [c for c in range(N) if c != 2]      # columns the huge value does not touch: full accuracy, the tiny row included
     np.testing.assert_allclose(yh[:, cols], ref[:, cols], rtol=0, atol=1e-5)
+    # the saturation is countable (sbv2_debug_f16x3_saturation), and what is not finite is not clamped: a NaN / an infinity reaches the result
+    lib, cnt = _lib.lib(), C.c_uint64(0)
+    _lib.check(lib.sbv2_debug_f16x3_saturation(0, 1, C.byref(cnt)))
+    try:
+        _gemm_bfs(x, w, None, None, 4)
+        _lib.check(lib.sbv2_debug_f16x3_saturation(0, -1, C.byref(cnt)))
+        assert cnt.value == 1
+        xn = x.copy(); xn[3, 2] = 1.0; xn[7, 4] = np.nan; xn[9, 6] = -np.inf
+        yn = _gemm_bfs(xn, w, None, None, 4)
+        _lib.check(lib.sbv2_debug_f16x3_saturation(0, -1, C.byref(cnt)))
+        assert cnt.value == 0
+        assert np.isnan(yn[:, 4]).all() and not np.isfinite(yn[:, 6]).any()
+        assert np.isfinite(yn[:, [c for c in range(N) if c not in (4, 6)]]).all()
+    finally:
+        _lib.check(lib.sbv2_debug_f16x3_saturation(0, 0, None))
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,L", [(1024, 1024, 1, 1, 66), (1024, 3072, 1, 1, 130), (4096, 1024, 1, 1, 66), (1024, 4096, 1, 1, 35),
@@ -919,12 +934,15 @@ def test_streaming_tiny_chunked_equals_whole():
 def test_config4_streaming_long_form_full_shapes():
     """BASELINE configs[4]: >= 2000 phonemes (T_text 4001, 14001 frames, 162.6 s of audio) streamed in 256-frame chunks through the
     captured decoder graph == the whole-sequence decode within 1e-5 (same arithmetic, same summation order: expected bit-equal);
-    a 600-symbol utterance streamed vs the oracle within north_star's 1e-3; the chunk decoder's workspace does not grow with the utterance."""
+    a 600-symbol utterance streamed vs the oracle within north_star's 1e-3; the chunk decoder's workspace does not grow with the utterance.
+    The DeBERTa inputs have the front end's own length (one token per character): 1000 tokens for the 2000 phonemes, 300 for the 600 symbols, so the
+    long-sequence attention (k_deberta_attn_long) is inside every one of these runs (the reference caps at 100 tokens per sentence, model.rs:14-16)."""
     bc, bw = weights("bert", "full")
     vc, vw = weights("vits", "full")
     bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
     pipe = model.Pipeline(bs, vs)
-    u = synth.make_utterance(2000, bc, vc, seed=991, chars=98)
+    u = synth.make_utterance(2000, bc, vc, seed=991)
+    assert u["S"] == 1000
     b = pipe.prepare([u], forced=True)
     pipe.run(b)
     whole = pipe.fetch(b)[0]
@@ -934,7 +952,8 @@ def test_config4_streaming_long_form_full_shapes():
     err = float(np.abs(got - whole).max())
     print(f"configs[4]: 2000 phonemes, 55 chunks of 256 frames, chunked vs whole-sequence max-abs {err:.3e}, chunk workspace {ws_long / 2**20:.0f} MiB")
     assert err <= 1e-5
-    u6 = synth.make_utterance(600, bc, vc, seed=990, chars=98)
+    u6 = synth.make_utterance(600, bc, vc, seed=990)
+    assert u6["S"] == 300
     got6, (_, graph6, ws_short), _ = _stream_all(bs, vs, u6, 256, forced=True)
     assert graph6 and ws_short == ws_long          # bounded by the window, not by the utterance
     O.set_conv_backend("torch")
@@ -948,7 +967,7 @@ def test_config4_streaming_long_form_full_shapes():
     assert e6 < 1e-3 and e6 < 5e-5
     # predicted durations + both noise streams (seeded) at the full shape: the streamed decode equals the whole-sequence call of the same seed
     kw = dict(sdp_ratio=0.2, noise_scale=0.667, noise_scale_w=0.8, noise_seed=1234)
-    un = synth.make_utterance(300, bc, vc, seed=992, chars=98)
+    un = synth.make_utterance(300, bc, vc, seed=992)
     bn = pipe.prepare([un], **kw)
     pipe.run(bn)
     whole_n = pipe.fetch(bn)[0]
