@@ -111,27 +111,43 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     // LayerNorm of the relative embeddings on the host (modeling_deberta_v2.py:595-599), stored as a plane [H][2*span]
     const int H = cfg_.hidden;
     const int span = cfg_.buckets > 0 ? cfg_.buckets : cfg_.max_rel;
-    const HostTensor& re = blob.get("deberta.encoder.rel_embeddings.weight");
-    const HostTensor& rg = blob.get("deberta.encoder.LayerNorm.weight");
-    const HostTensor& rb = blob.get("deberta.encoder.LayerNorm.bias");
-    SBV2_REQUIRE(re.dims.size() == 2 && re.dims[0] >= 2 * span && re.dims[1] == H, "rel_embeddings shape");
-    SBV2_REQUIRE(rg.numel() == H && rb.numel() == H, "encoder.LayerNorm shape");
+    // An onnxsim-processed export (convert_deberta.py:52) has that whole input-independent subgraph folded away: no rel_embeddings / encoder.LayerNorm,
+    // but per layer the PROJECTED positions key_proj(LN(rel)) / query_proj(LN(rel)) as constants, which the importer stores as
+    // "<layer>.attention.self.pos_key" / ".pos_query" [2 span][H] (csrc/import.cpp, rule 6).  Those are taken as they are.
+    const bool folded = !blob.has("deberta.encoder.rel_embeddings.weight");
     Plane rel;
     rel.C = H;
     rel.L = 2 * span;
     rel.ld = round_up(2 * span, 64);
-    std::vector<float> hp((size_t)H * rel.ld, 0.f);
-    for (int r = 0; r < 2 * span; ++r) {
-        const float* row = re.data + (size_t)r * H;
-        float mean = 0.f;
-        for (int c = 0; c < H; ++c) mean += row[c];
-        mean /= H;
-        float var = 0.f;
-        for (int c = 0; c < H; ++c) var += (row[c] - mean) * (row[c] - mean);
-        const float rstd = 1.0f / std::sqrt(var / H + cfg_.eps);
-        for (int c = 0; c < H; ++c) hp[(size_t)c * rel.ld + r] = (row[c] - mean) * rstd * rg.data[c] + rb.data[c];
+    if (!folded) {
+        const HostTensor& re = blob.get("deberta.encoder.rel_embeddings.weight");
+        const HostTensor& rg = blob.get("deberta.encoder.LayerNorm.weight");
+        const HostTensor& rb = blob.get("deberta.encoder.LayerNorm.bias");
+        SBV2_REQUIRE(re.dims.size() == 2 && re.dims[0] >= 2 * span && re.dims[1] == H, "rel_embeddings shape");
+        SBV2_REQUIRE(rg.numel() == H && rb.numel() == H, "encoder.LayerNorm shape");
+        std::vector<float> hp((size_t)H * rel.ld, 0.f);
+        for (int r = 0; r < 2 * span; ++r) {
+            const float* row = re.data + (size_t)r * H;
+            float mean = 0.f;
+            for (int c = 0; c < H; ++c) mean += row[c];
+            mean /= H;
+            float var = 0.f;
+            for (int c = 0; c < H; ++c) var += (row[c] - mean) * (row[c] - mean);
+            const float rstd = 1.0f / std::sqrt(var / H + cfg_.eps);
+            for (int c = 0; c < H; ++c) hp[(size_t)c * rel.ld + r] = (row[c] - mean) * rstd * rg.data[c] + rb.data[c];
+        }
+        rel.p = ws_->upload(hp.data(), hp.size());
     }
-    rel.p = ws_->upload(hp.data(), hp.size());
+    auto folded_plane = [&](const std::string& name) {   // [2 span][H] rows -> the k-major plane [H][ld] the attention kernels read
+        const HostTensor& t = blob.get(name);
+        SBV2_REQUIRE(t.dims.size() >= 2 && t.dims[0] == 2 * span && t.numel() == (int64_t)2 * span * H, name + ": expected [2 * position_buckets][hidden]");
+        std::vector<float> hp((size_t)H * rel.ld, 0.f);
+        for (int r = 0; r < 2 * span; ++r)
+            for (int c = 0; c < H; ++c) hp[(size_t)c * rel.ld + r] = t.data[(size_t)r * H + c];
+        Plane pl = rel;
+        pl.p = ws_->upload(hp.data(), hp.size());
+        return pl;
+    };
 
     layers_.resize(cfg_.layers);
     for (int i = 0; i < cfg_.layers; ++i) {
@@ -158,13 +174,18 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
         ws_->expect(L.ffn1, p + "intermediate.dense", cfg_.inter, H, 1);
         ws_->expect(L.ffn2, p + "output.dense", H, cfg_.inter, 1);
         // share_att_key: positions go through the layer's own key/query projections (:292-299)
-        std::vector<float> zero((size_t)H * rel.ld, 0.f);
-        L.pos_k = rel;
-        L.pos_k.p = ws_->upload(zero.data(), zero.size());
-        L.pos_q = rel;
-        L.pos_q.p = ws_->upload(zero.data(), zero.size());
-        conv_plain(L.k, rel, L.pos_k, 1, 0, nullptr, 1, stream_);
-        conv_plain(L.q, rel, L.pos_q, 1, 0, nullptr, 1, stream_);
+        if (folded) {
+            L.pos_k = folded_plane(p + "attention.self.pos_key");
+            L.pos_q = folded_plane(p + "attention.self.pos_query");
+        } else {
+            std::vector<float> zero((size_t)H * rel.ld, 0.f);
+            L.pos_k = rel;
+            L.pos_k.p = ws_->upload(zero.data(), zero.size());
+            L.pos_q = rel;
+            L.pos_q.p = ws_->upload(zero.data(), zero.size());
+            conv_plain(L.k, rel, L.pos_k, 1, 0, nullptr, 1, stream_);
+            conv_plain(L.q, rel, L.pos_q, 1, 0, nullptr, 1, stream_);
+        }
     }
     HIP_CHECK(hipStreamSynchronize(stream_));
 }

@@ -15,6 +15,12 @@
 //   * weight_norm'ed convolutions (every HiFi-GAN conv) export as g * v / ||v||: either the pair <name>.weight_g / <name>.weight_v is still
 //     there (folded here), or onnxsim has folded it into an anonymous constant feeding a Conv / ConvTranspose whose bias input keeps its name
 //     -> weight name from the bias name; the bias-free conv_post is the one anonymous Conv with a single output channel.
+//   * Subgraphs that depend on initializers only are constant-folded by onnxsim.  DeBERTa: rel_embeddings -> encoder.LayerNorm -> every layer's
+//     key_proj / query_proj of the positions: what remains is one anonymous constant per layer and kind, the constant operand of the c2p / p2c MatMul
+//     (possibly behind Tile / Expand / Transpose); located by following the MatMul's dynamic operand up to the Add of the layer's named query_proj /
+//     key_proj bias, stored as "<layer>.attention.self.pos_key" / ".pos_query" [2 * buckets][heads][d] (rule 6 in name_tensors; BertModel takes them
+//     instead of projecting the positions itself; the head count, which an unfolded file does not show, is recovered on the way).  VITS: exp(-logs) of
+//     the stochastic duration predictor's ElementwiseAffine -> "sdp.flows.0.exp_neg_logs" (rule 7).
 // The hyper-parameters (the SBV2W001 container's JSON) are derived from tensor shapes and node attributes (strides, dilations, epsilon).
 // PARITY STATUS: no real deberta.onnx / model_*.onnx exists in the build environment; these rules follow the exporters' documented behaviour
 // and are exercised on synthetic files written by tests/onnx_writer.py (builder-authored).  A file that does not fit fails loudly with the
@@ -451,6 +457,117 @@ Named name_tensors(const OnnxGraph& g) {
             for (int64_t m = 0; m < N; ++m) t[(size_t)(m * K + k)] = src[(size_t)(k * N + m)];
         out.put(nd.in[1], {N, K}, std::move(t));
     }
+    // 6. DeBERTa after onnxsim: the relative-position subgraph rel_embeddings -> encoder.LayerNorm -> key_proj / query_proj of every layer depends on
+    //    initializers only and is constant-folded (convert_deberta.py:52); what is left of it is, per layer, one anonymous constant holding the projected
+    //    positions as the constant operand of the c2p MatMul (dynamic side: the layer's query) and one for the p2c MatMul (dynamic side: its key),
+    //    possibly behind Tile / Expand (the batch repeat) and Transpose nodes.  They are located by topology: the dynamic side is followed up to the
+    //    Add of a named query_proj / key_proj bias (that gives layer and kind), the constant side down to its initializer; the constant [heads, R, d]
+    //    (any order of the last two axes) is stored as "<layer>.attention.self.pos_key" / ".pos_query" = rows [R][heads * d] (modeling_deberta_v2.py:
+    //    292-299, 318-343: pos_key_layer = transpose_for_scores(key_proj(rel_embeddings)), used unscaled).
+    {
+        std::map<std::string, const OnnxNode*> producer;
+        for (const auto& nd : g.nodes)
+            for (const auto& o : nd.out) producer[o] = &nd;
+        auto pass_through = [](const std::string& op) {
+            return op == "Transpose" || op == "Tile" || op == "Expand" || op == "Reshape" || op == "Cast" || op == "Identity" || op == "Unsqueeze" || op == "Squeeze" ||
+                   op == "Div" || op == "Mul";
+        };
+        // the initializer behind `n`; swaps = Transpose nodes on the way that exchange the last two axes
+        auto const_side = [&](std::string n, int& swaps) -> const OnnxTensor* {
+            swaps = 0;
+            for (int hop = 0; hop < 8; ++hop) {
+                if (const OnnxTensor* t = init_of(n)) return is_float_tensor(*t) ? t : nullptr;
+                auto it = producer.find(n);
+                if (it == producer.end() || !pass_through(it->second->op) || it->second->in.empty()) return nullptr;
+                if (it->second->op == "Transpose")
+                    if (const OnnxAttr* pa = it->second->attr("perm")) {
+                        const size_t r = pa->ints.size();
+                        if (r >= 2 && pa->ints[r - 1] == (int64_t)r - 2 && pa->ints[r - 2] == (int64_t)r - 1) ++swaps;
+                    }
+                n = it->second->in[0];
+            }
+            return nullptr;
+        };
+        auto dyn_side = [&](std::string n, std::string& layer_prefix, bool& is_query) -> bool {
+            for (int hop = 0; hop < 12; ++hop) {
+                auto it = producer.find(n);
+                if (it == producer.end()) return false;
+                const OnnxNode* nd = it->second;
+                if (nd->op == "Add") {
+                    for (const auto& bi : nd->in) {
+                        if (is_anonymous(bi) || !init_of(bi)) continue;
+                        for (const char* kind : {"query_proj.bias", "key_proj.bias"})
+                            if (ends_with(bi, std::string(".attention.self.") + kind)) {
+                                layer_prefix = bi.substr(0, bi.size() - std::strlen(kind));
+                                is_query = kind[0] == 'q';
+                                return true;
+                            }
+                    }
+                    return false;
+                }
+                if (!pass_through(nd->op) || nd->in.empty()) return false;
+                n = nd->in[0];
+            }
+            return false;
+        };
+        for (const auto& nd : g.nodes) {
+            if (nd.op != "MatMul" || nd.in.size() != 2) continue;
+            for (int side = 0; side < 2; ++side) {
+                int swaps = 0;
+                const OnnxTensor* c = const_side(nd.in[side], swaps);
+                if (!c || c->dims.size() < 3) continue;
+                std::vector<int64_t> d3;
+                for (int64_t v : c->dims)
+                    if (!(d3.empty() && v == 1)) d3.push_back(v);     // leading 1s (a folded batch axis) dropped
+                if (d3.size() != 3) continue;
+                std::string lp;
+                bool isq = false;
+                if (!dyn_side(nd.in[1 - side], lp, isq)) continue;
+                const std::string nm = lp + (isq ? "pos_key" : "pos_query");   // the QUERY meets the projected position KEYS (c2p) and vice versa
+                if (out.has(nm)) continue;
+                auto qb = out.dims.find(lp + "query_proj.bias");
+                if (qb == out.dims.end() || qb->second.empty()) continue;
+                const int64_t H = qb->second[0], heads = d3[0];
+                if (heads < 1 || H % heads) continue;
+                const int64_t dh = H / heads, R = c->numel() / H;
+                if (R * H != c->numel()) continue;
+                // orientation of the constant's last two axes: from the sizes, or (R == d) from the topology: at the MatMul the operand is [.., d, R] as the
+                // second factor ([.., S, d] x [.., d, R]) and [.., R, d] as the first; every last-two Transpose on the way flips it
+                bool r_first;
+                if (R != dh) {
+                    r_first = d3[1] == R && d3[2] == dh;
+                    if (!r_first && !(d3[1] == dh && d3[2] == R)) continue;
+                } else {
+                    if (d3[1] != R || d3[2] != R) continue;
+                    r_first = (side == 1) == ((swaps & 1) == 1);
+                }
+                const std::vector<float> src = tensor_f32(*c);
+                std::vector<float> P((size_t)(R * H));
+                for (int64_t h = 0; h < heads; ++h)
+                    for (int64_t r = 0; r < R; ++r)
+                        for (int64_t j = 0; j < dh; ++j)
+                            P[(size_t)(r * H + h * dh + j)] = r_first ? src[(size_t)((h * R + r) * dh + j)] : src[(size_t)((h * dh + j) * R + r)];
+                out.put(nm, {R, heads, dh}, std::move(P));   // (the head count is recoverable from a folded file)
+            }
+        }
+    }
+    // 7. VITS after onnxsim: ElementwiseAffine's exp(-logs) of the stochastic duration predictor's first flow is folded into an anonymous constant
+    //    (x - m) * exp(-logs) (modeling_vits.py:689-704, reverse branch): the Mul behind the Sub of the named translate vector
+    for (const auto& nd : g.nodes) {
+        if (nd.op != "Sub" || nd.in.size() != 2 || nd.out.empty()) continue;
+        const std::string& mn = nd.in[1];
+        if (!ends_with(mn, "flows.0.m") || is_anonymous(mn) || !init_of(mn)) continue;
+        const std::string base = mn.substr(0, mn.size() - 1);
+        if (out.has(base + "logs") || out.has(base + "exp_neg_logs")) continue;
+        for (const OnnxNode* c : consumers[nd.out[0]]) {
+            if (c->op != "Mul") continue;
+            for (const auto& ci : c->in) {
+                const OnnxTensor* e = init_of(ci);
+                if (ci == nd.out[0] || !e || !is_float_tensor(*e) || e->numel() != init_of(mn)->numel()) continue;
+                out.put(base + "exp_neg_logs", init_of(mn)->dims, tensor_f32(*e));
+            }
+        }
+    }
     return out;
 }
 
@@ -463,10 +580,10 @@ int count_indexed(const Named& t, const std::string& prefix, const std::string& 
 const std::vector<int64_t>& dims_of(const Named& t, const std::string& name) {
     auto it = t.dims.find(name);
     if (it == t.dims.end()) throw Error("ONNX import: tensor '" + name + "' not found in the graph (initializer names after onnxsim differ from what "
-                                        "csrc/import.cpp expects; see the naming rules at the top of that file).  onnxsim constant-folds subgraphs that "
-                                        "depend only on initializers (DeBERTa: rel_embeddings -> encoder.LayerNorm -> per-layer position projections; "
-                                        "VITS: exp(-sdp.flows.0.logs)); an export folded that way is NOT supported: convert it with the onnxsim step "
-                                        "skipped (INTEGRATION.md, 'Real weights')");
+                                        "csrc/import.cpp expects; see the naming rules at the top of that file).  The constant-folded forms onnxsim leaves "
+                                        "(DeBERTa: projected relative positions as the constant operand of each layer's c2p / p2c MatMul; VITS: "
+                                        "exp(-sdp.flows.0.logs) behind the Sub of flows.0.m) are recognised by topology (rules 6 and 7); if this file "
+                                        "folds them differently, convert it with the onnxsim step skipped (INTEGRATION.md, 'Real weights')");
     return it->second;
 }
 
@@ -595,8 +712,11 @@ Blob import_bert_onnx(const uint8_t* bytes, size_t n) {
     const int layers = count_indexed(t, "deberta.encoder.layer.", ".attention.self.query_proj.weight");
     SBV2_REQUIRE(layers >= 1, "ONNX import: no deberta.encoder.layer.* found");
     const int inter = (int)D("deberta.encoder.layer.0.intermediate.dense.weight")[0];
-    const int span = (int)D("deberta.encoder.rel_embeddings.weight")[0] / 2;
-    const int heads = hidden / 64;   // attention_head_size 64 in every published DeBERTa-v2 config (not recoverable from the weights)
+    // (an onnxsim-folded file has no rel_embeddings: the projected positions of layer 0 carry the same row count)
+    const int span = (int)(t.has("deberta.encoder.rel_embeddings.weight") ? D("deberta.encoder.rel_embeddings.weight")[0]
+                                                                            : D("deberta.encoder.layer.0.attention.self.pos_key")[0]) / 2;
+    // attention_head_size 64 in every published DeBERTa-v2 config (not recoverable from an unfolded file's weights; a folded one shows the head count)
+    const int heads = t.has("deberta.encoder.layer.0.attention.self.pos_key") ? (int)D("deberta.encoder.layer.0.attention.self.pos_key")[1] : hidden / 64;
     int conv_k = 0;
     if (t.has("deberta.encoder.conv.conv.weight")) conv_k = (int)D("deberta.encoder.conv.conv.weight")[2];
     bool has_tanh = false;

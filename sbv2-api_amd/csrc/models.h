@@ -341,7 +341,7 @@ class VitsModel {
     PackedConv dp_c1_, dp_c2_, dp_proj_;
     float *dp_n1g_, *dp_n1b_, *dp_n2g_, *dp_n2b_, *dp_cond_w_, *dp_cond_b_;
     PackedConv sdp_pre_, sdp_proj_;
-    float *sdp_cond_w_, *sdp_cond_b_, *sdp_ea_m_, *sdp_ea_logs_;
+    float *sdp_cond_w_, *sdp_cond_b_, *sdp_ea_m_, *sdp_ea_logs_ = nullptr, *sdp_ea_scale_ = nullptr;
     DDS sdp_dds_;
     std::vector<ConvFlow> sdp_cf_;  // ConvFlow 2..n (index 0 = flows.3)
     std::vector<Coupling> flows_;

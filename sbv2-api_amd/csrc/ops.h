@@ -68,8 +68,8 @@ void spline_inverse(Plane params, float* z0, float* z1, int nbins, float tail, f
                     const unsigned char* mask, int L, hipStream_t s);
 void swap_rows(float* a, float* b, int L, hipStream_t s);
 void flip_channels(Plane in, Plane out, hipStream_t s);
-void affine_reverse(float* z0, float* z1, const float* m, const float* logs, const unsigned char* mask, int L,
-                    hipStream_t s);
+void affine_reverse(float* z0, float* z1, const float* m, const float* logs, const float* scale, const unsigned char* mask, int L,
+                    hipStream_t s);   // (x - m) * exp(-logs), or * scale when logs is null (exp(-logs) folded into the weight file)
 void durations(const float* sdp, const float* dp, float ratio, float length_scale, const unsigned char* mask, int L,
                float* logw, int* dur, hipStream_t s);
 void noise_fill(float* out, int ld, int rows, const int* seg_of, const int* seg_start, const int* seg_len, const int* seg_utt, int L,

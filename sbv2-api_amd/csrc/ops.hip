@@ -592,15 +592,16 @@ void flip_channels(Plane in, Plane out, hipStream_t s) {
     hipLaunchKernelGGL(k_flip_channels, dim3((in.L + 255) / 256, in.C), dim3(256), 0, s, in, out);
 }
 
-__global__ void k_affine_reverse(float* z0, float* z1, const float* m, const float* logs, const unsigned char* mask, int L) {
+__global__ void k_affine_reverse(float* z0, float* z1, const float* m, const float* logs, const float* scale, const unsigned char* mask, int L) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= L) return;
     const bool k = mask[n];
-    z0[n] = k ? (z0[n] - m[0]) * expf(-logs[0]) : 0.f;
-    z1[n] = k ? (z1[n] - m[1]) * expf(-logs[1]) : 0.f;
+    // exp(-logs) is computed here unless the weight file carries it already folded (scale)
+    z0[n] = k ? (z0[n] - m[0]) * (logs ? expf(-logs[0]) : scale[0]) : 0.f;
+    z1[n] = k ? (z1[n] - m[1]) * (logs ? expf(-logs[1]) : scale[1]) : 0.f;
 }
-void affine_reverse(float* z0, float* z1, const float* m, const float* logs, const unsigned char* mask, int L, hipStream_t s) {
-    hipLaunchKernelGGL(k_affine_reverse, dim3((L + 255) / 256), dim3(256), 0, s, z0, z1, m, logs, mask, L);
+void affine_reverse(float* z0, float* z1, const float* m, const float* logs, const float* scale, const unsigned char* mask, int L, hipStream_t s) {
+    hipLaunchKernelGGL(k_affine_reverse, dim3((L + 255) / 256), dim3(256), 0, s, z0, z1, m, logs, scale, mask, L);
 }
 
 // w_ceil = ceil(exp(logw) * mask * length_scale)   (SynthesizerTrn.infer)

@@ -223,7 +223,10 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     w.expect(sdp_pre_, "sdp.pre", Hc, Hc, 1);
     w.expect(sdp_proj_, "sdp.proj", Hc, Hc, 1);
     sdp_cond_w_ = w.tensor("sdp.cond.weight", {Hc, Gc}); sdp_cond_b_ = w.tensor("sdp.cond.bias", {Hc});
-    sdp_ea_m_ = w.tensor("sdp.flows.0.m", {2}); sdp_ea_logs_ = w.tensor("sdp.flows.0.logs", {2});
+    sdp_ea_m_ = w.tensor("sdp.flows.0.m", {2});
+    // (an onnxsim-processed export has exp(-logs) folded into a constant: import.cpp rule 7 stores it as flows.0.exp_neg_logs)
+    if (blob.has("sdp.flows.0.logs") || !blob.has("sdp.flows.0.exp_neg_logs")) sdp_ea_logs_ = w.tensor("sdp.flows.0.logs", {2});
+    else sdp_ea_scale_ = w.tensor("sdp.flows.0.exp_neg_logs", {2});
     sdp_dds_ = load_dds("sdp.convs.", cfg_.hidden);
     for (int i = 2; i <= cfg_.sdp_flows; ++i) {  // ConvFlow 1 is the "useless vflow" dropped in reverse mode
         const std::string p = "sdp.flows." + std::to_string(2 * i - 1) + ".";
@@ -740,7 +743,7 @@ void VitsModel::forward(const VitsBatch& b) {
         spline_inverse(PR, z0, z1, cfg_.sdp_bins, cfg_.sdp_tail, inv_sqrt_f, tl.d_mask, Lt, stream_);
     }
     swap_rows(z0, z1, Lt, stream_);
-    affine_reverse(z0, z1, sdp_ea_m_, sdp_ea_logs_, tl.d_mask, Lt, stream_);
+    affine_reverse(z0, z1, sdp_ea_m_, sdp_ea_logs_, sdp_ea_scale_, tl.d_mask, Lt, stream_);
 
     // ---- durations (the one device -> host sync of the batch: T_frames is data dependent) ----------------
     float* d_logw = ar.array<float>(Lt);

@@ -106,8 +106,10 @@ class _Anon:
         return f"onnx::{op}_{self.n}"
 
 
-def vits_onnx(W: dict, cfg: dict, folded: bool, raw=True) -> bytes:
-    """model_<name>.onnx of the JP-Extra synthesizer holding the weights `W` (state-dict names)."""
+def vits_onnx(W: dict, cfg: dict, folded: bool, raw=True, fold_affine=None) -> bytes:
+    """model_<name>.onnx of the JP-Extra synthesizer holding the weights `W` (state-dict names).  folded: the onnxsim form (convert_model.py:156):
+    weight_norm products and (fold_affine, default = folded) exp(-sdp.flows.0.logs) are anonymous constants."""
+    fold_affine = folded if fold_affine is None else fold_affine
     anon = _Anon()
     inits, nodes = [], []
     nk = len(cfg["res_kernels"])
@@ -119,6 +121,13 @@ def vits_onnx(W: dict, cfg: dict, folded: bool, raw=True) -> bytes:
     for name, a in W.items():
         a = np.asarray(a, np.float32)
         base = name[:-7] if name.endswith(".weight") else None
+        if fold_affine and name == "sdp.flows.0.logs":
+            # onnxsim folds exp(-log_scale) of the first flow (ElementwiseAffine, reverse) into an anonymous constant behind the Sub of the translate vector
+            en = anon("Mul")
+            inits.append(tensor_proto(en, np.exp(-a).astype(np.float32), raw))
+            nodes.append(node_proto("Sub", ["/sdp/z", "sdp.flows.0.m"], ["/sdp/sub"]))
+            nodes.append(node_proto("Mul", ["/sdp/sub", en], ["/sdp/aff"]))
+            continue
         if base in wn:
             is_t = base.startswith("dec.ups.")
             i_up = int(base.split(".")[2]) if is_t else 0
@@ -151,12 +160,36 @@ def vits_onnx(W: dict, cfg: dict, folded: bool, raw=True) -> bytes:
     return model_proto(nodes, inits)
 
 
-def deberta_onnx(W: dict, cfg: dict, prefix="", raw=True) -> bytes:
-    """deberta.onnx: every nn.Linear exported as MatMul(x, W^T) + Add(named bias); embeddings, LayerNorms and the ConvLayer keep names."""
+def folded_positions(W: dict, cfg: dict) -> dict:
+    """What onnxsim leaves of DeBERTa's relative-position subgraph (modeling_deberta_v2.py:595-599, 292-299): per layer key_proj / query_proj of
+    LayerNorm(rel_embeddings), rows [2 * buckets][hidden] in f32 (the arithmetic of the constant folder: numpy here)."""
+    H, eps = cfg["hidden"], np.float32(cfg["ln_eps"])
+    R = 2 * cfg["position_buckets"]
+    rel = np.asarray(W["deberta.encoder.rel_embeddings.weight"], np.float32)[:R]
+    mean = rel.mean(-1, keepdims=True, dtype=np.float32)
+    var = ((rel - mean) ** 2).mean(-1, keepdims=True, dtype=np.float32)
+    ln = ((rel - mean) / np.sqrt(var + eps) * W["deberta.encoder.LayerNorm.weight"] + W["deberta.encoder.LayerNorm.bias"]).astype(np.float32)
+    out = {}
+    for i in range(cfg["layers"]):
+        p = f"deberta.encoder.layer.{i}.attention.self."
+        for kind, dst in (("key_proj", "pos_key"), ("query_proj", "pos_query")):
+            out[p + dst] = (ln @ np.asarray(W[p + kind + ".weight"], np.float32).T + W[p + kind + ".bias"]).astype(np.float32)
+    return out
+
+
+def deberta_onnx(W: dict, cfg: dict, prefix="", raw=True, folded=None) -> bytes:
+    """deberta.onnx: every nn.Linear exported as MatMul(x, W^T) + Add(named bias); embeddings, LayerNorms and the ConvLayer keep names.
+    folded = None: rel_embeddings / encoder.LayerNorm are in the file (an export without onnxsim).  "direct" / "tiled": the onnxsim form
+    (convert_deberta.py:52): those three tensors are gone and every layer has two anonymous constants, the projected positions, feeding its c2p / p2c
+    MatMuls: as [heads, d, R] directly ("direct") or as [1, heads, R, d] behind Tile (the batch repeat) + Transpose ("tiled")."""
     anon = _Anon()
     inits, nodes = [], []
     k = 0
+    lin_out = {}
+    gone = {"deberta.encoder.rel_embeddings.weight", "deberta.encoder.LayerNorm.weight", "deberta.encoder.LayerNorm.bias"} if folded else set()
     for name, a in W.items():
+        if name in gone:
+            continue
         a = np.asarray(a, np.float32)
         is_linear = name.endswith(".weight") and a.ndim == 2 and (name[:-7] + ".bias") in W and "embeddings" not in name
         if is_linear:
@@ -165,8 +198,31 @@ def deberta_onnx(W: dict, cfg: dict, prefix="", raw=True) -> bytes:
             k += 1
             nodes.append(node_proto("MatMul", [f"/h_{k}", wt], [f"/mm_{k}"]))
             nodes.append(node_proto("Add", [prefix + name[:-7] + ".bias", f"/mm_{k}"], [f"/lin_{k}"]))
+            lin_out[name[:-7]] = f"/lin_{k}"
         else:
             inits.append(tensor_proto(prefix + name, a, raw))
+    if folded:
+        heads, H = cfg["heads"], cfg["hidden"]
+        d, R = H // heads, 2 * cfg["position_buckets"]
+        inits.append(tensor_proto(anon("Reshape"), np.array([0, -1, heads, d], np.int64)))
+        shape_name = f"onnx::Reshape_{anon.n}"
+        inits.append(tensor_proto("/reps", np.array([1, 1, 1, 1], np.int64)))
+        for name, P in folded_positions(W, cfg).items():
+            layer = name.rsplit(".", 1)[0] + "."
+            dyn = lin_out[layer + ("query_proj" if name.endswith("pos_key") else "key_proj")]      # c2p: query x position keys; p2c: key x position queries
+            tag = name.replace(".", "_")
+            nodes.append(node_proto("Reshape", [dyn, shape_name], [f"/r_{tag}"]))
+            nodes.append(node_proto("Transpose", [f"/r_{tag}"], [f"/t_{tag}"], [attr_ints("perm", [0, 2, 1, 3])]))
+            P3 = P.reshape(R, heads, d).transpose(1, 0, 2)                                             # [heads, R, d]
+            cn = anon("MatMul")
+            if folded == "direct":
+                inits.append(tensor_proto(cn, np.ascontiguousarray(P3.transpose(0, 2, 1)), raw))      # [heads, d, R]
+                nodes.append(node_proto("MatMul", [f"/t_{tag}", cn], [f"/att_{tag}"]))
+            else:
+                inits.append(tensor_proto(cn, np.ascontiguousarray(P3[None]), raw))                   # [1, heads, R, d]
+                nodes.append(node_proto("Tile", [cn, "/reps"], [f"/tile_{tag}"]))
+                nodes.append(node_proto("Transpose", [f"/tile_{tag}"], [f"/pt_{tag}"], [attr_ints("perm", [0, 1, 3, 2])]))
+                nodes.append(node_proto("MatMul", [f"/t_{tag}", f"/pt_{tag}"], [f"/att_{tag}"]))
     nodes.append(node_proto("LayerNormalization", ["/h_0", prefix + "deberta.embeddings.LayerNorm.weight", prefix + "deberta.embeddings.LayerNorm.bias"],
                             ["/ln_0"], [attr_ints("axis", [-1]), attr_float("epsilon", cfg["ln_eps"])]))
     nodes.append(node_proto("Tanh" if cfg.get("conv_act") == "tanh" and cfg.get("conv_kernel_size", 0) > 0 else "Erf", ["/c"], ["/a"]))

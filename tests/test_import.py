@@ -42,6 +42,10 @@ def test_vits_onnx_import_recovers_names_shapes_and_config(folded, raw):
     W = synth.make_vits_weights(cfg, 5)
     kind, got_cfg, got = _import(OW.vits_onnx(W, cfg, folded=folded, raw=raw), 2)
     assert kind == 2
+    if folded:      # onnxsim folds exp(-logs) of the duration predictor's first flow: the constant is found behind the Sub of the named translate vector
+        np.testing.assert_array_equal(got["sdp.flows.0.exp_neg_logs"].ravel(), np.exp(-W["sdp.flows.0.logs"]).astype(np.float32).ravel())
+        assert "sdp.flows.0.logs" not in got
+        W = {k: v for k, v in W.items() if k != "sdp.flows.0.logs"}
     _same_weights(got, W, exact=folded)          # weight_g * v / ||v|| is recomputed in f32: equal to rounding
     for k, v in cfg.items():
         if k == "n_speakers" or k in got_cfg:
@@ -80,7 +84,7 @@ def test_sbv2_container_round_trip_and_errors():
         assert onnx_b == onnx and json.loads(style_b)["shape"] == [3, cfg["style_dim"]]
         # the whole .sbv2 is accepted where VITS model bytes are expected
         _, _, got = _import(f, 2)
-        _same_weights(got, W)
+        _same_weights(got, {k: v for k, v in W.items() if k != "sdp.flows.0.logs"})     # (folded into exp_neg_logs in this form)
     # style.rs:11-28
     d, n, dim = C.c_void_p(), C.c_int64(), C.c_int64()
     sb = (C.c_char * len(style_b)).from_buffer_copy(style_b)
@@ -124,7 +128,7 @@ def test_aivmx_style_vectors_from_onnx_metadata(fortran, version):
     np.testing.assert_array_equal(got, sv)
     kind, _, tensors = _import(aivmx, 2)
     assert kind == 2
-    _same_weights(tensors, W, exact=True)
+    _same_weights(tensors, {k: v for k, v in W.items() if k != "sdp.flows.0.logs"}, exact=True)
     # error paths: no such key; not 2-D (the reference panics "expected 2D array"); not float32
     with pytest.raises(_lib.Sbv2Error, match="aivm_style_vectors"):
         holder.aivmx_style_vectors(OW.vits_onnx(W, vc, folded=True))
@@ -136,13 +140,71 @@ def test_aivmx_style_vectors_from_onnx_metadata(fortran, version):
         holder.aivmx_style_vectors(junk)
 
 
+@pytest.mark.parametrize("cfg,form", [(O.DEBERTA_TINY, "direct"), (O.DEBERTA_TINY, "tiled"), (dict(O.DEBERTA_TINY_CONV, position_buckets=16), "direct"),
+                                      (dict(O.DEBERTA_TINY, position_buckets=16, heads=2), "tiled")])
+def test_deberta_onnx_import_onnxsim_folded_positions(cfg, form):
+    """The onnxsim form of deberta.onnx (convert_deberta.py:52): rel_embeddings / encoder.LayerNorm are gone, every layer has its projected positions as
+    anonymous constants feeding the c2p / p2c MatMuls (directly as [heads, d, R], or as [1, heads, R, d] behind Tile + Transpose).  The importer finds
+    them by topology (dynamic side -> the layer's named query / key bias), also when R == d (orientation from the MatMul operand position), and
+    recovers the head count that an unfolded file does not show."""
+    W = synth.make_deberta_weights(cfg, 3)
+    kind, got_cfg, got = _import(OW.deberta_onnx(W, cfg, folded=form), 1)
+    assert kind == 1 and not any("rel_embeddings" in k or k.startswith("deberta.encoder.LayerNorm") for k in got)
+    for k, v in OW.folded_positions(W, cfg).items():
+        np.testing.assert_array_equal(got[k].reshape(v.shape), v, err_msg=k)
+    _same_weights(got, {k: v for k, v in W.items() if "rel_embeddings" not in k and not k.startswith("deberta.encoder.LayerNorm")})
+    for k in ("vocab_size", "hidden", "layers", "heads", "intermediate", "position_buckets", "conv_kernel_size"):
+        assert got_cfg[k] == cfg[k], k
+
+
+@pytest.mark.gpu
+def test_onnxsim_folded_models_give_the_same_output():
+    """deberta.onnx with folded relative positions and a VITS file with folded exp(-logs) (both onnxsim forms) against the unfolded files: the DeBERTa
+    features agree to 2e-5 (the folded projections were computed by another f32 matmul), the integer durations are equal, the waveform within 1e-5."""
+    bc, vc = dict(O.DEBERTA_TINY_CONV, position_buckets=16), O.VITS_TINY
+    bw, vw = synth.make_deberta_weights(bc, 3), synth.make_vits_weights(vc, 5)
+    sv = np.zeros((1, vc["style_dim"]), np.float32)
+    outs, feats = [], []
+    for form, fa in ((None, False), ("direct", True), ("tiled", True)):
+        f = OW.sbv2_file(OW.vits_onnx(vw, vc, folded=True, fold_affine=fa), OW.style_json(sv))
+        bs = model.load_model(OW.deberta_onnx(bw, dict(bc, heads=1) if form is None else bc, folded=form), True)
+        vs = model.load_model(f, False)
+        if form is not None:
+            assert model._lib.lib().sbv2_bert_heads(bs.handle) == bc["heads"] if hasattr(model._lib.lib(), "sbv2_bert_heads") else True
+        utts = [synth.make_utterance(n, bc, vc, seed=300 + i) for i, n in enumerate((6, 11))]
+        feats.append([model.predict(bs, u["input_ids"], u["attention_mask"]) for u in utts])
+        pipe = model.Pipeline(bs, vs)
+        b = pipe.prepare(utts, sdp_ratio=0.2, noise_scale=0.6, noise_scale_w=0.8, noise_seed=9)
+        pipe.run(b)
+        outs.append(pipe.fetch(b))
+        pipe.close(); bs.close(); vs.close()
+    for fa, fb in zip(feats[1], feats[2]):
+        np.testing.assert_array_equal(fa, fb)              # the two folded layouts hold the same numbers
+    for a, b2 in zip(outs[1], outs[2]):
+        np.testing.assert_array_equal(a, b2)
+    # against the unfolded file the tiny config's head count differs (1 x 64 assumed there, 4 x 16 in the folded file): compare folded forms with the
+    # container path that carries the true config instead
+    bs = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, bw), True)
+    vs = model.load_model(synth.pack_blob(synth.KIND_VITS, vc, vw), False)
+    utts = [synth.make_utterance(n, bc, vc, seed=300 + i) for i, n in enumerate((6, 11))]
+    for u, f1 in zip(utts, feats[1]):
+        np.testing.assert_allclose(model.predict(bs, u["input_ids"], u["attention_mask"]), f1, atol=2e-5, rtol=0)
+    pipe = model.Pipeline(bs, vs)
+    b = pipe.prepare(utts, sdp_ratio=0.2, noise_scale=0.6, noise_scale_w=0.8, noise_seed=9)
+    pipe.run(b)
+    for a, b2 in zip(pipe.fetch(b), outs[1]):
+        assert a.shape == b2.shape                         # same integer durations
+        np.testing.assert_allclose(a, b2, atol=1e-5, rtol=0)
+    pipe.close(); bs.close(); vs.close()
+
+
 @pytest.mark.gpu
 def test_imported_models_synthesise_identically():
     """A synthetic .sbv2 + deberta.onnx round-trip to bit-identical device weights: the pipeline output equals the SBV2W001 path's."""
     bc, vc = O.DEBERTA_TINY_CONV, O.VITS_TINY
     bw, vw = synth.make_deberta_weights(bc, 3), synth.make_vits_weights(vc, 5)
     sv = np.zeros((1, vc["style_dim"]), np.float32)
-    f = OW.sbv2_file(OW.vits_onnx(vw, vc, folded=True), OW.style_json(sv))
+    f = OW.sbv2_file(OW.vits_onnx(vw, vc, folded=True, fold_affine=False), OW.style_json(sv))   # (exp(-logs) left to the device: same bits as the container)
     # heads of the tiny DeBERTa (4 x 16) are not derivable from weights (the importer assumes the published 64-wide heads): use hidden 64 -> 1 head
     bc1 = dict(bc, heads=1)
     outs = []
