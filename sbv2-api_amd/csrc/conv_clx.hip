@@ -84,7 +84,7 @@ __device__ __forceinline__ bf16x8 clx_read_b128o(unsigned addr) {
 // WM = 1: 4 waves, 64 rows; <= 80 KB of LDS so that TWO workgroups share a CU: their barriers, prologues and epilogues interleave.
 // kClxWR weight ring slots, kClxXB window buffers.
 template <int NTAPS, int WM, int kClxWR, int kClxXB>
-__global__ __launch_bounds__(256 * WM) void conv_clx_kernel(const ClxKernelParams kp) {
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 1 && kClxWR * 4 + kClxXB * 20 <= 52 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
     constexpr int NW = 4 * WM;                 // waves
     constexpr int kClxPW = 20 / (NW / 2);      // window DMA pieces per window wave and chunk (2 parts x 10 pieces of 32 rows)
     constexpr int PPT = (kClxPW + NTAPS - 2) / (NTAPS - 1);   // ... per tap (the last tap of a chunk carries none)
@@ -552,6 +552,10 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
         if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
         else launch_clx<11, 2, 8, 3>(kp, stream);
+    } else if (cfg == 4 && p.ntaps != 5) {   // 52 KB of LDS (3-slot weight ring, 2 window buffers) and <= 168 registers: THREE workgroups per CU
+        if (p.ntaps == 3) launch_clx<3, 1, 3, 2>(kp, stream);
+        else if (p.ntaps == 7) launch_clx<7, 1, 3, 2>(kp, stream);
+        else launch_clx<11, 1, 3, 2>(kp, stream);
     } else if (cfg == 3 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 1, 8, 2>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 1, 8, 2>(kp, stream);
