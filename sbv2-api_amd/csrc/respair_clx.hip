@@ -17,6 +17,10 @@
 //   * C = 16 multiplies two taps per MFMA (v_mfma_f32_16x16x32_bf16, weights packed as tap pairs at load): no half-empty A tiles.
 //   * The fragment reads of the next tap are dealt one per gap between the current tap's MFMAs (sched_barrier pins them).
 //   * Tiles are dealt to the XCDs in contiguous ranges (neighbouring tiles share their halo rows through one L2).
+// Measured and NOT kept (profiles/r04d_respair_persistent_probe.txt): persistent workgroups that prefetch the next tile's window / mask bytes / first
+// weight group (the per-tile dependency chain fell from 15.2k to 7.5k cycles at C = 16, 28.6k to 19.3k at C = 32) ran 5-10 % SLOWER: the loop keeps 40-60
+// more registers live (one wave per SIMD less at C = 16), and these launches are not latency bound any more: C = 16 and every k = 3 launch move their
+// 0.94 GB per half-size launch at 3.5-3.7 TB/s, C >= 32 at k >= 7 run 0.85-1.1 PFLOP/s of executed MFMA at a power-managed 1.65-1.75 GHz.
 // Fragment reads, window writes and the waits that cover them are inline asm: with an LDS-DMA pending hipcc puts s_waitcnt vmcnt(0) in front of every
 // LDS access it can see, which would serialise the weight stream with the MFMAs (conv_clx.hip has the same note).
 #include <atomic>
