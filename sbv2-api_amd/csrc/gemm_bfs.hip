@@ -440,8 +440,13 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
     const bool lone = blocks(128, 128) <= 256;
     const bool k32 = (p.K & 31) == 0;
     // configuration id (SBV2_BFS_SLOTS, experiments): tens = chunks per slot, units = slots
+    // 64 x 128 tiles (experiment, SBV2_BFS_HALF=1): products whose 128 x 128 tiling leaves half of the CUs without a workgroup (DeBERTa's 1024-row
+    // products at 2176 tokens: 136 workgroups) as twice as many half-height workgroups; same per-element summation order
+    static const int half = getenv("SBV2_BFS_HALF") ? atoi(getenv("SBV2_BFS_HALF")) : 1;
     if (p.W.f16) {   // the ring shapes of bf16x3 (same bytes per chunk), two accumulator sets
         if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
+        else if ((half == 1 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) || half == 2) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);
+        else if (half == 3 && blocks(128, 128) > 512 && blocks(128, 128) < 640) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);   // (the 544-workgroup product too)
         else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4, true>(kp, stream);
         else launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5, true>(kp, stream);
     } else if (p.W.parts == 2) {
