@@ -345,8 +345,8 @@ def main():
                         "conv_cl<1,f16>": ("conv_cl_kernel<1, 2, false, false",),
                         "conv_cl_km<2,split-bf16>": ("conv_cl_kernel<2, 1, true", "conv_cl_kernel<2, 1, false, true"),
                         "conv_cl_km<1,split-bf16>": ("conv_cl_kernel<1, 1, true", "conv_cl_kernel<1, 1, false, true"),
-                        "respair_cl<C<=32>": ("respair_cl_kernel<1, false, 1>", "respair_cl_kernel<1, true, 1>"),
-                        "respair_cl<C=64>": ("respair_cl_kernel<1, false, 2>",),
+                        "respair_cl<C<=32>": ("respair_clx_kernel<32,", "respair_clx_kernel<16,", "respair_cl_kernel<1, false, 1", "respair_cl_kernel<1, true, 1"),
+                        "respair_cl<C=64>": ("respair_clx_kernel<64,", "respair_cl_kernel<1, false, 2"),
                         "gemm_bfs<bf16x3>": ("gemm_bfs_kernel<2,",),
                         "gemm_bfs<bf16x6>": ("gemm_bfs_kernel<3,",),
                         "gemm_bfs<f16x3>": ("true>(sbv2::BfsKernelParams)",),

@@ -337,6 +337,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
     // ================================================================================================================================
     dma_group(std::integral_constant<int, 0>{});
     load_pair(0);
+    // The residual rows of the epilogue are requested NOW, together with the conv1 window that contains them: the second request for a line that is in
+    // flight (or just landed) is served by L2.  Requested before conv2, as rounds 1-3 did, they were HBM reads again: with three 64 KB tiles per CU the
+    // XCD's 4 MB L2 has turned over by then (PMC: 2.14 GB fetched per C = 32 launch for 0.94 GB of plane, profiles/r04f_pmc_hbm_traffic.csv).  Price: NIT x 4
+    // registers live over the tile.
+    const bool rres_early = !p.rres_late;
+    constexpr int LPR = C == 16 ? 4 : 8;               // lanes per output row of the wave's transposed tile (32 channels = 128 bytes; C = 16: 64 bytes)
+    constexpr int RPI = 64 / LPR, NIT = 64 / RPI;      // rows per iteration, iterations
+    const int c4 = wm * 32 + (lane % LPR) * 4, rowi = lane / LPR;
+    f32x4v rres[NIT];
+    auto load_rres = [&]() {
+        if (interior) {
+            const char* rb = reinterpret_cast<const char*>(p.X) + (int64_t)n0 * (C * 4);   // (uniform)
+            const unsigned rl = (unsigned)((wn * 64 + rowi) * (C * 4) + c4 * 4);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) rres[it] = *reinterpret_cast<const f32x4v*>(rb + it * RPI * C * 4 + (size_t)rl);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int64_t posr = min((int64_t)n0 + wn * 64 + it * RPI + rowi, (int64_t)NB - 1);
+                rres[it] = *reinterpret_cast<const f32x4v*>(p.X + posr * C + c4);
+            }
+        }
+    };
+    if (rres_early) load_rres();
     {
         // biases and the keep flags of the intermediate's rows (position inside the batch and not masked), parked in LDS for both epilogues
         const float bval = tid < 128 ? (tid < 64 ? p.b1[min(tid, C - 1)] : p.b2[min(tid - 64, C - 1)]) : 0.f;
@@ -451,25 +475,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
     }
     RPX_STAMP(3);
     zero_acc();
-    // the residual rows of the epilogue are requested now (they were fetched for the conv1 window a moment ago: L2 hits) and land behind conv2's MFMAs
-    constexpr int LPR = C == 16 ? 4 : 8;               // lanes per output row of the wave's transposed tile (32 channels = 128 bytes; C = 16: 64 bytes)
-    constexpr int RPI = 64 / LPR, NIT = 64 / RPI;      // rows per iteration, iterations
-    const int c4 = wm * 32 + (lane % LPR) * 4, rowi = lane / LPR;
-    f32x4v rres[NIT];
-    {
-        if (interior) {
-            const char* rb = reinterpret_cast<const char*>(p.X) + (int64_t)n0 * (C * 4);   // (uniform)
-            const unsigned rl = (unsigned)((wn * 64 + rowi) * (C * 4) + c4 * 4);
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) rres[it] = *reinterpret_cast<const f32x4v*>(rb + it * RPI * C * 4 + (size_t)rl);
-        } else {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int64_t posr = min((int64_t)n0 + wn * 64 + it * RPI + rowi, (int64_t)NB - 1);
-                rres[it] = *reinterpret_cast<const f32x4v*>(p.X + posr * C + c4);
-            }
-        }
-    }
+    if (!rres_early) load_rres();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -589,8 +595,11 @@ static void launch_rpx_any(const ResPairParams& p, hipStream_t stream) {
 }
 
 // p.mask_shift must be set (launch_respair_cl does it)
-void launch_respair_clx(const ResPairParams& p, hipStream_t stream) {
-    SBV2_REQUIRE(respair_clx_usable(p), "respair_clx: operands do not fit the kernel");
+void launch_respair_clx(const ResPairParams& p0, hipStream_t stream) {
+    SBV2_REQUIRE(respair_clx_usable(p0), "respair_clx: operands do not fit the kernel");
+    static const int late = getenv("SBV2_RPX_RRES_LATE") ? atoi(getenv("SBV2_RPX_RRES_LATE")) : 0;
+    ResPairParams p = p0;
+    p.rres_late = late;
     launch_rpx_any<-1>(p, stream);
 }
 void launch_respair_clx_diag(const ResPairParams& p0, hipStream_t stream) {
