@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
     const AttnGroup* groups, const float* Q, const float* K, const float* V, int ld, float* ctx, int ldc, int dk, const float* erk,
     const float* erv, int w, float qscale) {
     constexpr int DR = DT * 32;
-    constexpr int NP = DR / 8;
+    // (DR / 8 elements of each matrix per thread and tile)
     constexpr int KS = DR / 16;            // bf16 k-steps over the (padded) head dimension
     constexpr int PK = 2 * DR + 16;        // bytes per key row of the K tile
     constexpr int PV = 2 * 32 + 16;        // bytes per channel row of the V tile
@@ -275,30 +275,61 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         erk_s[idx] = in ? erk[r * dk + d] : 0.f;
         erv_s[idx] = in ? erv[r * dk + d] : 0.f;
     }
-    const int sc = tid & 31, sr = tid >> 5;
-    const int scp = (sc & ~12) | ((sc & 4) << 1) | ((sc & 8) >> 1);   // key order of the V tile (bits 2 and 3 swapped)
-    float kreg[NP], vreg[NP];
+    // Staging (round 4): a thread owns FOUR consecutive elements along the axis its LDS image is contiguous in, so that every LDS store is 8 bytes
+    // (round 3: one element per store: 48 two-byte ds_write per thread and tile, LDS bank-conflict ratio 0.36, the staging phase as long as the tile's
+    // MFMAs).  K image [key][d]: key = tid & 31, d = 4 g .. 4 g + 3 with g = (tid >> 5) + 8 p: four scalar loads (coalesced over the keys), one store
+    // per part.  V image [d][key, bits 2 and 3 swapped]: d = (tid >> 3) + 32 p, keys 4 q .. 4 q + 3 with q = tid & 7 (a group of four consecutive keys stays
+    // consecutive under the swap): ONE 16-byte load, one store per part.  Same values in the same places: bit-identical results.
+    typedef __bf16 fa_bf16x4 __attribute__((ext_vector_type(4)));
+    typedef float fa_f32x4 __attribute__((ext_vector_type(4)));
+    const int sc = tid & 31, sg = tid >> 5;            // K: key, first d group
+    const int vq = tid & 7, vd = tid >> 3;             // V: key quad, first d
+    const int vqp = (vq & 4) | ((vq & 1) << 1) | ((vq >> 1) & 1);   // the quad's place in the V image (bits 2 and 3 of the key index swapped)
+    float kreg[DT][4];
+    fa_f32x4 vreg[DT];
     auto load_tile = [&](int j0) {
         const int jc = min(j0 + sc, T - 1);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int d = min(sr + 8 * p, dk - 1);
-            kreg[p] = Kg[(int64_t)d * ld + jc];
-            vreg[p] = Vg[(int64_t)d * ld + jc];
+        for (int p = 0; p < DT; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kreg[p][e] = Kg[(int64_t)min(4 * (sg + 8 * p) + e, dk - 1) * ld + jc];
+        if (j0 + 32 <= T) {   // (uniform) whole tile inside the utterance: 16-byte loads (columns are 16-byte aligned: starts and pitches are multiples of 4)
+#pragma unroll
+            for (int p = 0; p < DT; ++p) vreg[p] = *reinterpret_cast<const fa_f32x4*>(Vg + (int64_t)min(vd + 32 * p, dk - 1) * ld + j0 + 4 * vq);
+        } else {
+#pragma unroll
+            for (int p = 0; p < DT; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vreg[p][e] = Vg[(int64_t)min(vd + 32 * p, dk - 1) * ld + min(j0 + 4 * vq + e, T - 1)];
         }
     };
     auto store_tile = [&](int j0) {
         const bool jin = j0 + sc < T;     // keys beyond the utterance: zero operands (their scores are masked anyway, V must not be NaN)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int d = sr + 8 * p;
-            const bool in = d < dk && jin;
-            const float kv = in ? kreg[p] : 0.f, vv = in ? vreg[p] : 0.f;
-            const __bf16 kh_ = (__bf16)kv, vh_ = (__bf16)vv;
-            *reinterpret_cast<__bf16*>(kt_hi + sc * PK + d * 2) = kh_;
-            *reinterpret_cast<__bf16*>(kt_lo + sc * PK + d * 2) = (__bf16)(kv - (float)kh_);
-            *reinterpret_cast<__bf16*>(vt_hi + d * PV + scp * 2) = vh_;
-            *reinterpret_cast<__bf16*>(vt_lo + d * PV + scp * 2) = (__bf16)(vv - (float)vh_);
+        for (int p = 0; p < DT; ++p) {
+            const int g = sg + 8 * p;
+            fa_bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float kv = (4 * g + e < dk && jin) ? kreg[p][e] : 0.f;
+                h[e] = (__bf16)kv;
+                l[e] = (__bf16)(kv - (float)h[e]);
+            }
+            *reinterpret_cast<fa_bf16x4*>(kt_hi + sc * PK + g * 8) = h;
+            *reinterpret_cast<fa_bf16x4*>(kt_lo + sc * PK + g * 8) = l;
+        }
+#pragma unroll
+        for (int p = 0; p < DT; ++p) {
+            const int d = vd + 32 * p;
+            fa_bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float vv = (d < dk && j0 + 4 * vq + e < T) ? vreg[p][e] : 0.f;
+                h[e] = (__bf16)vv;
+                l[e] = (__bf16)(vv - (float)h[e]);
+            }
+            *reinterpret_cast<fa_bf16x4*>(vt_hi + d * PV + vqp * 8) = h;
+            *reinterpret_cast<fa_bf16x4*>(vt_lo + d * PV + vqp * 8) = l;
         }
     };
     load_tile(0);

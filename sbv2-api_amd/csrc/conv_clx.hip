@@ -40,6 +40,7 @@ struct ClxKernelParams {
     int wshift0;   // first window row = n0 + wshift0
     int sh0, sh_step;
     int gy;        // row tiles (of 64 * WM rows)
+    int contig;    // position tiles dealt to the XCDs in contiguous ranges
 };
 
 template <int I, int N, class F>
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int by = slot % kp.gy;
-    const int bx = (slot / kp.gy) * 8 + xcd;
+    // position tiles: round-robin over the XCDs (rounds 3: neighbours on different L2s re-fetch each other's halo rows from HBM), or (contig) a
+    // contiguous range per XCD
+    const int bx = kp.contig ? xcd * ((int)gridDim.x / (8 * kp.gy)) + slot / kp.gy : (slot / kp.gy) * 8 + xcd;
     const int n0 = bx * kClxNT;
     if (n0 >= p.N) return;
     const int m0 = (by * WM + wm) * 64;        // first output row of this WAVE's tile
@@ -516,6 +519,8 @@ template <int NTAPS, int WM, int WR, int XB>
 static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     const ConvClxParams& p = kp.p;
     kp.gy = p.M / (64 * WM);
+    static const int contig = getenv("SBV2_CLX_CONTIG") ? atoi(getenv("SBV2_CLX_CONTIG")) : 0;
+    kp.contig = contig;
     const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * kClxXR * 32, (size_t)4 * WM * 64 * 36 * sizeof(float));
     auto kern = conv_clx_kernel<NTAPS, WM, WR, XB>;
     static std::atomic<uint64_t> lds_allowed{0};

@@ -85,9 +85,12 @@ struct RpxCfg {
     static constexpr int NXC = NT / 64 + 1;            // 64-row blocks of the conv1 window (NT + tap span <= NT + 64)
     static constexpr int ROWS1 = NXC * 64;
     static constexpr int ROWS2 = NT + NTAPS + 1;       // rows of the intermediate window (NT + k - 1 are read)
-    static constexpr int X1HALF = ROWS1 * 16 + 64;     // conv1 window, one chunk: [part][channel half][row] 16-byte cells; + 64: the halves on different bank halves
+    // conv1 window, one chunk: [part][channel half][row] 16-byte cells.  32x32x16 kernels: + 64 puts the two halves a conversion store touches on
+    // different bank halves (a fragment read touches one half only).  16x16x32 (C = 16): a fragment read touches BOTH halves (k groups 0 / 2 and 1 / 3):
+    // the half planes must be a multiple of 256 bytes apart or rows 4-11 of one collide with rows 0-3 / 12-15 of the other (PMC: conflict ratio 0.41)
+    static constexpr int X1HALF = TWOTAP ? (ROWS1 * 16 + 255) / 256 * 256 : ROWS1 * 16 + 64;
     static constexpr int X1PART = 2 * X1HALF;
-    static constexpr int X2HALF = ROWS2 * 16;          // intermediate: [part][chunk][channel half][row]
+    static constexpr int X2HALF = TWOTAP ? (ROWS2 * 16 + 255) / 256 * 256 : ROWS2 * 16;   // intermediate: [part][chunk][channel half][row]
     static constexpr int X2CH = 2 * X2HALF;
     static constexpr int X2PART = NCH * X2CH;
     static constexpr int XREG = rpx_max(2 * X1PART, 2 * X2PART);   // the intermediate ALIASES the conv1 window

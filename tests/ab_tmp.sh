@@ -1,18 +1,17 @@
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "respair_clx" 2>&1 | tail -2
-for v in 0 1 0 1; do SBV2_RPX_RRES_LATE=$v python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('late=$v', d['value'], d['ms_per_step'], {k:round(v,2) for k,v in d['roofline']['per_config_ms'].items() if 'respair' in k})
-"; done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r04g_fetch -- python3 tests/respair_pmc.py 3 > /dev/null 2>&1
-python tests/pmc_sum.py gpurun_out/r04g_fetch/.. respair 2>/dev/null | tail -3
+rm -rf gpurun_out/pmc_iso
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_iso -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob,collections
-f=glob.glob('gpurun_out/r04g_fetch/*/*counter_collection.csv')[0]
-agg=collections.defaultdict(list)
+f=glob.glob('gpurun_out/pmc_iso/*/*counter_collection.csv')[0]
+dur=collections.defaultdict(list); seen=set(); cnt=collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
-    if 'respair' in r['Kernel_Name']: agg[r['Kernel_Name'][:60]].append(float(r['Counter_Value']))
-for k,v in agg.items(): print(k, 'FETCH bytes (x2):', sum(v)/len(v)*1024*2/1e9, 'GB')
+    k=r['Kernel_Name'][:70]
+    cnt[k][r['Counter_Name']]+=float(r['Counter_Value'])
+    if r['Dispatch_Id'] in seen: continue
+    seen.add(r['Dispatch_Id']); dur[k].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
+rows=sorted(dur.items(), key=lambda kv:-sum(kv[1]))
+for k,v in rows[:26]:
+    c=cnt[k]; n=len(v)
+    print(f"{k:70s} n {n:4d} avg_us {sum(v)/n/1e3:8.1f} tot_ms/step {sum(v)/1e6/3:7.2f} bankconf {c['SQ_LDS_BANK_CONFLICT']/max(c['SQ_LDS_IDX_ACTIVE'],1):.3f} mfma {c['SQ_VALU_MFMA_BUSY_CYCLES']/max(c['GRBM_GUI_ACTIVE']/8*1024,1):.3f}")
 PY
