@@ -84,15 +84,15 @@ __device__ __forceinline__ bf16x8 clx_read_b128o(unsigned addr) {
 // WM = 2: 8 waves, 128 rows x 256 positions (both 64-row wave groups read the one staged window), one workgroup per CU.
 // WM = 1: 4 waves, 64 rows; <= 80 KB of LDS so that TWO workgroups share a CU: their barriers, prologues and epilogues interleave.
 // kClxWR weight ring slots, kClxXB window buffers.
-template <int NTAPS, int WM, int kClxWR, int kClxXB>
-__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 1 && kClxWR * 4 + kClxXB * 20 <= 52 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
+template <int NTAPS, int WM, int kClxWR, int kClxXB, int XR = kClxXR>
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 1 && kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
     constexpr int NW = 4 * WM;                 // waves
     constexpr int kClxPW = 20 / (NW / 2);      // window DMA pieces per window wave and chunk (2 parts x 10 pieces of 32 rows)
     constexpr int PPT = (kClxPW + NTAPS - 2) / (NTAPS - 1);   // ... per tap (the last tap of a chunk carries none)
     static_assert(PPT <= 8, "a tap's MFMA gaps hold its window pieces");
     constexpr int WSLOT = 2 * WM * 2 * 1024;   // one (chunk, tap): 2 WM row tiles x 2 parts x 1 KB
     constexpr int WBYTES = kClxWR * WSLOT;
-    constexpr int XPART = kClxXR * 32, XBUF = 2 * XPART;
+    constexpr int XPART = XR * 32, XBUF = 2 * XPART;   // (XR = window rows per buffer: 320 holds every tap span <= 64; 288 those <= 32)
     constexpr int NWW = NW / 2;                // weight-DMA waves (the others carry the window)
     constexpr int WPW = (2 * WM * 2) / NWW;    // weight DMAs per weight wave and step (= 2)
     static_assert(WPW == 2, "two weight blocks per weight wave and step");
@@ -515,14 +515,15 @@ bool conv_clx_usable(const ConvClxParams& p) {
     return p.N >= 1 && p.X.N == p.N;
 }
 
-template <int NTAPS, int WM, int WR, int XB>
+template <int NTAPS, int WM, int WR, int XB, int XR = kClxXR>
 static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     const ConvClxParams& p = kp.p;
+    SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
     kp.gy = p.M / (64 * WM);
     static const int contig = getenv("SBV2_CLX_CONTIG") ? atoi(getenv("SBV2_CLX_CONTIG")) : 0;
     kp.contig = contig;
-    const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * kClxXR * 32, (size_t)4 * WM * 64 * 36 * sizeof(float));
-    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB>;
+    const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * XR * 32, (size_t)4 * WM * 64 * 36 * sizeof(float));
+    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB, XR>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     const int ntx = round_up((p.N + kClxNT - 1) / kClxNT, 8);
@@ -552,11 +553,22 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     kp.xrows = kClxNT + (smax - smin);
     kp.sh0 = p.shift0 - smin;
     kp.sh_step = step;
-    static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 1;   // experiments: 2 = 128-row workgroups (one per CU), 1 = 64-row (two per CU)
+    // 7 (default, round 4): k = 3 / 5 / 7 on a 4-slot weight ring + two 288-row window buffers = 52 KB, THREE 64-row workgroups per CU (the prologue and
+    // epilogue of one overlap the others' loops: conv_clx 33.1 -> 32.0 ms, the flow's FFN convs 6.57 -> 6.32 ms per step, same box); k = 11 (tap span up to
+    // 50 rows: 320-row buffers, 56 KB) stays at two per CU (its 3-slot-ring variant, cfg 6, is slower).  1 = two per CU for every k (round 3), 2 = 128-row
+    // workgroups (one per CU), 3 / 4 = other ring shapes (measured, slower: DESIGN 5.3)
+    static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 7;
     if (cfg == 2 && (p.M & 127) == 0 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
         else launch_clx<11, 2, 8, 3>(kp, stream);
+    } else if ((cfg == 5 || cfg == 6 || cfg == 7) && kp.xrows <= 288 && p.ntaps != 11 && (p.ntaps != 5 || cfg == 7)) {
+        // 4-slot weight ring + two 288-row window buffers (tap spans <= 32: k = 3 and k = 7 at every dilation of the model): 52 KB, THREE workgroups per CU
+        if (p.ntaps == 3) launch_clx<3, 1, 4, 2, 288>(kp, stream);
+        else if (p.ntaps == 5) launch_clx<5, 1, 4, 2, 288>(kp, stream);
+        else launch_clx<7, 1, 4, 2, 288>(kp, stream);
+    } else if (cfg == 6 && p.ntaps == 11) {
+        launch_clx<11, 1, 3, 2>(kp, stream);
     } else if (cfg == 4 && p.ntaps != 5) {   // 52 KB of LDS (3-slot weight ring, 2 window buffers) and <= 168 registers: THREE workgroups per CU
         if (p.ntaps == 3) launch_clx<3, 1, 3, 2>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 1, 3, 2>(kp, stream);
