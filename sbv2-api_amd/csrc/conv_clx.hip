@@ -174,14 +174,15 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     };
     const int lcol = lane & 31, lh = lane >> 5;
     const unsigned abase = lds0 + (wm * 2) * 2048 + lane * 16;
-    unsigned boff0[NTAPS], boff1[NTAPS];       // window offsets of this lane's B fragments per tap (the XOR swizzle depends on the row)
+    // window offsets of this lane's B fragments per tap (the XOR swizzle depends on the row).  The second position tile is 32 rows further: + 1024 bytes
+    // with the SAME swizzle bit ((r + 32) >> 3 has the parity of r >> 3), an immediate in its reads instead of a second register per tap
+    unsigned boff0[NTAPS];
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
-        const int r0 = wq * 64 + lcol + kp.sh0 + t * kp.sh_step, r1 = r0 + 32;
+        const int r0 = wq * 64 + lcol + kp.sh0 + t * kp.sh_step;
         boff0[t] = lds0 + WBYTES + r0 * 32 + (((lh ^ (r0 >> 3)) & 1) << 4);
-        boff1[t] = lds0 + WBYTES + r1 * 32 + (((lh ^ (r1 >> 3)) & 1) << 4);
     }
-    auto read_frag = [&](Frags& f, auto rc, unsigned aaddr, unsigned b0, unsigned b1) {
+    auto read_frag = [&](Frags& f, auto rc, unsigned aaddr, unsigned b0) {
         constexpr int r = decltype(rc)::value;   // 0..3: A (row tile, part); 4..7: B (position tile, part)
         if constexpr (r == 0) f.ah[0] = clx_read_b128o<0>(aaddr);
         else if constexpr (r == 1) f.al[0] = clx_read_b128o<1024>(aaddr);
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         else if constexpr (r == 3) f.al[1] = clx_read_b128o<3072>(aaddr);
         else if constexpr (r == 4) f.bh[0] = clx_read_b128o<0>(b0);
         else if constexpr (r == 5) f.bl[0] = clx_read_b128o<XPART>(b0);
-        else if constexpr (r == 6) f.bh[1] = clx_read_b128o<0>(b1);
-        else f.bl[1] = clx_read_b128o<XPART>(b1);
+        else if constexpr (r == 6) f.bh[1] = clx_read_b128o<1024>(b0);
+        else f.bl[1] = clx_read_b128o<XPART + 1024>(b0);
     };
     unsigned wroff = 0;        // ring offset of the weight slot the NEXT fragment reads take (step s + 1 while step s runs)
     unsigned xroff = 0;        // buffer offset of the window those reads take
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     }
     __builtin_amdgcn_s_barrier();
     Frags fa, fb;
-    clx_static_for<0, 8>([&](auto rc) { read_frag(fa, rc, abase, boff0[0], boff1[0]); });
+    clx_static_for<0, 8>([&](auto rc) { read_frag(fa, rc, abase, boff0[0]); });
     wroff = WSLOT == WBYTES ? 0 : WSLOT;
 
     // One step: tap `tap` of chunk `chunk` (s = chunk * NTAPS + tap).  LAST = the step's successor opens a new chunk.
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         __builtin_amdgcn_sched_barrier(0);
         const bool rd = s + 1 < S;
         if (LAST) xroff = xroff + XBUF == kClxXB * XBUF ? 0 : xroff + XBUF;   // the next step reads the next chunk's window
-        const unsigned aaddr = abase + wroff, b0 = boff0[tapn] + xroff, b1 = boff1[tapn] + xroff;
+        const unsigned aaddr = abase + wroff, b0 = boff0[tapn] + xroff;
         wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
         const bool stw = wwave && s + kClxWR < S;
         const bool stx = !wwave && chunk + kClxXB - 1 < nchunks;
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
             mfma_one(cur, nc);
             if constexpr (n < 4) {
                 if (rd) {
-                    read_frag(nxt, std::integral_constant<int, 2 * n>{}, aaddr, b0, b1);
-                    read_frag(nxt, std::integral_constant<int, 2 * n + 1>{}, aaddr, b0, b1);
+                    read_frag(nxt, std::integral_constant<int, 2 * n>{}, aaddr, b0);
+                    read_frag(nxt, std::integral_constant<int, 2 * n + 1>{}, aaddr, b0);
                 }
             } else {
                 if constexpr (n == 5) {
@@ -553,16 +554,19 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     kp.xrows = kClxNT + (smax - smin);
     kp.sh0 = p.shift0 - smin;
     kp.sh_step = step;
-    // 7 (default, round 4): k = 3 / 5 / 7 on a 4-slot weight ring + two 288-row window buffers = 52 KB, THREE 64-row workgroups per CU (the prologue and
-    // epilogue of one overlap the others' loops: conv_clx 33.1 -> 32.0 ms, the flow's FFN convs 6.57 -> 6.32 ms per step, same box); k = 11 (tap span up to
-    // 50 rows: 320-row buffers, 56 KB) stays at two per CU (its 3-slot-ring variant, cfg 6, is slower).  1 = two per CU for every k (round 3), 2 = 128-row
-    // workgroups (one per CU), 3 / 4 = other ring shapes (measured, slower: DESIGN 5.3)
-    static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 7;
+    // 8 (default, round 4): every launch whose tap span fits 288-row window buffers (k = 3 / 5 / 7 at every dilation, k = 11 at dilations 1 and 3 and in
+    // every conv2) runs on a 4-slot weight ring + two such buffers = 52 KB, THREE 64-row workgroups per CU: the prologue and epilogue of one overlap the
+    // others' loops (conv_clx 33.1 -> 31.0 ms, the flow's FFN convs 6.57 -> 6.2 ms per step, same boxes); k = 11 at dilation 5 (span 50 rows: 320-row
+    // buffers, 56 KB) stays at two per CU.  7 = the same without k = 11; 1 = two per CU for every k (round 3); 2 = 128-row workgroups (one per CU); 3 / 4 / 6
+    // = other ring shapes (measured, slower: DESIGN 5.3)
+    static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 8;
     if (cfg == 2 && (p.M & 127) == 0 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
         else launch_clx<11, 2, 8, 3>(kp, stream);
-    } else if ((cfg == 5 || cfg == 6 || cfg == 7) && kp.xrows <= 288 && p.ntaps != 11 && (p.ntaps != 5 || cfg == 7)) {
+    } else if (cfg == 8 && kp.xrows <= 288 && p.ntaps == 11) {   // k = 11 at dilations 1 and 3 (and every conv2) fits the 288-row buffers too
+        launch_clx<11, 1, 4, 2, 288>(kp, stream);
+    } else if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8) && kp.xrows <= 288 && p.ntaps != 11 && (p.ntaps != 5 || cfg >= 7)) {
         // 4-slot weight ring + two 288-row window buffers (tap spans <= 32: k = 3 and k = 7 at every dilation of the model): 52 KB, THREE workgroups per CU
         if (p.ntaps == 3) launch_clx<3, 1, 4, 2, 288>(kp, stream);
         else if (p.ntaps == 5) launch_clx<5, 1, 4, 2, 288>(kp, stream);

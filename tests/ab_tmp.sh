@@ -1,5 +1,5 @@
-SBV2_CLX_CFG=7 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "clx or vits_e2e or config2" 2>&1 | tail -2
-for v in 5 6 7 5 6 7; do SBV2_CLX_CFG=$v python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+SBV2_CLX_CFG=8 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "clx" 2>&1 | tail -2
+for v in 7 8 7 8; do SBV2_CLX_CFG=$v python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
