@@ -235,8 +235,15 @@ struct ConvClParams {
     int in_km = 0, out_km = 0;  // operand / result layout: 0 = channels-last [pos][C], 1 = k-major plane [C][ld]
     int act = ACT_NONE;         // k-major output only
     float alpha = 1.0f;         // k-major output only
+    // channels-last output only: the result ALSO as chunk-major bf16 hi / lo planes of lrelu(result, ys_slope) (SplitClPlanes below: the operand format of
+    // conv_clx.hip), indexed by OUTPUT position: the transposed convolution of a wide decoder stage writes the ResBlocks' first operand itself
+    void* ys_p = nullptr;
+    int64_t ys_rows = 0;        // front + N + back rows of one (chunk, part) plane
+    int ys_front = 0;
+    float ys_slope = 1.0f;
 };
 void launch_conv_cl(const ConvClParams& p, hipStream_t stream);
+bool conv_cl_parts_ok(const ConvClParams& p);   // launch_conv_cl(p) would honour p.ys_p
 bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t stream);   // conv_cl_small.hip
 void launch_conv_cl_diag(const ConvClParams& p, int abl, unsigned long long* stamps, hipStream_t stream);   // diagnostics (clock stamps + ablations)
 

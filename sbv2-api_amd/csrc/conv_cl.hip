@@ -74,6 +74,7 @@ struct ClKernelParams {
 template <int TM, int PREC, bool IN_KM, bool OUT_KM, int WM, int ABL = 0>
 __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernelParams kp) {
     constexpr int kT = kClThreads * WM;
+    constexpr bool YS = ABL == 20;   // the channels-last epilogue also writes the result's bf16 parts (ConvClParams::ys_p): the transposed convs of the wide stages
     constexpr bool SPLIT = PREC == PREC_BF16X3;
     using elem_t = std::conditional_t<PREC == PREC_F16, _Float16, __bf16>;
     using ex8 = std::conditional_t<PREC == PREC_F16, f16x8, bf16x8>;
@@ -488,6 +489,20 @@ __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernel
                     if (!p.mask[mi]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 *reinterpret_cast<float4*>(yp) = v;
+                if (YS && p.ys_p) {   // (uniform; compiled into the ABL = 20 instantiation only: in every kernel of the family it cost 40 registers) bf16 parts of lrelu(result): 4 channels = 8 bytes of a 32-byte row of chunk co >> 4; the lo plane follows the hi plane
+                    typedef __bf16 cl_bf16x4 __attribute__((ext_vector_type(4)));
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    cl_bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = vv[e] >= 0.f ? vv[e] : vv[e] * p.ys_slope;
+                        h[e] = (__bf16)x;
+                        l[e] = (__bf16)(x - (float)h[e]);
+                    }
+                    char* qs = static_cast<char*>(p.ys_p) + ((int64_t)(co >> 4) * 2 * p.ys_rows + p.ys_front + pos) * 32 + (co & 15) * 2;
+                    *reinterpret_cast<cl_bf16x4*>(qs) = h;
+                    *reinterpret_cast<cl_bf16x4*>(qs + p.ys_rows * 32) = l;
+                }
             }
             pos += pstep;
             if (rp) rp += rstep;
@@ -528,6 +543,15 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
     auto kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM, WM>;
     static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
+    if constexpr (SPLIT && !IN_KM && !OUT_KM && TM == 2) {
+        if (p.ys_p) {
+            kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM, WM, 20>;
+            static std::atomic<uint64_t> lds_allowed_ys{0};
+            allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed_ys);
+        }
+    } else {
+        SBV2_REQUIRE(!p.ys_p, "conv_cl: the parts output exists for the split-bf16 channels-last kernel with 64-row wave tiles only");
+    }
     const int ntx = round_up((p.N + kClNT - 1) / kClNT, 8);   // padded so that the (xcd, slot) <-> (tile, row tile) map is a bijection
     dim3 grid(ntx * (kp.nmt / (TM * WM)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -616,6 +640,14 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
         if (tm == 2) launch_cl_layout<2, PREC_BF16>(kp, stream);
         else launch_cl_layout<1, PREC_BF16>(kp, stream);
     }
+}
+
+// whether launch_conv_cl(p) would take a kernel that can also write the result's bf16 parts (ConvClParams::ys_p): the split-bf16 channels-last kernel
+// with 64-row wave tiles, i.e. not a small grid (those go to 32-row tiles or conv_cl_small: same bits, no parts epilogue)
+bool conv_cl_parts_ok(const ConvClParams& p) {
+    if (!p.split || p.f16 || p.in_km || p.out_km || p.tm != 2 || p.N <= 0) return false;
+    const int64_t tiles = (p.N + kClNT - 1) / kClNT;
+    return tiles * std::max(1, p.nmt / 2) >= small_grid_max() && tiles * (p.nmt / 2) >= 128;
 }
 
 // Diagnostic launch of the dominant configuration (128-row workgroups, split-bf16, channels-last in and out) with an ablation variant and

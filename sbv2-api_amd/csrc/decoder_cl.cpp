@@ -235,6 +235,33 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         float* T1 = ar.array<float>((size_t)Lo * C);
         float* YA = ar.array<float>((size_t)Lo * C);
         float* YB = ar.array<float>((size_t)Lo * C);
+        // Wide stages (>= 128 channels, split-bf16): the ResBlock convolutions read PRE-SPLIT operands (conv_clx.hip: LDS-DMA only, one barrier
+        // per tap).  The stage input is split once (split_cl); every other operand is written by the producing convolution's epilogue as the
+        // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
+        int ushift = 0;
+        while ((1 << ushift) < U) ++ushift;
+        // (large launches only: a single utterance or a streaming window has too few tiles to pay for the extra split / halo launches; the two
+        // paths give the same bits, so the choice is free)
+        static const int clx_min_c = getenv("SBV2_CLX_MINC") ? atoi(getenv("SBV2_CLX_MINC")) : 128;   // A/B knob
+        bool clx = clx_enabled() && dec_mode_ == 1 && C >= clx_min_c && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
+        for (int j = 0; j < nk && clx; ++j) {
+            const ClBranch& rb = st.branches[j];
+            if (!(rb.k == 3 || rb.k == 7 || rb.k == 11)) clx = false;
+            for (int d : rb.dil)
+                if (d * (rb.k - 1) > 64 || d * (rb.k - 1) / 2 > kClxFront) clx = false;
+        }
+        SplitClPlanes XUs, T1s, YsA, YsB;
+        if (clx) {
+            const size_t sb = split_cl_bytes(C, Lo);
+            XUs = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            T1s = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            YsA = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+            YsB = make_split_cl(ar.alloc(sb), C, Lo, stream_);
+        }
+        // (the stage input's parts are written by the transposed convolution's own epilogue below: no separate split pass over XU;
+        // SBV2_CLX_UPSPLIT=0 restores the pass, same bits)
+        static const int up_split = getenv("SBV2_CLX_UPSPLIT") ? atoi(getenv("SBV2_CLX_UPSPLIT")) : 1;
+        bool parts_done = clx && up_split != 0;   // every phase group's launch wrote its share of XUs
         for (const auto& g : st.up) {
             ConvClParams p;
             p.X = cur;
@@ -259,32 +286,17 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             p.out_stride = st.rate;
             p.phase_rows = C;
             for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
+            if (clx && up_split && conv_cl_parts_ok(p)) {
+                p.ys_p = XUs.p;
+                p.ys_rows = (int64_t)XUs.front + XUs.N + XUs.back;
+                p.ys_front = XUs.front;
+                p.ys_slope = 0.1f;
+            } else {
+                parts_done = false;
+            }
             launch_conv_cl(p, stream_);
         }
-        // Wide stages (>= 128 channels, split-bf16): the ResBlock convolutions read PRE-SPLIT operands (conv_clx.hip: LDS-DMA only, one barrier
-        // per tap).  The stage input is split once (split_cl); every other operand is written by the producing convolution's epilogue as the
-        // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
-        int ushift = 0;
-        while ((1 << ushift) < U) ++ushift;
-        // (large launches only: a single utterance or a streaming window has too few tiles to pay for the extra split / halo launches; the two
-        // paths give the same bits, so the choice is free)
-        static const int clx_min_c = getenv("SBV2_CLX_MINC") ? atoi(getenv("SBV2_CLX_MINC")) : 128;   // A/B knob
-        bool clx = clx_enabled() && dec_mode_ == 1 && C >= clx_min_c && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
-        for (int j = 0; j < nk && clx; ++j) {
-            const ClBranch& rb = st.branches[j];
-            if (!(rb.k == 3 || rb.k == 7 || rb.k == 11)) clx = false;
-            for (int d : rb.dil)
-                if (d * (rb.k - 1) > 64 || d * (rb.k - 1) / 2 > kClxFront) clx = false;
-        }
-        SplitClPlanes XUs, T1s, YsA, YsB;
-        if (clx) {
-            const size_t sb = split_cl_bytes(C, Lo);
-            XUs = make_split_cl(ar.alloc(sb), C, Lo, stream_);
-            T1s = make_split_cl(ar.alloc(sb), C, Lo, stream_);
-            YsA = make_split_cl(ar.alloc(sb), C, Lo, stream_);
-            YsB = make_split_cl(ar.alloc(sb), C, Lo, stream_);
-            split_cl(XU, C, Lo, C, 0.1f, XUs, stream_);
-        }
+        if (clx && !parts_done) split_cl(XU, C, Lo, C, 0.1f, XUs, stream_);   // (small launches: one pass over the finished plane, same bits)
         for (int j = 0; j < nk; ++j) {
             const ClBranch& rb = st.branches[j];
             const float* y = XU;
