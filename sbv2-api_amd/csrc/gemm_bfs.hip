@@ -440,13 +440,19 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
     const bool lone = blocks(128, 128) <= 256;
     const bool k32 = (p.K & 31) == 0;
     // configuration id (SBV2_BFS_SLOTS, experiments): tens = chunks per slot, units = slots
-    // 64 x 128 tiles (experiment, SBV2_BFS_HALF=1): products whose 128 x 128 tiling leaves half of the CUs without a workgroup (DeBERTa's 1024-row
-    // products at 2176 tokens: 136 workgroups) as twice as many half-height workgroups; same per-element summation order
-    static const int half = getenv("SBV2_BFS_HALF") ? atoi(getenv("SBV2_BFS_HALF")) : 1;
+    // Tile policy of the large f16x3 products (SBV2_BFS_HALF; same per-element summation order in every case).  5 (default, round 4): 64 x 128 tiles on a
+    // 4-slot ring = 48 KB and 99 registers: THREE workgroups per CU instead of two 128 x 128 ones (80 KB, 222 registers): gemm_bfs 8.07 -> 7.13 ms and the
+    // step -1.4 ms on the same box (the 128 x 128 grid of the 4096-row product is 544 workgroups on 512 slots, that of the 1024-row products 136).
+    // 0 = 128 x 128 everywhere (round 3); 1 = 64 x 128 (6 slots, two per CU) only where the 128 x 128 grid covers half the CUs; 2 = that tile everywhere;
+    // 6 = 3 slots / four per CU (7.7 ms); 7 = mode 1 on 4 slots
+    static const int half = getenv("SBV2_BFS_HALF") ? atoi(getenv("SBV2_BFS_HALF")) : 5;
     if (p.W.f16) {   // the ring shapes of bf16x3 (same bytes per chunk), two accumulator sets
         if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
         else if ((half == 1 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) || half == 2) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);
         else if (half == 3 && blocks(128, 128) > 512 && blocks(128, 128) < 640) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);   // (the 544-workgroup product too)
+        else if (half == 5) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);   // experiments: 64 x 128 everywhere, 48 KB: three workgroups per CU
+        else if (half == 6) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 3, true>(kp, stream);   // ... 36 KB: four per CU
+        else if (half == 7 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
         else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4, true>(kp, stream);
         else launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5, true>(kp, stream);
     } else if (p.W.parts == 2) {
