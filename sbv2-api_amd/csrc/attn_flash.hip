@@ -394,6 +394,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sacc, 0, 0, 0);
             }
             const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
+            const bool tail = j0 + 32 > T;   // (uniform) only the utterance's last key step has keys to mask
             float mt = kFaNegBig;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                         band_s[wave][rr][col] = sv;
                     }
                 }
-                sv = j < T ? sv : kFaNegBig;
+                if (tail) sv = j < T ? sv : kFaNegBig;
                 sacc[r] = sv;
                 mt = fmaxf(mt, sv);
             }
@@ -427,10 +428,14 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                 l = l * alpha + (lo + hi);
             }
             m = mn;
+            // (the running maximum of most columns stops moving after the first key steps: multiplying by exactly 1 changes nothing, so the 48
+            // multiplies are skipped whenever no lane of the wave has a new maximum: same bits)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+            }
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 float pv8[8];
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sacc, 0, 0, 0);
                 }
                 const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
+                const bool tail = j0 + 32 > T;   // (uniform) only the utterance's last key step has keys to mask
                 float mt = kFaNegBig;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                             band_s[wave][rr][col] = sv;
                         }
                     }
-                    sv = j < T ? sv : kFaNegBig;
+                    if (tail) sv = j < T ? sv : kFaNegBig;
                     sacc[r] = sv;
                     mt = fmaxf(mt, sv);
                 }
@@ -676,10 +682,14 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                     l = l * alpha + (lo + hi);
                 }
                 m = mn;
+                // (the running maximum of most columns stops moving after the first key steps: multiplying by exactly 1 changes nothing, so the 48
+                // multiplies are skipped whenever no lane of the wave has a new maximum: same bits)
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+                }
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     float pv8[8];
