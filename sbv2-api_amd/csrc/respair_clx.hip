@@ -71,19 +71,24 @@ __device__ __forceinline__ void rpx_write_b8(unsigned addr, unsigned v) { asm vo
 
 constexpr int rpx_max(int a, int b) { return a > b ? a : b; }
 
-template <int C, int NTAPS, int GT>
+// WNP = position groups of 64 per workgroup (0: the default of the channel count: 2 at C = 64, 4 below); a workgroup has NMT * WN waves
+template <int C, int NTAPS, int GT, int WNP = 0>
 struct RpxCfg {
     static constexpr int NCH = C / 16;                 // 16-channel chunks (the K dimension of one MFMA)
     static constexpr int NMT = C == 64 ? 2 : 1;        // 32-row tiles of the output channels (C = 16: half of the one tile is zero rows)
-    static constexpr int NT = C == 64 ? 128 : 256;     // positions of the intermediate per workgroup
+    static constexpr int WN = WNP > 0 ? WNP : (C == 64 ? 2 : 4);   // 64-position groups
+    static constexpr int NW = NMT * WN;                // waves
+    static constexpr int T = 64 * NW;                  // threads
+    static constexpr int NT = 64 * WN;                 // positions of the intermediate per workgroup
     static constexpr bool TWOTAP = C == 16;            // C = 16: two taps per 32-deep MFMA (v_mfma_f32_16x16x32_bf16), see the kernel
     static constexpr int NTW = TWOTAP ? (NTAPS + 1) / 2 : NTAPS;   // weight steps of a chunk: taps, or tap pairs
     static constexpr int G = NTW < GT ? NTW : GT;      // weight steps per group
     static constexpr int NG = (NTW + G - 1) / G;
     static constexpr int WSLOT = G * NMT * 2048;       // one weight buffer: [row tile][tap of the group][part][1 KB fragment block]
     static constexpr int WREG = 2 * WSLOT;
-    static constexpr int NXC = NT / 64 + 1;            // 64-row blocks of the conv1 window (NT + tap span <= NT + 64)
-    static constexpr int ROWS1 = NXC * 64;
+    static constexpr int RB = T / 4;                   // window rows one load instruction of the workgroup covers (4 threads per 64-byte row piece)
+    static constexpr int NXC = (NT + 64 + RB - 1) / RB;   // such blocks in the conv1 window (NT + tap span <= NT + 64)
+    static constexpr int ROWS1 = NXC * RB;
     static constexpr int ROWS2 = NT + NTAPS + 1;       // rows of the intermediate window (NT + k - 1 are read)
     // conv1 window, one chunk: [part][channel half][row] 16-byte cells.  32x32x16 kernels: + 64 puts the two halves a conversion store touches on
     // different bank halves (a fragment read touches one half only).  16x16x32 (C = 16): a fragment read touches BOTH halves (k groups 0 / 2 and 1 / 3):
@@ -95,7 +100,7 @@ struct RpxCfg {
     static constexpr int X2PART = NCH * X2CH;
     static constexpr int XREG = rpx_max(2 * X1PART, 2 * X2PART);   // the intermediate ALIASES the conv1 window
     static constexpr int TPITCH = TWOTAP ? 20 : 36;    // floats per row of the epilogue's transpose tiles
-    static constexpr int TT = 4 * 64 * TPITCH * 4;     // the epilogue's per-wave transpose tiles (overlay everything above)
+    static constexpr int TT = NW * 64 * TPITCH * 4;    // the epilogue's per-wave transpose tiles (overlay everything above)
     static constexpr int MAIN = rpx_max(WREG + XREG, TT);
     static constexpr int BIAS_OFF = MAIN;              // 64 floats b1, 64 floats b2
     static constexpr int MASK_OFF = MAIN + 512;        // one byte per row of the intermediate
@@ -104,9 +109,10 @@ struct RpxCfg {
 };
 
 // DG >= 0: diagnostic instantiation (phase stamps of thread 0 into p.stamps[16 per workgroup]; sbv2_debug_respair_clock)
-template <int C, int NTAPS, int DG, int GT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && GT == 4 ? 2 : 3))) void respair_clx_kernel(const ResPairParams p) {
-    using K = RpxCfg<C, NTAPS, GT>;
+template <int C, int NTAPS, int DG, int GT, int WNP = 0>
+__global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdgpu_waves_per_eu(C == 64 && GT == 4 && WNP == 0 ? 2 : 3))) void respair_clx_kernel(const ResPairParams p) {
+    using K = RpxCfg<C, NTAPS, GT, WNP>;
+    constexpr int T = K::T, NW = K::NW, WN = K::WN, RB = K::RB;
     constexpr bool DIAG = DG >= 0;
     constexpr int NCH = K::NCH, NMT = K::NMT, NT = K::NT, G = K::G, NG = K::NG, NXC = K::NXC, NTW = K::NTW;
     constexpr bool TWOTAP = K::TWOTAP;
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = NMT == 2 ? wave >> 1 : 0;           // this wave's 32-row tile of the output channels
-    const int wn = NMT == 2 ? wave & 1 : wave;         // ... and its 64 positions
+    const int wm = NMT == 2 ? wave / WN : 0;           // this wave's 32-row tile of the output channels
+    const int wn = NMT == 2 ? wave - wm * WN : wave;   // ... and its 64 positions
     const int lcol = lane & 31, lh = lane >> 5;
     const int d = p.dil, h1 = d * h2, NB = p.N;
     const int ntiles = (NB + nto - 1) / nto;
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
         constexpr int NP = NMT * G * 2;                 // 1 KB piece slots of a buffer
         const char* W = static_cast<const char*>(TWOTAP ? (conv ? p.W2p : p.W1p) : (conv ? p.W2 : p.W1));
 #pragma unroll
-        for (int i = 0; i < (NP + 3) / 4; ++i) {
-            const int pc = wave + 4 * i;                // (uniform) piece = ((row tile * G + tap in group) * 2 + part)
+        for (int i = 0; i < (NP + NW - 1) / NW; ++i) {
+            const int pc = wave + NW * i;               // (uniform) piece = ((row tile * G + tap in group) * 2 + part)
             const int part = pc & 1, tgx = pc >> 1, mt = tgx / G, tg = tgx - mt * G;
             if (pc < NP && tg < ntg) {
                 const char* src = W + ((((int64_t)(chunk * NMT + mt) * NTW + g * G + tg) * 2 + part) << 10) + lane * 16;
@@ -176,13 +182,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
 #pragma unroll
             for (int c = 0; c < PAIR; ++c)
 #pragma unroll
-                for (int i = 0; i < NXC; ++i) rx[c][i] = *reinterpret_cast<const f32x4v*>(b + (i * 64 * C * 4 + c * 64) + (size_t)xlane);
+                for (int i = 0; i < NXC; ++i) rx[c][i] = *reinterpret_cast<const f32x4v*>(b + (i * RB * C * 4 + c * 64) + (size_t)xlane);
         } else {
 #pragma unroll
             for (int c = 0; c < PAIR; ++c)
 #pragma unroll
                 for (int i = 0; i < NXC; ++i) {
-                    const int pos = min(max(wstart + i * 64 + (tid >> 2), 0), NB - 1);
+                    const int pos = min(max(wstart + i * RB + (tid >> 2), 0), NB - 1);
                     rx[c][i] = *reinterpret_cast<const f32x4v*>(p.X + (int64_t)pos * C + (pr * PAIR + c) * 16 + (tid & 3) * 4);
                 }
         }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
             constexpr int i = decltype(ic)::value;
             f32x4v v = rx[c][i];
             if constexpr (EDGE) {
-                const int pos = wstart + i * 64 + (tid >> 2);
+                const int pos = wstart + i * RB + (tid >> 2);
                 if (pos < 0 || pos >= NB) v = f32x4v{0.f, 0.f, 0.f, 0.f};
             }
             bf16x4 h, l;
@@ -206,8 +212,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
                 h[e] = (__bf16)x;
                 l[e] = (__bf16)(x - (float)h[e]);
             }
-            rpx_write_b64<i * 1024>(x1w, h);
-            rpx_write_b64<K::X1PART + i * 1024>(x1w, l);
+            rpx_write_b64<i * RB * 16>(x1w, h);
+            rpx_write_b64<K::X1PART + i * RB * 16>(x1w, l);
         });
     };
     auto convert = [&](auto cc) {
@@ -367,11 +373,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
     {
         // biases and the keep flags of the intermediate's rows (position inside the batch and not masked), parked in LDS for both epilogues
         const float bval = tid < 128 ? (tid < 64 ? p.b1[min(tid, C - 1)] : p.b2[min(tid - 64, C - 1)]) : 0.f;
-        constexpr int NMV = (K::ROWS2 + 255) / 256;   // (ROWS2 <= 512)
+        constexpr int NMV = (K::ROWS2 + T - 1) / T;
         unsigned mval[NMV];
 #pragma unroll
         for (int h = 0; h < NMV; ++h) {
-            const int pos = t0 + tid + h * 256;
+            const int pos = t0 + tid + h * T;
             const int pc = min(max(pos, 0), NB - 1);
             const unsigned m = p.mask ? p.mask[pc >> p.mask_shift] : 1u;
             mval[h] = (pos >= 0 && pos < NB) ? m : 0u;
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
         if (tid < 128) rpx_write_b32(lds0 + K::BIAS_OFF + tid * 4, bval);
 #pragma unroll
         for (int h = 0; h < NMV; ++h)
-            if (tid + h * 256 < K::ROWS2) rpx_write_b8(lds0 + K::MASK_OFF + tid + h * 256, mval[h]);
+            if (tid + h * T < K::ROWS2) rpx_write_b8(lds0 + K::MASK_OFF + tid + h * T, mval[h]);
     }
     convert(std::integral_constant<int, 0>{});
     RPX_STAMP(1);
@@ -549,11 +555,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 && 
 #undef RPX_STAMP
 }
 
-template <int C, int NTAPS, int DG, int GT>
+template <int C, int NTAPS, int DG, int GT, int WNP = 0>
 static void launch_rpx(const ResPairParams& p, hipStream_t stream) {
-    using K = RpxCfg<C, NTAPS, GT>;
+    using K = RpxCfg<C, NTAPS, GT, WNP>;
     static_assert(K::LDS <= 160 * 1024, "LDS budget");
-    auto kern = respair_clx_kernel<C, NTAPS, DG, GT>;
+    auto kern = respair_clx_kernel<C, NTAPS, DG, GT, WNP>;
     static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     constexpr int nto = K::NT - (NTAPS - 1);
@@ -566,7 +572,7 @@ static void launch_rpx(const ResPairParams& p, hipStream_t stream) {
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), K::LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(K::T), K::LDS, stream, p);
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -587,6 +593,21 @@ static void launch_rpx_any(const ResPairParams& p, hipStream_t stream) {
     static const int g64 = getenv("SBV2_RPX_G64") ? atoi(getenv("SBV2_RPX_G64")) : 2;
 #define RPX_CASE(CC, KK) \
     if (p.C == CC && p.k == KK) return launch_rpx<CC, KK, DG, 4>(p, stream);
+    // experiments (measured, slower): wider tiles on 6-wave workgroups, two per CU: a third less weight traffic per FLOP and less halo, the same 12 waves
+    // per CU, and 20-30 % MORE time (C = 64, k = 7: 0.62 -> 0.77 ms per half-size launch; C = 32: 0.36 -> 0.47): three independent workgroups in
+    // different phases are worth more than what two larger ones save
+    static const int wn64 = getenv("SBV2_RPX_WN64") ? atoi(getenv("SBV2_RPX_WN64")) : 0;   // 3 = 192-position tiles on 6 waves at C = 64
+    static const int wn32 = getenv("SBV2_RPX_WN32") ? atoi(getenv("SBV2_RPX_WN32")) : 0;   // 6 = 384-position tiles on 6 waves at C = 32
+    if (p.C == 64 && wn64 == 3) {
+        if (p.k == 3) return launch_rpx<64, 3, DG, 2, 3>(p, stream);
+        if (p.k == 7) return launch_rpx<64, 7, DG, 2, 3>(p, stream);
+        if (p.k == 11) return launch_rpx<64, 11, DG, 2, 3>(p, stream);
+    }
+    if (p.C == 32 && wn32 == 6) {
+        if (p.k == 3) return launch_rpx<32, 3, DG, 4, 6>(p, stream);
+        if (p.k == 7) return launch_rpx<32, 7, DG, 4, 6>(p, stream);
+        if (p.k == 11) return launch_rpx<32, 11, DG, 4, 6>(p, stream);
+    }
     if (p.C == 64 && g64 == 2) {
         if (p.k == 3) return launch_rpx<64, 3, DG, 2>(p, stream);
         if (p.k == 7) return launch_rpx<64, 7, DG, 2>(p, stream);
