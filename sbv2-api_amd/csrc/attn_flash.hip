@@ -102,12 +102,23 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         float part[kFaBand];
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
-#pragma unroll 2
-        for (int s = 0; s < NS; ++s) {
-            const int d = 2 * s + kh;
-            const float qd = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+        // (blocks of 16 k-steps: the 16 loads of a block are in flight together; one load per step with its use right behind it exposed the
+        // global latency 24 times per workgroup, 12-20 us of an 84 us single-utterance launch.  Same order of additions.)
+#pragma unroll 1
+        for (int sb = 0; sb < NS; sb += 16) {
+            float qd[16];
 #pragma unroll
-            for (int r = 0; r < kFaBand; ++r) part[r] += qd * erk_s[r * DR + d];
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+                const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];   // (unconditional: no branch around the load)
+                qd[u] = d < dk ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+#pragma unroll
+                for (int r = 0; r < kFaBand; ++r) part[r] += qd[u] * erk_s[r * DR + d];
+            }
         }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
@@ -148,20 +159,28 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             for (int s = 0; s < NS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * s + kh) * kFaPitch + col], qv[s], sacc, 0, 0, 0);
             const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;   // wave-uniform: the tile touches the +-w band
             float mt = kFaNegBig;
+            if (diag) {   // (one wave-uniform branch per key step instead of one per element)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float sv = sacc[r] * qscale;
-                if (diag) {
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    float sv = sacc[r] * qscale;
                     const int rr = j - i + w;
                     if (rr >= 0 && rr < nb && j < T) {
                         sv += rk_s[wave][rr][col];
                         band_s[wave][rr][col] = sv;
                     }
+                    sv = j < T ? sv : kFaNegBig;
+                    sacc[r] = sv;
+                    mt = fmaxf(mt, sv);
                 }
-                sv = j < T ? sv : kFaNegBig;
-                sacc[r] = sv;
-                mt = fmaxf(mt, sv);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float sv = j < T ? sacc[r] * qscale : kFaNegBig;
+                    sacc[r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mn = fmaxf(m, mt);
@@ -339,12 +358,21 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         float part[kFaBand];
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
-#pragma unroll 2
-        for (int s = 0; s < DR / 2; ++s) {
-            const int d = 2 * s + kh;
-            const float qd = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+#pragma unroll 1
+        for (int sb = 0; sb < DR / 2; sb += 16) {   // blocks of 16 loads in flight together (see k_vits_flash)
+            float qd[16];
 #pragma unroll
-            for (int r = 0; r < kFaBand; ++r) part[r] += qd * erk_s[r * DR + d];
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+                const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];   // (unconditional: no branch around the load)
+                qd[u] = d < dk ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+#pragma unroll
+                for (int r = 0; r < kFaBand; ++r) part[r] += qd[u] * erk_s[r * DR + d];
+            }
         }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
@@ -396,20 +424,36 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
             const bool tail = j0 + 32 > T;   // (uniform) only the utterance's last key step has keys to mask
             float mt = kFaNegBig;
+            // three copies of the loop behind ONE wave-uniform branch: tested per element, `diag` and `tail` were 32 taken branches per key step
+            // (a quarter of the step's issue time); interior steps, all but two or three per wave, are 16 multiplies and 16 maxima
+            if (diag) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float sv = sacc[r] * qs2;
-                if (diag) {
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    float sv = sacc[r] * qs2;
                     const int rr = j - i + w;
                     if (rr >= 0 && rr < nb && j < T) {
                         sv += rk_s[wave][rr][col];
                         band_s[wave][rr][col] = sv;
                     }
+                    if (tail) sv = j < T ? sv : kFaNegBig;
+                    sacc[r] = sv;
+                    mt = fmaxf(mt, sv);
                 }
-                if (tail) sv = j < T ? sv : kFaNegBig;
-                sacc[r] = sv;
-                mt = fmaxf(mt, sv);
+            } else if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float sv = j < T ? sacc[r] * qs2 : kFaNegBig;
+                    sacc[r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] *= qs2;
+                    mt = fmaxf(mt, sacc[r]);
+                }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mn = fmaxf(m, mt);
@@ -572,12 +616,21 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         float part[kFaBand];
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
-#pragma unroll 2
-        for (int s = 0; s < DR / 2; ++s) {
-            const int d = 2 * s + kh;
-            const float qd = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+#pragma unroll 1
+        for (int sb = 0; sb < DR / 2; sb += 16) {   // blocks of 16 loads in flight together (see k_vits_flash)
+            float qd[16];
 #pragma unroll
-            for (int r = 0; r < kFaBand; ++r) part[r] += qd * erk_s[r * DR + d];
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+                const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];   // (unconditional: no branch around the load)
+                qd[u] = d < dk ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+#pragma unroll
+                for (int r = 0; r < kFaBand; ++r) part[r] += qd[u] * erk_s[r * DR + d];
+            }
         }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
@@ -650,20 +703,36 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                 const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
                 const bool tail = j0 + 32 > T;   // (uniform) only the utterance's last key step has keys to mask
                 float mt = kFaNegBig;
+                // three copies of the loop behind ONE wave-uniform branch: tested per element, `diag` and `tail` were 32 taken branches per key step
+                // (a quarter of the step's issue time); interior steps, all but two or three per wave, are 16 multiplies and 16 maxima
+                if (diag) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    float sv = sacc[r] * qs2;
-                    if (diag) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        float sv = sacc[r] * qs2;
                         const int rr = j - i + w;
                         if (rr >= 0 && rr < nb && j < T) {
                             sv += rk_s[wave][rr][col];
                             band_s[wave][rr][col] = sv;
                         }
+                        if (tail) sv = j < T ? sv : kFaNegBig;
+                        sacc[r] = sv;
+                        mt = fmaxf(mt, sv);
                     }
-                    if (tail) sv = j < T ? sv : kFaNegBig;
-                    sacc[r] = sv;
-                    mt = fmaxf(mt, sv);
+                } else if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        const float sv = j < T ? sacc[r] * qs2 : kFaNegBig;
+                        sacc[r] = sv;
+                        mt = fmaxf(mt, sv);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sacc[r] *= qs2;
+                        mt = fmaxf(mt, sacc[r]);
+                    }
                 }
                 mt = fmaxf(mt, __shfl_xor(mt, 32));
                 const float mn = fmaxf(m, mt);
