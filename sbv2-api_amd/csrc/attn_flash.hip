@@ -36,6 +36,14 @@ constexpr int kFaMaxWin = 4;
 constexpr int kFaBand = 2 * kFaMaxWin + 1;
 constexpr float kFaNegBig = -1e30f;
 
+// The two halves of a wave exchange a value (lane l <-> lane l ^ 32) with ONE v_permlane32_swap instead of a round trip through the LDS crossbar
+// (ds_bpermute: ~100 cycles of latency, twice per key step on the softmax's critical path).  lo = the value of lane l & 31, hi = that of lane (l & 31) + 32.
+__device__ __forceinline__ void fa_halves(float x, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
 template <int DT>
 __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_vits_flash(const AttnGroup* groups, const float* Q, const float* K, const float* V, int ld,
                                                             float* ctx, int ldc, int dk, const float* erk, const float* erv, int w,
@@ -122,9 +130,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
-            const float other = __shfl_xor(part[r], 32);   // executed by every lane (not inside the select)
-            const float lo = kh ? other : part[r];          // fixed order: (even d) + (odd d) in both halves
-            const float hi = kh ? part[r] : other;
+            float lo, hi;                                   // fixed order: (even d) + (odd d) in both halves
+            fa_halves(part[r], lo, hi);
             rk_s[wave][r][col] = (lo + hi) * qscale;
             band_s[wave][r][col] = kFaNegBig;
         }
@@ -135,7 +142,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int d = 2 * s + kh;
-        qv[s] = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+        const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];
+        qv[s] = d < dk ? x : 0.f;
     }
 
     f32x16 cacc[DT];
@@ -182,7 +190,11 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                     mt = fmaxf(mt, sv);
                 }
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            {
+                float lo, hi;
+                fa_halves(mt, lo, hi);
+                mt = fmaxf(mt, kh ? lo : hi);
+            }
             const float mn = fmaxf(m, mt);
             const float alpha = expf(m - mn);
             float ps = 0.f;
@@ -193,9 +205,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                 ps += e;
             }
             {
-                const float other = __shfl_xor(ps, 32);
-                const float lo = kh ? other : ps;
-                const float hi = kh ? ps : other;
+                float lo, hi;
+                fa_halves(ps, lo, hi);
                 l = l * alpha + (lo + hi);
             }
             m = mn;
@@ -376,9 +387,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
-            const float other = __shfl_xor(part[r], 32);
-            const float lo = kh ? other : part[r];
-            const float hi = kh ? part[r] : other;
+            float lo, hi;
+            fa_halves(part[r], lo, hi);
             rk_s[wave][r][col] = (lo + hi) * qs2;
             band_s[wave][r][col] = kFaNegBig;
         }
@@ -391,7 +401,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int d = 16 * s + 8 * kh + t;
-            v[t] = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+            const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];
+            v[t] = d < dk ? x : 0.f;
         }
         fa_split8(v, qh[s], ql[s]);
     }
@@ -455,7 +466,11 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                     mt = fmaxf(mt, sacc[r]);
                 }
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            {
+                float lo, hi;
+                fa_halves(mt, lo, hi);
+                mt = fmaxf(mt, kh ? lo : hi);
+            }
             const float mn = fmaxf(m, mt);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
             float ps = 0.f;
@@ -466,9 +481,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                 ps += e;
             }
             {
-                const float other = __shfl_xor(ps, 32);
-                const float lo = kh ? other : ps;
-                const float hi = kh ? ps : other;
+                float lo, hi;
+                fa_halves(ps, lo, hi);
                 l = l * alpha + (lo + hi);
             }
             m = mn;
@@ -591,6 +605,18 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         }
     };
     auto store_tile = [&](int j0) {
+        if (j0 + kFpKeys <= T && dk == DR) {   // (uniform) an interior tile of a full-width head: nothing to mask, 24 stores and no VALU work
+#pragma unroll
+            for (int p = 0; p < NL; ++p) {
+                const int d = ty + 16 * p;
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    *reinterpret_cast<uint2*>(kt + (part * DR + d) * kFpKS + 8 * tx) = kreg[part][p];
+                    *reinterpret_cast<uint2*>(vt + (part * DR + d) * kFpVS + 8 * tx) = vreg[part][p];
+                }
+            }
+            return;
+        }
         // keys beyond the utterance and rows beyond dk: zero operands (their scores are masked anyway, V must not carry garbage)
         const int nv = min(max(T - (j0 + 4 * tx), 0), 4);
         const unsigned m0 = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
@@ -634,9 +660,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
         }
 #pragma unroll
         for (int r = 0; r < kFaBand; ++r) {
-            const float other = __shfl_xor(part[r], 32);
-            const float lo = kh ? other : part[r];
-            const float hi = kh ? part[r] : other;
+            float lo, hi;
+            fa_halves(part[r], lo, hi);
             rk_s[wave][r][col] = (lo + hi) * qs2;
             band_s[wave][r][col] = kFaNegBig;
         }
@@ -648,7 +673,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int d = 16 * s + 8 * kh + t;
-            v[t] = d < dk ? Qg[(int64_t)min(d, dk - 1) * ld + ic] : 0.f;
+            const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];
+            v[t] = d < dk ? x : 0.f;
         }
         fa_split8(v, qh[s], ql[s]);
     }
@@ -734,7 +760,11 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                         mt = fmaxf(mt, sacc[r]);
                     }
                 }
-                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                {
+                float lo, hi;
+                fa_halves(mt, lo, hi);
+                mt = fmaxf(mt, kh ? lo : hi);
+            }
                 const float mn = fmaxf(m, mt);
                 const float alpha = __builtin_amdgcn_exp2f(m - mn);
                 float ps = 0.f;
@@ -745,9 +775,8 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                     ps += e;
                 }
                 {
-                    const float other = __shfl_xor(ps, 32);
-                    const float lo = kh ? other : ps;
-                    const float hi = kh ? ps : other;
+                    float lo, hi;
+                    fa_halves(ps, lo, hi);
                     l = l * alpha + (lo + hi);
                 }
                 m = mn;
