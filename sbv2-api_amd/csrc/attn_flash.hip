@@ -21,9 +21,17 @@
 // the batch, as the packed-batch contract requires.
 #include <atomic>
 #include <cfloat>
+#include <type_traits>
+#include <vector>
+#include <cstdio>
 
 #include "common.h"
 #include "ops.h"
+
+// No floating-point contraction in this file: the three split-bf16 kernels below (converting, pre-split, pre-split + pipelined) promise the SAME bits
+// (a batch row runs on one, the single-utterance call on another), and whether `a * b + c` becomes one fma is otherwise the optimiser's choice per
+// kernel (it differed: x * qs2 - max fused in one kernel and not in the other, 3e-7 on the waveform).  Every fma that is wanted is written as fmaf.
+#pragma clang fp contract(off)
 
 namespace sbv2 {
 
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             for (int u = 0; u < 16; ++u) {
                 const int d = 2 * (sb + u) + kh;
 #pragma unroll
-                for (int r = 0; r < kFaBand; ++r) part[r] += qd[u] * erk_s[r * DR + d];
+                for (int r = 0; r < kFaBand; ++r) part[r] = fmaf(qd[u], erk_s[r * DR + d], part[r]);
             }
         }
 #pragma unroll
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             {
                 float lo, hi;
                 fa_halves(ps, lo, hi);
-                l = l * alpha + (lo + hi);
+                l = fmaf(l, alpha, lo + hi);
             }
             m = mn;
 #pragma unroll
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             float v = cacc[dt][r] * inv;
 #pragma unroll
-            for (int b = 0; b < kFaBand; ++b) v += pb[b] * erv_s[b * DR + d];
+            for (int b = 0; b < kFaBand; ++b) v = fmaf(pb[b], erv_s[b * DR + d], v);
             if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
         }
 }
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             for (int u = 0; u < 16; ++u) {
                 const int d = 2 * (sb + u) + kh;
 #pragma unroll
-                for (int r = 0; r < kFaBand; ++r) part[r] += qd[u] * erk_s[r * DR + d];
+                for (int r = 0; r < kFaBand; ++r) part[r] = fmaf(qd[u], erk_s[r * DR + d], part[r]);
             }
         }
 #pragma unroll
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             {
                 float lo, hi;
                 fa_halves(ps, lo, hi);
-                l = l * alpha + (lo + hi);
+                l = fmaf(l, alpha, lo + hi);
             }
             m = mn;
             // (the running maximum of most columns stops moving after the first key steps: multiplying by exactly 1 changes nothing, so the 48
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             float v = cacc[dt][r] * inv;
 #pragma unroll
-            for (int b = 0; b < kFaBand; ++b) v += pb[b] * erv_s[b * DR + d];
+            for (int b = 0; b < kFaBand; ++b) v = fmaf(pb[b], erv_s[b * DR + d], v);
             if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
         }
 }
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             for (int u = 0; u < 16; ++u) {
                 const int d = 2 * (sb + u) + kh;
 #pragma unroll
-                for (int r = 0; r < kFaBand; ++r) part[r] += qd[u] * erk_s[r * DR + d];
+                for (int r = 0; r < kFaBand; ++r) part[r] = fmaf(qd[u], erk_s[r * DR + d], part[r]);
             }
         }
 #pragma unroll
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
                 {
                     float lo, hi;
                     fa_halves(ps, lo, hi);
-                    l = l * alpha + (lo + hi);
+                    l = fmaf(l, alpha, lo + hi);
                 }
                 m = mn;
                 // (the running maximum of most columns stops moving after the first key steps: multiplying by exactly 1 changes nothing, so the 48
@@ -821,9 +829,549 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
             const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             float v = cacc[dt][r] * inv;
 #pragma unroll
-            for (int b = 0; b < kFaBand; ++b) v += pb[b] * erv_s[b * DR + d];
+            for (int b = 0; b < kFaBand; ++b) v = fmaf(pb[b], erv_s[b * DR + d], v);
             if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The pre-split attention, software-pipelined (round 4): k_vits_flash_x3q.  Measured on k_vits_flash_x3 / x3p (ISA + kernel trace): a 32-key step
+// costs a lone wave ~6 700 cycles for 1 152 cycles of MFMA: every phase waits for the one before it (fragment reads -> 18 chained MFMAs -> 190
+// VALU instructions of softmax -> fragment reads -> 18 MFMAs), the staging registers (48) leave the compiler no room to read fragments ahead, and two
+// waves per SIMD only interleave 1.3x.  Here
+//   * K / V tiles (64 keys, both parts) go L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double-buffered, no staging registers and no staging
+//     instructions; a tile image is [part][d][64 keys] with 128-byte rows, its 16-byte segments XOR-swizzled on the DMA's SOURCE address
+//     (K: segment ^ 2 ((d >> 1) & 3): the transposing reads of a 16-lane group touch 4 rows x 32 bytes on disjoint banks; V: segment ^ ((d >> 1) & 7): the
+//     16 rows a group of 8-byte reads touches fall on 16 distinct bank pairs);
+//   * the wave's program is pipelined by one key step: QK(t + 1)'s 18 MFMAs are issued with the softmax of step t dealt into their gaps (scale / max,
+//     exponentials, the split of P), then PV(t)'s 18 MFMAs, term-major over the three accumulators; fragment reads run two MFMA groups ahead;
+//   * one barrier per key step (K tile u + 1 is requested at the barrier of step 2u - 1 and needed at that of step 2u + 1; V tile u + 1 at 2u / 2u + 2).
+// The arithmetic and its order per accumulator are those of k_vits_flash_x3: same bits (tests/test_gpu_parity.py).
+// The utterance's last tile, when T is no multiple of 64, is completed by a fix-up pass (keys >= T zero: V must not carry garbage; the segment that
+// straddles T copied element-wise: the DMA of such a segment reads a clamped in-row address instead).
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void fq_lds_t;
+typedef const __attribute__((address_space(1))) void fq_gbl_t;
+template <int OFF>
+__device__ __forceinline__ fa_s16x4 fq_read_tr(unsigned addr) {
+    fa_s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint2 fq_read_b64(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void fq_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fq_static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void fq_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// DG: builder's timeline variant (SBV2_FLASH_Q_STAMPS=<file>): s_memtime at every barrier / phase boundary of every wave of workgroup (0, 0), kept in LDS
+template <int DT, int NW, bool DG = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vits_flash_x3q(const AttnGroup* groups, const float* Q, int ld, const __bf16* Kp, const __bf16* Vp,
+                                                              int64_t pstride, int ldp, float* ctx, int ldc, int dk, const float* erk, const float* erv,
+                                                              int w, float qscale, unsigned long long* stamps = nullptr) {
+    constexpr int DR = DT * 32;
+    constexpr int KS = DR / 16;            // bf16 k-steps over the head dimension
+    constexpr int NB8 = DR / 8;            // 8-row DMA blocks per part (1 KB each)
+    constexpr int PART = DR * 128;         // bytes of one part of a tile image
+    constexpr int IMG = 2 * PART;          // one tile image
+    constexpr int NI = 2 * NB8 / NW;       // DMAs per wave, matrix and tile
+    static_assert((2 * NB8) % NW == 0 && NI >= 1, "a tile's DMA blocks are dealt evenly over the waves");
+    constexpr int NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) char fq_smem[];
+    // LDS: K images [2] | V images [2] | erk | erv | rk [NW] | band [NW]
+    float* erk_s = reinterpret_cast<float*>(fq_smem + 4 * IMG);
+    float* erv_s = erk_s + kFaBand * DR;
+    float (*rk_s)[kFaBand][32] = reinterpret_cast<float (*)[kFaBand][32]>(erv_s + kFaBand * DR);
+    float (*band_s)[kFaBand][32] = rk_s + NW;
+    const unsigned lds_k0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)fq_smem);
+    const unsigned lds_v0 = lds_k0 + 2 * IMG;
+    constexpr int kStampMax = 160;   // per wave
+    const unsigned lds_st = lds_k0 + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32);
+    int nst = 0;
+    auto stamp = [&]() {
+        if constexpr (DG) {
+            if (nst < kStampMax) {
+                const unsigned long long tm = __builtin_amdgcn_s_memtime();
+                const unsigned a = lds_st + ((threadIdx.x >> 6) * kStampMax + nst) * 8;
+                asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(tm) : "memory");
+                ++nst;
+            }
+        }
+    };
+
+    const AttnGroup g = groups[blockIdx.y];
+    const int T = g.T;
+    const int q0 = blockIdx.x * (32 * NW);
+    if (q0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < T;
+    const int i = i0 + col;
+    const int ic = min(i, T - 1);
+    const float* Qg = Q + (int64_t)g.head * dk * ld + g.col0;
+    const int64_t poff = (int64_t)g.head * dk * ldp + g.col0;
+    const int nb = 2 * w + 1;
+    const float qs2 = qscale * 1.4426950408889634f;   // base-2 logits, as in k_vits_flash_x3
+    const int ntiles = (T + 63) >> 6, nsteps = (T + 31) >> 5;
+
+    // ---- DMA: instruction i of this wave moves block e = wave + NW i (part e / NB8, rows 8 (e % NB8) .. + 7); lane -> row lane / 8, LDS segment lane % 8
+    const int drow = lane >> 3, dseg = lane & 7;
+    const int kgseg = dseg ^ (2 * ((drow >> 1) & 3)), vgseg = dseg ^ ((drow >> 1) & 3);   // the GLOBAL segment this lane's LDS segment holds (V: even blocks)
+    const int nblk = dk >> 3;              // blocks that exist (dk is a multiple of 8); blocks beyond repeat the last one (their q / outputs are unused)
+    // (V's swizzle takes bit 3 of the row as well: odd 8-row blocks hold global segment ^ 4)
+    auto dma_tile = [&](const __bf16* base, int gseg, int odd_xor, int u, unsigned img) {
+        const __bf16* lrow = base + poff + (int64_t)drow * ldp;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int e = wave + NW * q;
+            const int part = e / NB8, blk = e - part * NB8;
+            const int jq = u * 64 + 8 * (gseg ^ ((blk & 1) ? odd_xor : 0));
+            const int colq = jq + 8 <= T ? jq : max(min(jq, T - 8), 0);   // a segment that is not whole inside the utterance: a clamped in-row address (fix-up)
+            const int64_t uo = (int64_t)part * pstride + (int64_t)min(blk, nblk - 1) * 8 * ldp;   // wave-uniform
+            __builtin_amdgcn_global_load_lds((fq_gbl_t*)(lrow + uo + colq), (fq_lds_t*)(uintptr_t)(img + part * PART + blk * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_k = [&](int u) { dma_tile(Kp, kgseg, 0, u, lds_k0 + (u & 1) * IMG); };
+    auto dma_v = [&](int u) { dma_tile(Vp, vgseg, 4, u, lds_v0 + (u & 1) * IMG); };
+    // the utterance's last tile, T % 64 != 0: segments k0 / 8 .. 7 of every row rewritten (valid keys copied, the rest zero)
+    auto fixup_tail = [&]() {
+        const int u = ntiles - 1, tl = T - u * 64, k0 = tl & ~7, nseg = 8 - (k0 >> 3);
+        const int items = 4 * DR * nseg;
+        for (int it = tid; it < items; it += NTH) {
+            const int seg = (k0 >> 3) + it % nseg, r = it / nseg;
+            const int d = r % DR, mp = r / DR, part = mp & 1, mat = mp >> 1;
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(mat ? Vp : Kp) + (int64_t)part * pstride + poff + (int64_t)min(d, dk - 1) * ldp + u * 64;
+            unsigned short v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * seg + e;
+                v[e] = (k < tl && d < dk) ? src[k] : (unsigned short)0;
+            }
+            const int swz = mat ? ((d >> 1) & 7) : 2 * ((d >> 1) & 3);
+            uint4 o = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
+                       (unsigned)v[6] | ((unsigned)v[7] << 16)};
+            *reinterpret_cast<uint4*>(fq_smem + (mat ? 2 * IMG : 0) + (u & 1) * IMG + part * PART + d * 128 + ((seg ^ swz) << 4)) = o;
+        }
+    };
+    const bool has_tail = (T & 63) != 0;
+    const int t_fix = 2 * (ntiles - 1) - 1;   // the barrier at which the tail tile is completed (-1 = the one in front of the loop)
+
+    dma_k(0);
+    dma_v(0);
+    for (int idx = tid; idx < kFaBand * DR; idx += NTH) {
+        const int r = idx / DR, d = idx - r * DR;
+        const bool in = r < nb && d < dk;
+        erk_s[idx] = in ? erk[r * dk + d] : 0.f;
+        erv_s[idx] = in ? erv[r * dk + d] : 0.f;
+    }
+    __syncthreads();   // erk_s / erv_s
+    {   // relative-key logits (f32, as in k_vits_flash)
+        float part[kFaBand];
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) part[r] = 0.f;
+#pragma unroll 1
+        for (int sb = 0; sb < DR / 2; sb += 16) {
+            float qd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+                const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];
+                qd[u] = d < dk ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int d = 2 * (sb + u) + kh;
+#pragma unroll
+                for (int r = 0; r < kFaBand; ++r) part[r] = fmaf(qd[u], erk_s[r * DR + d], part[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kFaBand; ++r) {
+            float lo, hi;
+            fa_halves(part[r], lo, hi);
+            rk_s[wave][r][col] = (lo + hi) * qs2;
+            band_s[wave][r][col] = kFaNegBig;
+        }
+    }
+    fa_bf16x8 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = 16 * s + 8 * kh + t;
+            const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];
+            v[t] = d < dk ? x : 0.f;
+        }
+        fa_split8(v, qh[s], ql[s]);
+    }
+
+    // ---- fragment addresses (LDS byte addresses inside image 0; + (tile & 1) IMG; parts, k-steps and row tiles are immediates)
+    const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    unsigned kfa[2][2];   // [key half h2][rows + 4]
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int row = 8 * (g16 >> 1) + q4 + 4 * hi;
+            const int seg = 4 * h2 + 2 * (g16 & 1) + (p4 >> 1);
+            kfa[h2][hi] = lds_k0 + row * 128 + ((seg ^ (2 * ((row >> 1) & 3))) << 4) + (p4 & 1) * 8;
+        }
+    unsigned vfa[2][2][2];   // [key half h2][sp][keys + 8]
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                const int seg = 4 * h2 + 2 * sp + sec;
+                vfa[h2][sp][sec] = lds_v0 + col * 128 + ((seg ^ ((col >> 1) & 7)) << 4) + 8 * kh;
+            }
+
+    struct KF {
+        fa_s16x4 hl, hh, ll, lh;   // hi part: rows d .. d + 3 | d + 4 .. d + 7; lo part
+    };
+    struct VF {
+        uint2 h0, h1, l0, l1;      // hi part: keys .. + 3 | + 8 .. + 11; lo part
+    };
+    auto read_k = [&](KF& f, auto sc, unsigned alo, unsigned ahi) {
+        constexpr int s = decltype(sc)::value;
+        f.hl = fq_read_tr<s * 2048>(alo);
+        f.hh = fq_read_tr<s * 2048>(ahi);
+        f.ll = fq_read_tr<PART + s * 2048>(alo);
+        f.lh = fq_read_tr<PART + s * 2048>(ahi);
+    };
+    auto read_v = [&](VF& f, auto dtc, unsigned a0, unsigned a1) {
+        constexpr int dt = decltype(dtc)::value;
+        f.h0 = fq_read_b64<dt * 4096>(a0);
+        f.h1 = fq_read_b64<dt * 4096>(a1);
+        f.l0 = fq_read_b64<PART + dt * 4096>(a0);
+        f.l1 = fq_read_b64<PART + dt * 4096>(a1);
+    };
+    auto k_hi = [](const KF& f) {
+        const fa_s16x8 v = {f.hl[0], f.hl[1], f.hl[2], f.hl[3], f.hh[0], f.hh[1], f.hh[2], f.hh[3]};
+        return __builtin_bit_cast(fa_bf16x8, v);
+    };
+    auto k_lo = [](const KF& f) {
+        const fa_s16x8 v = {f.ll[0], f.ll[1], f.ll[2], f.ll[3], f.lh[0], f.lh[1], f.lh[2], f.lh[3]};
+        return __builtin_bit_cast(fa_bf16x8, v);
+    };
+    auto v_hi = [](const VF& f) {
+        const uint4 v = {f.h0.x, f.h0.y, f.h1.x, f.h1.y};
+        return __builtin_bit_cast(fa_bf16x8, v);
+    };
+    auto v_lo = [](const VF& f) {
+        const uint4 v = {f.l0.x, f.l0.y, f.l1.x, f.l1.y};
+        return __builtin_bit_cast(fa_bf16x8, v);
+    };
+    // the reads are asm the compiler does not count: waits are explicit and tied to the registers they release
+    auto wait_k = [](KF& f, auto nc) {
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.hl), "+v"(f.hh), "+v"(f.ll), "+v"(f.lh) : "n"(decltype(nc)::value));
+    };
+    auto wait_v = [](VF& f, auto nc) {
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.h0), "+v"(f.h1), "+v"(f.l0), "+v"(f.l1) : "n"(decltype(nc)::value));
+    };
+
+    f32x16 cacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[dt][r] = 0.f;
+    float m = kFaNegBig, l = 0.f;
+
+    // The barrier in front of step t (t = -1: in front of the loop).  Outstanding DMA groups of this wave, oldest first, when it arrives: the tile
+    // this step needs (K tile (t + 1) / 2 for odd t, V tile t / 2 for even t: requested two barriers ago) and the one requested at the last barrier.
+    auto step_barrier = [&](int t) {
+        const int uy = t < 0 ? 1 : (t & 1 ? (t - 1) / 2 + 1 : t / 2 + 1);   // tile of the younger group (K tile for even t, V tile for odd t)
+        if (t == t_fix && has_tail) {
+            fq_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            fixup_tail();
+            __syncthreads();
+        } else {
+            if (t >= 0 && uy < ntiles) fq_wait_vm<NI>();
+            else fq_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        // requests: odd t (and -1): K tile (t + 3) / 2; even t: V tile t / 2 + 1
+        if (t & 1) {
+            const int u = (t + 3) / 2;
+            if (u < ntiles) dma_k(u);
+        } else {
+            const int u = t / 2 + 1;
+            if (u < ntiles) dma_v(u);
+        }
+    };
+
+    // QK(step): 18 MFMAs into acc with `gap(n)` run behind MFMA n
+    KF kf[3];
+    auto qk = [&](f32x16& acc, int step, auto&& gap) {
+        const unsigned bo = ((step >> 1) & 1) * IMG;
+        const int h2 = step & 1;
+        const unsigned alo = (h2 ? kfa[1][0] : kfa[0][0]) + bo, ahi = (h2 ? kfa[1][1] : kfa[0][1]) + bo;
+        read_k(kf[0], std::integral_constant<int, 0>{}, alo, ahi);
+        if constexpr (KS > 1) read_k(kf[1], std::integral_constant<int, 1>{}, alo, ahi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        fq_static_for<0, 3 * KS>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            constexpr int s = n / 3, term = n % 3;
+            KF& f = kf[s % 3];
+            if constexpr (term == 0) {
+                if constexpr (s + 1 < KS) wait_k(f, std::integral_constant<int, 4>{});
+                else wait_k(f, std::integral_constant<int, 0>{});
+                if constexpr (s + 2 < KS) read_k(kf[(s + 2) % 3], std::integral_constant<int, s + 2>{}, alo, ahi);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_lo(f), qh[s], acc, 0, 0, 0);
+            } else if constexpr (term == 1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), ql[s], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), qh[s], acc, 0, 0, 0);
+            }
+            gap(nc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // One pipelined step: softmax(t) on `cur` (with QK(t + 1) into `nxt` when NEXT), then PV(t).  GEN: the step touches the +-w band or the utterance's end.
+    VF vf[3];   // row tile g % 3 of the 2 DT (key half, row tile) groups of a step
+    auto iter = [&](int t, f32x16& cur, f32x16& nxt, auto genc, auto nextc) {
+        constexpr bool GEN = decltype(genc)::value, NEXT = decltype(nextc)::value;
+        const int j0 = t * 32;
+        float mt = kFaNegBig, mn = 0.f, alpha = 0.f, ps = 0.f;
+        fa_bf16x8 ph[2], pl[2];
+        const unsigned vbo = ((t >> 1) & 1) * IMG;
+        const int vh2 = t & 1;
+        unsigned va[2][2];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) va[sp][sec] = (vh2 ? vfa[1][sp][sec] : vfa[0][sp][sec]) + vbo;
+        if constexpr (GEN) {
+            const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
+            const bool tail = j0 + 32 > T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float sv = cur[r] * qs2;
+                if (diag) {
+                    const int rr = j - i + w;
+                    if (rr >= 0 && rr < nb && j < T) {
+                        sv += rk_s[wave][rr][col];
+                        band_s[wave][rr][col] = sv;
+                    }
+                }
+                if (tail) sv = j < T ? sv : kFaNegBig;
+                cur[r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+        }
+        // the softmax of step t in 18 slices
+        auto slice = [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            if constexpr (n < 4) {
+                if constexpr (!GEN) {
+#pragma unroll
+                    for (int r = 4 * n; r < 4 * n + 4; ++r) {
+                        cur[r] *= qs2;
+                        mt = fmaxf(mt, cur[r]);
+                    }
+                }
+            } else if constexpr (n == 4) {
+                float lo, hi;
+                fa_halves(mt, lo, hi);
+                mt = fmaxf(mt, kh ? lo : hi);
+                mn = fmaxf(m, mt);
+                alpha = __builtin_amdgcn_exp2f(m - mn);
+            } else if constexpr (n < 9) {
+#pragma unroll
+                for (int r = 4 * (n - 5); r < 4 * (n - 5) + 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(cur[r] - mn);
+                    cur[r] = e;
+                    ps += e;
+                }
+            } else if constexpr (n == 9) {
+                float lo, hi;
+                fa_halves(ps, lo, hi);
+                l = fmaf(l, alpha, lo + hi);
+                m = mn;
+            } else if constexpr (n < 14) {
+                constexpr int q = n - 10, sp = q >> 1, h = q & 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = cur[4 * q + e];
+                    const __bf16 hh = (__bf16)x;
+                    ph[sp][4 * h + e] = hh;
+                    pl[sp][4 * h + e] = (__bf16)(x - (float)hh);
+                }
+            } else if constexpr (n >= 16) {
+                // the V fragments of PV(t)'s first two groups (key half 0, row tiles 0 and 1)
+                if constexpr (n - 16 < DT) read_v(vf[n - 16], std::integral_constant<int, n - 16>{}, va[0][0], va[0][1]);
+            }
+        };
+        if constexpr (NEXT) {
+            qk(nxt, t + 1, slice);
+            if constexpr (3 * KS < 18) fq_static_for<3 * KS, 18>([&](auto nc) { slice(nc); });
+        } else {
+            fq_static_for<0, 18>([&](auto nc) { slice(nc); });
+        }
+        stamp();
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
+        }
+        stamp();
+        // PV(t): groups g = (key half sp, row tile dt) = 0 .. 2 DT - 1, three MFMAs each (lo * hi, hi * lo, hi * hi on accumulator dt), in PAIRS with their
+        // MFMAs interleaved (two independent accumulators back to back); three fragment sets: group g0 + 2 is requested at the pair's start (the set group
+        // g0 - 1 released), group g0 + 3 behind g0's last MFMA
+        constexpr int NG = 2 * DT;
+        auto pv_mfma = [&](auto gc, auto termc) {
+            constexpr int gq = decltype(gc)::value, term = decltype(termc)::value;
+            constexpr int sp = gq / DT, dt = gq % DT;
+            const VF& f = vf[gq % 3];
+            if constexpr (term == 0) cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_lo(f), ph[sp], cacc[dt], 0, 0, 0);
+            else if constexpr (term == 1) cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_hi(f), pl[sp], cacc[dt], 0, 0, 0);
+            else cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_hi(f), ph[sp], cacc[dt], 0, 0, 0);
+        };
+        auto pv_read = [&](auto gc) {
+            constexpr int gq = decltype(gc)::value;
+            if constexpr (gq < NG) {
+                constexpr int sp = gq / DT, dt = gq % DT;
+                read_v(vf[gq % 3], std::integral_constant<int, dt>{}, va[sp][0], va[sp][1]);
+            }
+        };
+        if constexpr (DT == 1) pv_read(std::integral_constant<int, 1>{});   // (DT = 1: the pre-requested groups are 0 only)
+        fq_static_for<0, (NG + 1) / 2>([&](auto pc) {
+            constexpr int g0 = 2 * decltype(pc)::value, g1 = g0 + 1;
+            constexpr bool two = g1 < NG;
+            // outstanding when this pair starts: its own sets (+ nothing younger)
+            wait_v(vf[g0 % 3], std::integral_constant<int, two ? 4 : 0>{});
+            pv_read(std::integral_constant<int, g0 + 2>{});      // into the set group g0 - 1 released
+            pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (two) {
+                wait_v(vf[g1 % 3], std::integral_constant<int, g0 + 2 < NG ? 4 : 0>{});
+                pv_mfma(std::integral_constant<int, g1>{}, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (two) {
+                pv_mfma(std::integral_constant<int, g1>{}, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 2>{});
+            pv_read(std::integral_constant<int, g0 + 3>{});      // into group g0's own set
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (two) {
+                pv_mfma(std::integral_constant<int, g1>{}, std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    // a step is general when it touches the band of this wave's queries or the utterance's end
+    auto general = [&](int t) { return (t * 32 <= i0 + 31 + w && t * 32 + 31 >= i0 - w) || t * 32 + 32 > T; };
+    auto run = [&](int t, f32x16& cur, f32x16& nxt) {
+        if (t + 1 < nsteps) {
+            if (general(t)) iter(t, cur, nxt, std::true_type{}, std::true_type{});
+            else iter(t, cur, nxt, std::false_type{}, std::true_type{});
+        } else {
+            iter(t, cur, nxt, std::true_type{}, std::false_type{});   // the last step always touches the utterance's end or is cheap to treat so
+        }
+    };
+
+    f32x16 sa, sb;
+    stamp();
+    step_barrier(-1);
+    stamp();
+    if (active) qk(sa, 0, [](auto) {});
+    for (int t = 0; t < nsteps; t += 2) {
+        stamp();
+        step_barrier(t);
+        stamp();
+        if (active) run(t, sa, sb);
+        if (t + 1 < nsteps) {
+            stamp();
+            step_barrier(t + 1);
+            stamp();
+            if (active) run(t + 1, sb, sa);
+        }
+    }
+    stamp();
+    if constexpr (DG) {
+        __syncthreads();
+        if (blockIdx.x == 0 && blockIdx.y == 0 && stamps)
+            for (int q = threadIdx.x; q < NW * kStampMax; q += NTH) stamps[q] = q % kStampMax < nst ? reinterpret_cast<unsigned long long*>(fq_smem + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32))[q] : 0ull;
+    }
+    if (!active) return;
+
+    const float inv = 1.0f / l;
+    float pb[kFaBand];
+#pragma unroll
+    for (int r = 0; r < kFaBand; ++r) pb[r] = __builtin_amdgcn_exp2f(band_s[wave][r][col] - m) * inv;
+    float* Cg = ctx + (int64_t)g.head * dk * ldc + g.col0;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = cacc[dt][r] * inv;
+#pragma unroll
+            for (int b = 0; b < kFaBand; ++b) v = fmaf(pb[b], erv_s[b * DR + d], v);
+            if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
+        }
+}
+
+template <int DT, int NW>
+void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0, int v_row0, float* ctx,
+                      int ldc, int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
+    constexpr int DR = DT * 32;
+    constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32);
+    const __bf16* base = static_cast<const __bf16*>(kv.p);
+    const dim3 grid((maxT + 32 * NW - 1) / (32 * NW), ngroups);
+    static const char* stamp_file = getenv("SBV2_FLASH_Q_STAMPS");
+    if (stamp_file && DT == 3) {   // builder's timeline run: every launch appends the stamps of workgroup (0, 0)
+        auto kern = k_vits_flash_x3q<DT, NW, true>;
+        static std::atomic<uint64_t> lds_allowed_dg{0};
+        allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed_dg);
+        constexpr int n = NW * 160;
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) HIP_CHECK(hipMalloc(&dbuf, n * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds + n * 8, s, groups, Q, ld, base + (int64_t)k_row0 * kv.ld, base + (int64_t)v_row0 * kv.ld, kv.pstride,
+                           kv.ld, ctx, ldc, dk, erk, erv, window, qscale, dbuf);
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(n);
+        HIP_CHECK(hipMemcpy(h.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(stamp_file, "a")) {
+            for (int wv = 0; wv < NW; ++wv) {
+                fprintf(f, "T %d wave %d:", maxT, wv);
+                for (int q = 0; q < 160 && h[wv * 160 + q]; ++q) fprintf(f, " %llu", h[wv * 160 + q] - h[0]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        return;
+    }
+    auto kern = k_vits_flash_x3q<DT, NW>;
+    static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
+    allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, groups, Q, ld, base + (int64_t)k_row0 * kv.ld, base + (int64_t)v_row0 * kv.ld, kv.pstride, kv.ld,
+                       ctx, ldc, dk, erk, erv, window, qscale, (unsigned long long*)nullptr);
 }
 
 template <int DT>
@@ -848,6 +1396,15 @@ void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, 
     SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
     SBV2_REQUIRE(kv.parts == 2 && !kv.f16 && (kv.ld & 3) == 0, "flash attention: keys / values must be two bf16 parts");
     if (ngroups <= 0 || maxT <= 0) return;
+    // the software-pipelined kernel (k_vits_flash_x3q) wherever its DMA blocks fit (head dimensions that are multiples of 8); SBV2_FLASH_Q=0: k_vits_flash_x3p
+    static const int use_q = getenv("SBV2_FLASH_Q") ? atoi(getenv("SBV2_FLASH_Q")) : 1;
+    if (use_q && (dk & 7) == 0) {
+        if (dk <= 32) launch_flash_x3q<1, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        else if (dk <= 64) launch_flash_x3q<2, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        else launch_flash_x3q<3, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const dim3 grid((maxT + 127) / 128, ngroups);
     if (dk <= 32) launch_flash_x3p<1>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
     else if (dk <= 64) launch_flash_x3p<2>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
