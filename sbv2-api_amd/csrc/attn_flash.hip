@@ -897,8 +897,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float (*band_s)[kFaBand][32] = rk_s + NW;
     const unsigned lds_k0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)fq_smem);
     const unsigned lds_v0 = lds_k0 + 2 * IMG;
+    const unsigned lds_dummy = lds_k0 + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32);   // NW x 64 floats
+    const unsigned lds_ql = lds_dummy + NW * 64 * 4;   // the lo parts of q as B fragments: [NW][KS][64 lanes][16 bytes]
     constexpr int kStampMax = 160;   // per wave
-    const unsigned lds_st = lds_k0 + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32);
+    const unsigned lds_st = lds_ql + NW * KS * 1024;
     int nst = 0;
     auto stamp = [&]() {
         if constexpr (DG) {
@@ -932,21 +934,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int drow = lane >> 3, dseg = lane & 7;
     const int kgseg = dseg ^ (2 * ((drow >> 1) & 3)), vgseg = dseg ^ ((drow >> 1) & 3);   // the GLOBAL segment this lane's LDS segment holds (V: even blocks)
     const int nblk = dk >> 3;              // blocks that exist (dk is a multiple of 8); blocks beyond repeat the last one (their q / outputs are unused)
-    // (V's swizzle takes bit 3 of the row as well: odd 8-row blocks hold global segment ^ 4)
-    auto dma_tile = [&](const __bf16* base, int gseg, int odd_xor, int u, unsigned img) {
-        const __bf16* lrow = base + poff + (int64_t)drow * ldp;
+    // (V's swizzle takes bit 3 of the row as well: odd 8-row blocks hold global segment ^ 4.)  A DMA's address = a wave-uniform base (matrix, part,
+    // block, tile: scalar registers, recomputed per request) + a 32-bit per-lane byte offset (row in the block, segment): no per-request 64-bit lane pointers
+    // (hoisted out of the loop they were spilled, and every reload waited vmcnt(0): for the DMAs just issued, 2 400 cycles per K request)
+    const unsigned k_loff = ((unsigned)drow * (unsigned)ldp + 8u * kgseg) * 2u;
+    const unsigned v_loff0 = ((unsigned)drow * (unsigned)ldp + 8u * vgseg) * 2u, v_loff1 = ((unsigned)drow * (unsigned)ldp + 8u * (vgseg ^ 4)) * 2u;
+    auto dma_tile = [&](const __bf16* base, unsigned loff_even, unsigned loff_odd, int gseg, int odd_xor, int u, unsigned img) {
+        const bool whole = u * 64 + 64 <= T;   // (uniform) every segment of the tile lies inside the utterance
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int e = wave + NW * q;
             const int part = e / NB8, blk = e - part * NB8;
-            const int jq = u * 64 + 8 * (gseg ^ ((blk & 1) ? odd_xor : 0));
-            const int colq = jq + 8 <= T ? jq : max(min(jq, T - 8), 0);   // a segment that is not whole inside the utterance: a clamped in-row address (fix-up)
-            const int64_t uo = (int64_t)part * pstride + (int64_t)min(blk, nblk - 1) * 8 * ldp;   // wave-uniform
-            __builtin_amdgcn_global_load_lds((fq_gbl_t*)(lrow + uo + colq), (fq_lds_t*)(uintptr_t)(img + part * PART + blk * 1024), 16, 0, 0);
+            const char* ub = reinterpret_cast<const char*>(base + poff + (int64_t)part * pstride + (int64_t)min(blk, nblk - 1) * 8 * ldp + u * 64);   // wave-uniform
+            const unsigned dst = img + part * PART + blk * 1024;
+            if (whole) {
+                __builtin_amdgcn_global_load_lds((fq_gbl_t*)(ub + ((blk & 1) ? loff_odd : loff_even)), (fq_lds_t*)(uintptr_t)dst, 16, 0, 0);
+            } else {
+                // a segment that is not whole inside the utterance reads a clamped in-row address instead (the fix-up pass rewrites it)
+                const int js = 8 * (gseg ^ ((blk & 1) ? odd_xor : 0));
+                const int jq = u * 64 + js;
+                const int colq = jq + 8 <= T ? jq : max(min(jq, T - 8), 0);
+                __builtin_amdgcn_global_load_lds((fq_gbl_t*)(ub + ((int64_t)drow * ldp + (colq - u * 64)) * 2), (fq_lds_t*)(uintptr_t)dst, 16, 0, 0);
+            }
         }
     };
-    auto dma_k = [&](int u) { dma_tile(Kp, kgseg, 0, u, lds_k0 + (u & 1) * IMG); };
-    auto dma_v = [&](int u) { dma_tile(Vp, vgseg, 4, u, lds_v0 + (u & 1) * IMG); };
+    auto dma_k = [&](int u) { dma_tile(Kp, k_loff, k_loff, kgseg, 0, u, lds_k0 + (u & 1) * IMG); };
+    auto dma_v = [&](int u) { dma_tile(Vp, v_loff0, v_loff1, vgseg, 4, u, lds_v0 + (u & 1) * IMG); };
     // the utterance's last tile, T % 64 != 0: segments k0 / 8 .. 7 of every row rewritten (valid keys copied, the rest zero)
     auto fixup_tail = [&]() {
         const int u = ntiles - 1, tl = T - u * 64, k0 = tl & ~7, nseg = 8 - (k0 >> 3);
@@ -1007,7 +1020,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             band_s[wave][r][col] = kFaNegBig;
         }
     }
-    fa_bf16x8 qh[KS], ql[KS];
+    // q: the hi parts stay in registers; the lo parts live in LDS (24 registers the pipelined loop needs), read with the K fragments of their k-step
+    fa_bf16x8 qh[KS];
+    const unsigned ql_a = lds_ql + (wave * KS * 64 + lane) * 16;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         float v[8];
@@ -1017,33 +1032,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const float x = Qg[(int64_t)min(d, dk - 1) * ld + ic];
             v[t] = d < dk ? x : 0.f;
         }
-        fa_split8(v, qh[s], ql[s]);
+        fa_bf16x8 qlo;
+        fa_split8(v, qh[s], qlo);
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ql_a), "v"(qlo), "n"(s * 1024) : "memory");
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    // ---- fragment addresses (LDS byte addresses inside image 0; + (tile & 1) IMG; parts, k-steps and row tiles are immediates)
+    // ---- fragment addresses.  A byte offset inside a tile image = row * 128 + (segment << 4) + sub; the swizzles are XORs on the segment bits, so
+    // the address of (key half h2, sp, keys + 8) is ONE per-lane base XOR a constant: no per-(h2, sp) address registers
     const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-    unsigned kfa[2][2];   // [key half h2][rows + 4]
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int hi = 0; hi < 2; ++hi) {
-            const int row = 8 * (g16 >> 1) + q4 + 4 * hi;
-            const int seg = 4 * h2 + 2 * (g16 & 1) + (p4 >> 1);
-            kfa[h2][hi] = lds_k0 + row * 128 + ((seg ^ (2 * ((row >> 1) & 3))) << 4) + (p4 & 1) * 8;
-        }
-    unsigned vfa[2][2][2];   // [key half h2][sp][keys + 8]
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int sec = 0; sec < 2; ++sec) {
-                const int seg = 4 * h2 + 2 * sp + sec;
-                vfa[h2][sp][sec] = lds_v0 + col * 128 + ((seg ^ ((col >> 1) & 7)) << 4) + 8 * kh;
-            }
+    const int krow = 8 * (g16 >> 1) + q4, ksegl = 2 * (g16 & 1) + (p4 >> 1);
+    const unsigned kb_lo = krow * 128 + ((ksegl ^ (2 * ((krow >> 1) & 3))) << 4) + (p4 & 1) * 8;                  // rows d .. d + 3 (h2 = 0; h2 = 1: ^ 64)
+    const unsigned kb_hi = (krow + 4) * 128 + ((ksegl ^ (2 * (((krow + 4) >> 1) & 3))) << 4) + (p4 & 1) * 8;      // rows d + 4 .. d + 7
+    const unsigned vb = col * 128 + (((col >> 1) & 7) << 4) + 8 * kh;                                            // segment 0 (segment g: ^ (g << 4))
+    // the wave's row of rk_s / band_s (+ rr * 128), and a dummy slot the band stores of elements outside the band go to
+    const unsigned rk_a = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)&rk_s[wave][0][col]);
+    constexpr unsigned band_off = NW * kFaBand * 32 * 4;   // band_s[wave][rr][col] = rk_s[wave][rr][col] + band_off
 
     struct KF {
         fa_s16x4 hl, hh, ll, lh;   // hi part: rows d .. d + 3 | d + 4 .. d + 7; lo part
+        fa_bf16x8 ql;              // the lo part of q of the same k-step
     };
     struct VF {
         uint2 h0, h1, l0, l1;      // hi part: keys .. + 3 | + 8 .. + 11; lo part
@@ -1054,6 +1062,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         f.hh = fq_read_tr<s * 2048>(ahi);
         f.ll = fq_read_tr<PART + s * 2048>(alo);
         f.lh = fq_read_tr<PART + s * 2048>(ahi);
+        const unsigned qa = ql_a;   // (a local: an asm operand cannot name a captured variable)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ql) : "v"(qa), "n"(s * 1024));
     };
     auto read_v = [&](VF& f, auto dtc, unsigned a0, unsigned a1) {
         constexpr int dt = decltype(dtc)::value;
@@ -1080,7 +1090,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     // the reads are asm the compiler does not count: waits are explicit and tied to the registers they release
     auto wait_k = [](KF& f, auto nc) {
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.hl), "+v"(f.hh), "+v"(f.ll), "+v"(f.lh) : "n"(decltype(nc)::value));
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f.hl), "+v"(f.hh), "+v"(f.ll), "+v"(f.lh), "+v"(f.ql) : "n"(decltype(nc)::value));
     };
     auto wait_v = [](VF& f, auto nc) {
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.h0), "+v"(f.h1), "+v"(f.l0), "+v"(f.l1) : "n"(decltype(nc)::value));
@@ -1118,26 +1128,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
 
     // QK(step): 18 MFMAs into acc with `gap(n)` run behind MFMA n
-    KF kf[3];
+    KF kf[2];   // (two sets: the reads of k-step s + 1 are issued behind the wait for s; three MFMA gaps full of VALU work cover their latency)
     auto qk = [&](f32x16& acc, int step, auto&& gap) {
-        const unsigned bo = ((step >> 1) & 1) * IMG;
-        const int h2 = step & 1;
-        const unsigned alo = (h2 ? kfa[1][0] : kfa[0][0]) + bo, ahi = (h2 ? kfa[1][1] : kfa[0][1]) + bo;
+        const unsigned kbase = lds_k0 + ((step >> 1) & 1) * IMG, hx = (step & 1) << 6;
+        const unsigned alo = kbase + (kb_lo ^ hx), ahi = kbase + (kb_hi ^ hx);
         read_k(kf[0], std::integral_constant<int, 0>{}, alo, ahi);
-        if constexpr (KS > 1) read_k(kf[1], std::integral_constant<int, 1>{}, alo, ahi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         fq_static_for<0, 3 * KS>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             constexpr int s = n / 3, term = n % 3;
-            KF& f = kf[s % 3];
+            KF& f = kf[s % 2];
             if constexpr (term == 0) {
-                if constexpr (s + 1 < KS) wait_k(f, std::integral_constant<int, 4>{});
-                else wait_k(f, std::integral_constant<int, 0>{});
-                if constexpr (s + 2 < KS) read_k(kf[(s + 2) % 3], std::integral_constant<int, s + 2>{}, alo, ahi);
+                wait_k(f, std::integral_constant<int, 0>{});
+                if constexpr (s + 1 < KS) read_k(kf[(s + 1) % 2], std::integral_constant<int, s + 1>{}, alo, ahi);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_lo(f), qh[s], acc, 0, 0, 0);
             } else if constexpr (term == 1) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), ql[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), f.ql, acc, 0, 0, 0);
             } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), qh[s], acc, 0, 0, 0);
             }
@@ -1146,51 +1153,67 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         });
     };
 
-    // One pipelined step: softmax(t) on `cur` (with QK(t + 1) into `nxt` when NEXT), then PV(t).  GEN: the step touches the +-w band or the utterance's end.
+    // One pipelined step: the softmax of step t on `cur` (dealt into the gaps of QK(t + 1) -> `nxt` when NEXT), then PV(t).
     VF vf[3];   // row tile g % 3 of the 2 DT (key half, row tile) groups of a step
-    auto iter = [&](int t, f32x16& cur, f32x16& nxt, auto genc, auto nextc) {
-        constexpr bool GEN = decltype(genc)::value, NEXT = decltype(nextc)::value;
+    auto iter = [&](int t, f32x16& cur, f32x16& nxt, auto nextc) {
+        constexpr bool NEXT = decltype(nextc)::value;
         const int j0 = t * 32;
         float mt = kFaNegBig, mn = 0.f, alpha = 0.f, ps = 0.f;
         fa_bf16x8 ph[2], pl[2];
-        const unsigned vbo = ((t >> 1) & 1) * IMG;
-        const int vh2 = t & 1;
-        unsigned va[2][2];
+        const unsigned va0 = lds_v0 + ((t >> 1) & 1) * IMG + (vb ^ ((t & 1) << 6));   // (sp = 0, keys + 0); sp: ^ 32; keys + 8: ^ 16
+        const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w, tail = j0 + 32 > T;   // (wave-uniform)
+        if (diag) {
+            // the step touches the +-w band of this wave's queries: relative-key logits added, band scores kept for the relative-value term.  Branch
+            // free (elements outside the band add nothing and store to a dummy slot), LDS through asm (a compiler-visible LDS access waits for every
+            // pending LDS-DMA): 4 000-6 000 cycles per such step as compiled from the plain loop, against ~1 250 for an interior step
+            const int rr0 = j0 - i + w + 4 * kh;
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
+            for (int hf = 0; hf < 2; ++hf) {   // (two halves: eight values in flight)
+                float rk[8];
 #pragma unroll
-            for (int sec = 0; sec < 2; ++sec) va[sp][sec] = (vh2 ? vfa[1][sp][sec] : vfa[0][sp][sec]) + vbo;
-        if constexpr (GEN) {
-            const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w;
-            const bool tail = j0 + 32 > T;
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 8 * hf + q, ro = (r & 3) + 8 * (r >> 2);
+                    const int rr = rr0 + ro;
+                    const bool in = (unsigned)rr < (unsigned)nb && j0 + 4 * kh + ro < T;
+                    const unsigned a = rk_a + (in ? rr : 0) * 128;
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(rk[q]) : "v"(a));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rk[0]), "+v"(rk[1]), "+v"(rk[2]), "+v"(rk[3]), "+v"(rk[4]), "+v"(rk[5]), "+v"(rk[6]), "+v"(rk[7]));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 8 * hf + q, ro = (r & 3) + 8 * (r >> 2);
+                    const int rr = rr0 + ro;
+                    const bool jin = j0 + 4 * kh + ro < T;
+                    const bool in = (unsigned)rr < (unsigned)nb && jin;
+                    float sv = cur[r] * qs2;
+                    const float sb = sv + rk[q];
+                    sv = in ? sb : sv;
+                    const unsigned a = in ? rk_a + band_off + rr * 128 : lds_dummy + (wave * 64 + lane) * 4;
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(sv) : "memory");
+                    if (tail) sv = jin ? sv : kFaNegBig;
+                    cur[r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+            }
+        } else if (tail) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float sv = cur[r] * qs2;
-                if (diag) {
-                    const int rr = j - i + w;
-                    if (rr >= 0 && rr < nb && j < T) {
-                        sv += rk_s[wave][rr][col];
-                        band_s[wave][rr][col] = sv;
-                    }
-                }
-                if (tail) sv = j < T ? sv : kFaNegBig;
+                const float sv = j < T ? cur[r] * qs2 : kFaNegBig;
                 cur[r] = sv;
                 mt = fmaxf(mt, sv);
             }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                cur[r] *= qs2;
+                mt = fmaxf(mt, cur[r]);
+            }
         }
-        // the softmax of step t in 18 slices
+        // the rest of the softmax of step t in 18 slices
         auto slice = [&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            if constexpr (n < 4) {
-                if constexpr (!GEN) {
-#pragma unroll
-                    for (int r = 4 * n; r < 4 * n + 4; ++r) {
-                        cur[r] *= qs2;
-                        mt = fmaxf(mt, cur[r]);
-                    }
-                }
-            } else if constexpr (n == 4) {
+            if constexpr (n == 0) {
                 float lo, hi;
                 fa_halves(mt, lo, hi);
                 mt = fmaxf(mt, kh ? lo : hi);
@@ -1198,7 +1221,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 alpha = __builtin_amdgcn_exp2f(m - mn);
             } else if constexpr (n < 9) {
 #pragma unroll
-                for (int r = 4 * (n - 5); r < 4 * (n - 5) + 4; ++r) {
+                for (int r = 2 * (n - 1); r < 2 * (n - 1) + 2; ++r) {
                     const float e = __builtin_amdgcn_exp2f(cur[r] - mn);
                     cur[r] = e;
                     ps += e;
@@ -1208,18 +1231,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 fa_halves(ps, lo, hi);
                 l = fmaf(l, alpha, lo + hi);
                 m = mn;
-            } else if constexpr (n < 14) {
-                constexpr int q = n - 10, sp = q >> 1, h = q & 1;
+            } else {
+                // n = 10 .. 17: the split of P, two elements per slice (pinned here: sunk to its use it would run un-overlapped in front of PV)
+                constexpr int q = n - 10, sp = q >> 2, e0 = 2 * (q & 3);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = cur[4 * q + e];
+                for (int e = e0; e < e0 + 2; ++e) {
+                    const float x = cur[8 * sp + e];
                     const __bf16 hh = (__bf16)x;
-                    ph[sp][4 * h + e] = hh;
-                    pl[sp][4 * h + e] = (__bf16)(x - (float)hh);
+                    ph[sp][e] = hh;
+                    pl[sp][e] = (__bf16)(x - (float)hh);
                 }
-            } else if constexpr (n >= 16) {
+                if constexpr ((q & 3) == 3) asm volatile("" : "+v"(ph[sp]), "+v"(pl[sp]));
                 // the V fragments of PV(t)'s first two groups (key half 0, row tiles 0 and 1)
-                if constexpr (n - 16 < DT) read_v(vf[n - 16], std::integral_constant<int, n - 16>{}, va[0][0], va[0][1]);
+                if constexpr (n >= 16 && n - 16 < DT) read_v(vf[n - 16], std::integral_constant<int, n - 16>{}, va0, va0 ^ 16);
             }
         };
         if constexpr (NEXT) {
@@ -1252,14 +1276,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             constexpr int gq = decltype(gc)::value;
             if constexpr (gq < NG) {
                 constexpr int sp = gq / DT, dt = gq % DT;
-                read_v(vf[gq % 3], std::integral_constant<int, dt>{}, va[sp][0], va[sp][1]);
+                read_v(vf[gq % 3], std::integral_constant<int, dt>{}, va0 ^ (32 * sp), va0 ^ (32 * sp + 16));
             }
         };
         if constexpr (DT == 1) pv_read(std::integral_constant<int, 1>{});   // (DT = 1: the pre-requested groups are 0 only)
+        if constexpr (DT == 1) {   // one accumulator: its two groups in order
+            wait_v(vf[0], std::integral_constant<int, 4>{});
+            fq_static_for<0, 3>([&](auto tc) { pv_mfma(std::integral_constant<int, 0>{}, tc); });
+            wait_v(vf[1], std::integral_constant<int, 0>{});
+            fq_static_for<0, 3>([&](auto tc) { pv_mfma(std::integral_constant<int, 1>{}, tc); });
+        } else
         fq_static_for<0, (NG + 1) / 2>([&](auto pc) {
             constexpr int g0 = 2 * decltype(pc)::value, g1 = g0 + 1;
             constexpr bool two = g1 < NG;
-            // outstanding when this pair starts: its own sets (+ nothing younger)
             wait_v(vf[g0 % 3], std::integral_constant<int, two ? 4 : 0>{});
             pv_read(std::integral_constant<int, g0 + 2>{});      // into the set group g0 - 1 released
             pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 0>{});
@@ -1284,15 +1313,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         });
     };
-    // a step is general when it touches the band of this wave's queries or the utterance's end
-    auto general = [&](int t) { return (t * 32 <= i0 + 31 + w && t * 32 + 31 >= i0 - w) || t * 32 + 32 > T; };
     auto run = [&](int t, f32x16& cur, f32x16& nxt) {
-        if (t + 1 < nsteps) {
-            if (general(t)) iter(t, cur, nxt, std::true_type{}, std::true_type{});
-            else iter(t, cur, nxt, std::false_type{}, std::true_type{});
-        } else {
-            iter(t, cur, nxt, std::true_type{}, std::false_type{});   // the last step always touches the utterance's end or is cheap to treat so
-        }
+        if (t + 1 < nsteps) iter(t, cur, nxt, std::true_type{});
+        else iter(t, cur, nxt, std::false_type{});
     };
 
     f32x16 sa, sb;
@@ -1316,7 +1339,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if constexpr (DG) {
         __syncthreads();
         if (blockIdx.x == 0 && blockIdx.y == 0 && stamps)
-            for (int q = threadIdx.x; q < NW * kStampMax; q += NTH) stamps[q] = q % kStampMax < nst ? reinterpret_cast<unsigned long long*>(fq_smem + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32))[q] : 0ull;
+            for (int q = threadIdx.x; q < NW * kStampMax; q += NTH) stamps[q] = q % kStampMax < nst ? reinterpret_cast<unsigned long long*>(fq_smem + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + NW * KS * 1024)[q] : 0ull;
     }
     if (!active) return;
 
@@ -1341,7 +1364,7 @@ template <int DT, int NW>
 void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0, int v_row0, float* ctx,
                       int ldc, int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
     constexpr int DR = DT * 32;
-    constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32);
+    constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + NW * (DR / 16) * 1024;
     const __bf16* base = static_cast<const __bf16*>(kv.p);
     const dim3 grid((maxT + 32 * NW - 1) / (32 * NW), ngroups);
     static const char* stamp_file = getenv("SBV2_FLASH_Q_STAMPS");
