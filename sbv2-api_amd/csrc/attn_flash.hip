@@ -960,24 +960,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     auto dma_k = [&](int u) { dma_tile(Kp, k_loff, k_loff, kgseg, 0, u, lds_k0 + (u & 1) * IMG); };
     auto dma_v = [&](int u) { dma_tile(Vp, v_loff0, v_loff1, vgseg, 4, u, lds_v0 + (u & 1) * IMG); };
-    // the utterance's last tile, T % 64 != 0: segments k0 / 8 .. 7 of every row rewritten (valid keys copied, the rest zero)
+    // the utterance's last tile, T % 64 != 0: segments k0 / 8 .. 7 of every row rewritten (valid keys copied, the rest zero).  One (matrix, part, row) per
+    // thread and pass: the <= 7 element loads of the segment that straddles T are in flight together, then 16-byte stores
     auto fixup_tail = [&]() {
-        const int u = ntiles - 1, tl = T - u * 64, k0 = tl & ~7, nseg = 8 - (k0 >> 3);
-        const int items = 4 * DR * nseg;
-        for (int it = tid; it < items; it += NTH) {
-            const int seg = (k0 >> 3) + it % nseg, r = it / nseg;
-            const int d = r % DR, mp = r / DR, part = mp & 1, mat = mp >> 1;
-            const unsigned short* src = reinterpret_cast<const unsigned short*>(mat ? Vp : Kp) + (int64_t)part * pstride + poff + (int64_t)min(d, dk - 1) * ldp + u * 64;
+        const int u = ntiles - 1, tl = T - u * 64, sg = tl >> 3, nv = tl & 7;
+        for (int it = tid; it < 4 * DR; it += NTH) {
+            const int d = it % DR, mp = it / DR, part = mp & 1, mat = mp >> 1;
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(mat ? Vp : Kp) + (int64_t)part * pstride + poff + (int64_t)min(d, dk - 1) * ldp + u * 64 + 8 * sg;
             unsigned short v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 8 * seg + e;
-                v[e] = (k < tl && d < dk) ? src[k] : (unsigned short)0;
-            }
+            for (int e = 0; e < 8; ++e) v[e] = (e < nv && d < dk) ? src[e] : (unsigned short)0;
             const int swz = mat ? ((d >> 1) & 7) : 2 * ((d >> 1) & 3);
-            uint4 o = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
-                       (unsigned)v[6] | ((unsigned)v[7] << 16)};
-            *reinterpret_cast<uint4*>(fq_smem + (mat ? 2 * IMG : 0) + (u & 1) * IMG + part * PART + d * 128 + ((seg ^ swz) << 4)) = o;
+            char* row = fq_smem + (mat ? 2 * IMG : 0) + (u & 1) * IMG + part * PART + d * 128;
+            const uint4 o = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
+                             (unsigned)v[6] | ((unsigned)v[7] << 16)};
+            *reinterpret_cast<uint4*>(row + ((sg ^ swz) << 4)) = o;
+            for (int seg = sg + 1; seg < 8; ++seg) *reinterpret_cast<uint4*>(row + ((seg ^ swz) << 4)) = uint4{0u, 0u, 0u, 0u};
         }
     };
     const bool has_tail = (T & 63) != 0;
@@ -1153,20 +1151,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         });
     };
 
-    // One pipelined step: the softmax of step t on `cur` (dealt into the gaps of QK(t + 1) -> `nxt` when NEXT), then PV(t).
-    VF vf[3];   // row tile g % 3 of the 2 DT (key half, row tile) groups of a step
-    auto iter = [&](int t, f32x16& cur, f32x16& nxt, auto nextc) {
+    // One pipelined step.  `cur` holds the base-2 logits of step t (already scaled; mt = their maximum over this lane's 16 when the step is interior).
+    // Phase A: QK(t + 1) -> `nxt` (when NEXT) with the softmax of step t and the split of P's first key half in its gaps.  Phase B: PV(t), term-paired,
+    // with the split of P's second key half and the scaling / maximum of `nxt` in its gaps.
+    VF vf[4];   // set g % 4 of the 2 DT (key half, row tile) groups of a step
+    auto iter = [&](int t, f32x16& cur, f32x16& nxt, float& mt, auto nextc) {
         constexpr bool NEXT = decltype(nextc)::value;
         const int j0 = t * 32;
-        float mt = kFaNegBig, mn = 0.f, alpha = 0.f, ps = 0.f;
+        float mn = 0.f, alpha = 0.f, ps = 0.f, mtn = kFaNegBig;
         fa_bf16x8 ph[2], pl[2];
         const unsigned va0 = lds_v0 + ((t >> 1) & 1) * IMG + (vb ^ ((t & 1) << 6));   // (sp = 0, keys + 0); sp: ^ 32; keys + 8: ^ 16
         const bool diag = j0 <= i0 + 31 + w && j0 + 31 >= i0 - w, tail = j0 + 32 > T;   // (wave-uniform)
         if (diag) {
             // the step touches the +-w band of this wave's queries: relative-key logits added, band scores kept for the relative-value term.  Branch
             // free (elements outside the band add nothing and store to a dummy slot), LDS through asm (a compiler-visible LDS access waits for every
-            // pending LDS-DMA): 4 000-6 000 cycles per such step as compiled from the plain loop, against ~1 250 for an interior step
+            // pending LDS-DMA): 4 000-6 000 cycles per such step as compiled from the plain loop
             const int rr0 = j0 - i + w + 4 * kh;
+            mt = kFaNegBig;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {   // (two halves: eight values in flight)
                 float rk[8];
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const int rr = rr0 + ro;
                     const bool jin = j0 + 4 * kh + ro < T;
                     const bool in = (unsigned)rr < (unsigned)nb && jin;
-                    float sv = cur[r] * qs2;
+                    float sv = cur[r];
                     const float sb = sv + rk[q];
                     sv = in ? sb : sv;
                     const unsigned a = in ? rk_a + band_off + rr * 128 : lds_dummy + (wave * 64 + lane) * 4;
@@ -1196,21 +1197,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
             }
         } else if (tail) {
+            mt = kFaNegBig;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float sv = j < T ? cur[r] * qs2 : kFaNegBig;
+                const float sv = j < T ? cur[r] : kFaNegBig;
                 cur[r] = sv;
                 mt = fmaxf(mt, sv);
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                cur[r] *= qs2;
-                mt = fmaxf(mt, cur[r]);
-            }
         }
-        // the rest of the softmax of step t in 18 slices
+        auto read_vg = [&](auto gc) {   // the V fragments of group gc of PV(t)
+            constexpr int gq = decltype(gc)::value;
+            if constexpr (gq < 2 * DT) {
+                constexpr int sp = gq / DT, dt = gq % DT;
+                read_v(vf[gq % 4], std::integral_constant<int, dt>{}, va0 ^ (32 * sp), va0 ^ (32 * sp + 16));
+            }
+        };
+        auto split2 = [&](auto spc, auto ec) {   // elements e, e + 1 of key half sp of P -> bf16 hi / lo
+            constexpr int sp = decltype(spc)::value, e0 = decltype(ec)::value;
+#pragma unroll
+            for (int e = e0; e < e0 + 2; ++e) {
+                const float x = cur[8 * sp + e];
+                const __bf16 hh = (__bf16)x;
+                ph[sp][e] = hh;
+                pl[sp][e] = (__bf16)(x - (float)hh);
+            }
+            if constexpr (e0 == 6) asm volatile("" : "+v"(ph[sp]), "+v"(pl[sp]));   // (pinned here: sunk to its use it would run un-overlapped)
+        };
+        // phase A: the softmax of step t in 18 slices
         auto slice = [&](auto nc) {
             constexpr int n = decltype(nc)::value;
             if constexpr (n == 0) {
@@ -1231,19 +1245,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 fa_halves(ps, lo, hi);
                 l = fmaf(l, alpha, lo + hi);
                 m = mn;
-            } else {
-                // n = 10 .. 17: the split of P, two elements per slice (pinned here: sunk to its use it would run un-overlapped in front of PV)
-                constexpr int q = n - 10, sp = q >> 2, e0 = 2 * (q & 3);
-#pragma unroll
-                for (int e = e0; e < e0 + 2; ++e) {
-                    const float x = cur[8 * sp + e];
-                    const __bf16 hh = (__bf16)x;
-                    ph[sp][e] = hh;
-                    pl[sp][e] = (__bf16)(x - (float)hh);
-                }
-                if constexpr ((q & 3) == 3) asm volatile("" : "+v"(ph[sp]), "+v"(pl[sp]));
-                // the V fragments of PV(t)'s first two groups (key half 0, row tiles 0 and 1)
-                if constexpr (n >= 16 && n - 16 < DT) read_v(vf[n - 16], std::integral_constant<int, n - 16>{}, va0, va0 ^ 16);
+            } else if constexpr (n < 14) {
+                split2(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (n - 10)>{});
+            } else if constexpr (n >= 15) {
+                read_vg(std::integral_constant<int, n - 15>{});   // groups 0 .. 2 (behind QK's last fragment wait)
             }
         };
         if constexpr (NEXT) {
@@ -1252,6 +1257,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         } else {
             fq_static_for<0, 18>([&](auto nc) { slice(nc); });
         }
+        read_vg(std::integral_constant<int, 3>{});
         stamp();
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
@@ -1260,80 +1266,109 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int r = 0; r < 16; ++r) cacc[dt][r] *= alpha;
         }
         stamp();
-        // PV(t): groups g = (key half sp, row tile dt) = 0 .. 2 DT - 1, three MFMAs each (lo * hi, hi * lo, hi * hi on accumulator dt), in PAIRS with their
-        // MFMAs interleaved (two independent accumulators back to back); three fragment sets: group g0 + 2 is requested at the pair's start (the set group
-        // g0 - 1 released), group g0 + 3 behind g0's last MFMA
+        // phase B: PV(t).  Groups g = (key half sp, row tile dt) = 0 .. 2 DT - 1, three MFMAs each (lo * hi, hi * lo, hi * hi on accumulator dt), in PAIRS with
+        // their MFMAs interleaved (two independent accumulators back to back).  Four fragment sets: groups 0 .. 3 are on their way when the phase starts,
+        // groups 4 and 5 are requested behind the last MFMA of groups 0 and 1.
         constexpr int NG = 2 * DT;
         auto pv_mfma = [&](auto gc, auto termc) {
             constexpr int gq = decltype(gc)::value, term = decltype(termc)::value;
             constexpr int sp = gq / DT, dt = gq % DT;
-            const VF& f = vf[gq % 3];
+            const VF& f = vf[gq % 4];
             if constexpr (term == 0) cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_lo(f), ph[sp], cacc[dt], 0, 0, 0);
             else if constexpr (term == 1) cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_hi(f), pl[sp], cacc[dt], 0, 0, 0);
             else cacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_hi(f), ph[sp], cacc[dt], 0, 0, 0);
         };
-        auto pv_read = [&](auto gc) {
+        auto wait_vg = [&](auto gc) {   // groups requested behind group g when its wait is reached: up to group min(NG - 1, g < 2 ? 3 : 5)
             constexpr int gq = decltype(gc)::value;
-            if constexpr (gq < NG) {
-                constexpr int sp = gq / DT, dt = gq % DT;
-                read_v(vf[gq % 3], std::integral_constant<int, dt>{}, va0 ^ (32 * sp), va0 ^ (32 * sp + 16));
-            }
+            constexpr int last = (gq < 2 ? 3 : 5) < NG - 1 ? (gq < 2 ? 3 : 5) : NG - 1;
+            wait_v(vf[gq % 4], std::integral_constant<int, 4 * (last - gq)>{});
         };
-        if constexpr (DT == 1) pv_read(std::integral_constant<int, 1>{});   // (DT = 1: the pre-requested groups are 0 only)
-        if constexpr (DT == 1) {   // one accumulator: its two groups in order
-            wait_v(vf[0], std::integral_constant<int, 4>{});
+        // gap n of phase B (behind its MFMA n): the second key half of P, then the next step's logits scaled and their maximum
+        auto bgap = [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            if constexpr (n < 4) {
+                split2(std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * n>{});
+            } else if constexpr (NEXT && n >= 6 && n < 14) {
+#pragma unroll
+                for (int r = 2 * (n - 6); r < 2 * (n - 6) + 2; ++r) {
+                    nxt[r] *= qs2;
+                    mtn = fmaxf(mtn, nxt[r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (DT == 1) {   // one accumulator: its two groups in order (the second key half of P split in front of them)
+            fq_static_for<0, 4>([&](auto nc) { split2(std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * decltype(nc)::value>{}); });
+            wait_vg(std::integral_constant<int, 0>{});
             fq_static_for<0, 3>([&](auto tc) { pv_mfma(std::integral_constant<int, 0>{}, tc); });
-            wait_v(vf[1], std::integral_constant<int, 0>{});
+            wait_vg(std::integral_constant<int, 1>{});
             fq_static_for<0, 3>([&](auto tc) { pv_mfma(std::integral_constant<int, 1>{}, tc); });
-        } else
-        fq_static_for<0, (NG + 1) / 2>([&](auto pc) {
-            constexpr int g0 = 2 * decltype(pc)::value, g1 = g0 + 1;
-            constexpr bool two = g1 < NG;
-            wait_v(vf[g0 % 3], std::integral_constant<int, two ? 4 : 0>{});
-            pv_read(std::integral_constant<int, g0 + 2>{});      // into the set group g0 - 1 released
-            pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (two) {
-                wait_v(vf[g1 % 3], std::integral_constant<int, g0 + 2 < NG ? 4 : 0>{});
+            fq_static_for<6, 14>([&](auto nc) { bgap(nc); });
+        } else {
+            fq_static_for<0, NG / 2>([&](auto pc) {
+                constexpr int p = decltype(pc)::value, g0 = 2 * p, g1 = g0 + 1;
+                wait_vg(std::integral_constant<int, g0>{});
+                pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 0>{});
+                bgap(std::integral_constant<int, 6 * p>{});
+                wait_vg(std::integral_constant<int, g1>{});
                 pv_mfma(std::integral_constant<int, g1>{}, std::integral_constant<int, 0>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (two) {
+                bgap(std::integral_constant<int, 6 * p + 1>{});
+                pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 1>{});
+                bgap(std::integral_constant<int, 6 * p + 2>{});
                 pv_mfma(std::integral_constant<int, g1>{}, std::integral_constant<int, 1>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 2>{});
-            pv_read(std::integral_constant<int, g0 + 3>{});      // into group g0's own set
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (two) {
+                bgap(std::integral_constant<int, 6 * p + 3>{});
+                pv_mfma(std::integral_constant<int, g0>{}, std::integral_constant<int, 2>{});
+                if constexpr (p == 0) read_vg(std::integral_constant<int, 4>{});      // into group 0's set
+                bgap(std::integral_constant<int, 6 * p + 4>{});
                 pv_mfma(std::integral_constant<int, g1>{}, std::integral_constant<int, 2>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-    };
-    auto run = [&](int t, f32x16& cur, f32x16& nxt) {
-        if (t + 1 < nsteps) iter(t, cur, nxt, std::true_type{});
-        else iter(t, cur, nxt, std::false_type{});
+                if constexpr (p == 0) read_vg(std::integral_constant<int, 5>{});      // into group 1's set
+                bgap(std::integral_constant<int, 6 * p + 5>{});
+            });
+            if constexpr (3 * NG < 14) fq_static_for<3 * NG, 14>([&](auto nc) { bgap(nc); });
+        }
+        mt = mtn;   // (of the next step, when it is interior; a step on the band or at the utterance's end computes its own)
     };
 
+    // steps 0 .. nsteps - 2 with QK of their successor in flight, two per loop iteration (the two accumulators swap roles); the last one on its own
     f32x16 sa, sb;
+    float mt = kFaNegBig;
     stamp();
     step_barrier(-1);
     stamp();
-    if (active) qk(sa, 0, [](auto) {});
-    for (int t = 0; t < nsteps; t += 2) {
+    if (active) {
+        qk(sa, 0, [](auto) {});
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sa[r] *= qs2;
+            mt = fmaxf(mt, sa[r]);
+        }
+    }
+    const int n1 = nsteps - 1;
+    int t = 0;
+    for (; t + 2 <= n1; t += 2) {
         stamp();
         step_barrier(t);
         stamp();
-        if (active) run(t, sa, sb);
-        if (t + 1 < nsteps) {
-            stamp();
-            step_barrier(t + 1);
-            stamp();
-            if (active) run(t + 1, sb, sa);
-        }
+        if (active) iter(t, sa, sb, mt, std::true_type{});
+        stamp();
+        step_barrier(t + 1);
+        stamp();
+        if (active) iter(t + 1, sb, sa, mt, std::true_type{});
+    }
+    if (t < n1) {
+        stamp();
+        step_barrier(t);
+        stamp();
+        if (active) iter(t, sa, sb, mt, std::true_type{});
+        stamp();
+        step_barrier(t + 1);
+        stamp();
+        if (active) iter(t + 1, sb, sa, mt, std::false_type{});
+    } else {
+        stamp();
+        step_barrier(t);
+        stamp();
+        if (active) iter(t, sa, sb, mt, std::false_type{});
     }
     stamp();
     if constexpr (DG) {
