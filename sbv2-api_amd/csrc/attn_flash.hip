@@ -1449,14 +1449,14 @@ void launch_flash_x3p(dim3 grid, const AttnGroup* groups, const float* Q, int ld
 // keys / values from bf16 hi / lo planes (rows k_row0 .. + heads dk and v_row0 .. of kv: two bf16 parts, the columns of Q's plane)
 void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
                                 int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
-                                hipStream_t s) {
+                                hipStream_t s, bool pipelined) {
     SBV2_REQUIRE(window <= kFaMaxWin, "relative attention window larger than the compiled maximum");
     SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
     SBV2_REQUIRE(kv.parts == 2 && !kv.f16 && (kv.ld & 3) == 0, "flash attention: keys / values must be two bf16 parts");
     if (ngroups <= 0 || maxT <= 0) return;
     // the software-pipelined kernel (k_vits_flash_x3q) wherever its DMA blocks fit (head dimensions that are multiples of 8); SBV2_FLASH_Q=0: k_vits_flash_x3p
     static const int use_q = getenv("SBV2_FLASH_Q") ? atoi(getenv("SBV2_FLASH_Q")) : 1;
-    if (use_q && (dk & 7) == 0) {
+    if (use_q && pipelined && (dk & 7) == 0) {
         if (dk <= 32) launch_flash_x3q<1, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
         else if (dk <= 64) launch_flash_x3q<2, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
         else launch_flash_x3q<3, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);

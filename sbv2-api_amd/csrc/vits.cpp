@@ -17,7 +17,8 @@
 namespace sbv2 {
 
 // keys / values of the flow's attention as pre-split bf16 planes for long sequences (SBV2_FLASH_PARTS = 1: from SBV2_FLASH_PARTS_MIN_T frames,
-// 2: at every length, 0: never = converted per key tile inside the attention kernel; bit-identical; sbv2_debug_set_flash_parts for the test)
+// 2: at every length, 3: at every length on the un-pipelined kernel k_vits_flash_x3p, 0: never = converted per key tile inside the attention kernel;
+// bit-identical; sbv2_debug_set_flash_parts for the test)
 static std::atomic<int> g_flash_parts{getenv("SBV2_FLASH_PARTS") ? atoi(getenv("SBV2_FLASH_PARTS")) : 1};
 bool flash_parts_enabled() { return g_flash_parts.load(std::memory_order_relaxed) != 0; }
 static int flash_parts_mode() { return g_flash_parts.load(std::memory_order_relaxed); }
@@ -407,11 +408,12 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     // sequence 78.5 -> 76.9 ms): what it saves, one conversion of every key tile per 128-query workgroup, grows with T / 128.  The bits are the
     // same, so the choice is made by length (SBV2_FLASH_PARTS_MIN_T, default 4096 frames; set_flash_parts(2) = every length, for the test).
     static const int parts_min_t = getenv("SBV2_FLASH_PARTS_MIN_T") ? atoi(getenv("SBV2_FLASH_PARTS_MIN_T")) : 4096;
-    // ... and by grid size: a launch of <= 64 workgroups (a single utterance: 16) is a serial chain of key tiles per workgroup, where half the
-    // barriers and no conversion in the chain win as well (12.67 -> 12.52 ms per call for one 128-phoneme utterance).
-    static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 64;
+    // ... and by grid size: a launch of at most one workgroup per CU (a single utterance: 16) is a serial chain of key steps per workgroup, which the
+    // software-pipelined kernel on pre-split tiles (k_vits_flash_x3q, one workgroup per CU by its LDS) walks in 58 us at 897 frames against 84 (x3p) and
+    // ~80 (converting kernel): 12.67 -> 11.9 ms per call for one 128-phoneme utterance.  Larger launches (two workgroups per CU) stay on the converting kernel.
+    static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 256;
     const int64_t attn_wgs = (int64_t)((pl.maxT + 127) / 128) * pl.ng;
-    const bool kv_parts = SP && split_attn && flash_parts_enabled() && (pl.maxT >= parts_min_t || attn_wgs <= parts_max_wgs || flash_parts_mode() == 2);
+    const bool kv_parts = SP && split_attn && flash_parts_enabled() && (pl.maxT >= parts_min_t || attn_wgs <= parts_max_wgs || flash_parts_mode() >= 2);
     if (kv_parts) QKVs = alloc_split(ar, 2, 3 * H, N);
     // Large batches: the FFN pair on conv_clx.hip (pre-split chunk-major operands by LDS-DMA instead of conv_cl's transposing register staging):
     // x is split once per layer from its k-major plane (split_cl_km), conv_1's epilogue writes relu(.) as conv_2's operand parts, conv_2 writes
@@ -434,7 +436,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             else conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
             if (kv_parts)
                 vits_flash_attention_parts(pl.d_ag, pl.ng, pl.maxT, Q.p, Q.ld, QKVs, H, 2 * H, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window,
-                                           qscale, stream_);
+                                           qscale, stream_, flash_parts_mode() != 3);
             else
                 vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
                                      split_attn, stream_);

@@ -525,8 +525,9 @@ def test_decoder_respair_clx_path_same_bits_as_respair_cl_path():
 
 
 def test_flow_attention_on_presplit_keys_values_same_bits():
-    """The flow's split-bf16 attention on keys / values pre-split by the q | k | v product's epilogue (attn_flash.hip k_vits_flash_x3p: 64-key
-    staged tiles, transposing LDS reads; the default from 4096 frames) against the kernel that converts every key tile while staging it
+    """The flow's split-bf16 attention on keys / values pre-split by the q | k | v product's epilogue (attn_flash.hip k_vits_flash_x3q: LDS-DMA tiles,
+    software-pipelined steps; and k_vits_flash_x3p: 64-key staged tiles; the default from 4096 frames and for launches of <= 64 workgroups) against
+    the kernel that converts every key tile while staging it
     (sbv2_debug_set_flash_parts(0)): every sample identical, bit for bit, on a mixed batch whose lengths end inside a 32-key step, on a
     64-key tile edge, and below one tile, at the full shape (2 heads x 96) and the tiny one (head dimension 16: padded rows)."""
     lib = _lib.lib()
@@ -537,15 +538,18 @@ def test_flow_attention_on_presplit_keys_values_same_bits():
         # forced durations chosen so that the frame counts hit 64 k, 64 k + 32 and odd remainders
         for u, f in zip(utts, (128, 96, 37, 64)):
             d = np.ones_like(u["forced_durations"]); d[0] = max(1, f - (d.size - 1)); u["forced_durations"] = d
-        prev = lib.sbv2_debug_set_flash_parts(2)      # 2 = at every length (1, the default, takes it from 4096 frames)
+        prev = lib.sbv2_debug_set_flash_parts(2)      # 2 = at every length (1, the default, takes it from 4096 frames): k_vits_flash_x3q
         try:
             a = model.synthesize_batch(s, utts, forced=True)
+            lib.sbv2_debug_set_flash_parts(3)         # ... on the un-pipelined kernel k_vits_flash_x3p
+            c = model.synthesize_batch(s, utts, forced=True)
             lib.sbv2_debug_set_flash_parts(0)
             b = model.synthesize_batch(s, utts, forced=True)
         finally:
             lib.sbv2_debug_set_flash_parts(prev)
-        for x, y in zip(a, b):
+        for x, y, z in zip(a, b, c):
             np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(z, y)
         s.close()
 
 
