@@ -452,7 +452,11 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
         else if (half == 3 && blocks(128, 128) > 512 && blocks(128, 128) < 640) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);   // (the 544-workgroup product too)
         else if (half == 8 && k32) launch_bfs_cfg<2, 1, 2, 2, 2, 2, 2, true>(kp, stream);   // experiments: two chunks per slot (a barrier every 32 k), two slots: 48 KB
         else if (half == 9) launch_bfs_cfg<2, 2, 1, 2, 2, 1, 4, true>(kp, stream);          // experiments: 128 x 64 tiles, 48 KB
-        else if (half == 5 || half == 8 || half == 9) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);   // 64 x 128 everywhere, 48 KB: three workgroups per CU
+        else if ((half == 10 || half == 11) && blocks(64, 128) < 400) {   // experiments: the 1024-row products (272 workgroups of 64 x 128) on 64 x 64 tiles: 544
+            if (half == 10) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 4, true>(kp, stream);   // 32 KB: four per CU
+            else launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);              // 64 KB: two per CU
+        }
+        else if (half == 5 || half == 8 || half == 9 || half == 10 || half == 11) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);   // 64 x 128 everywhere, 48 KB: three workgroups per CU
         else if (half == 6) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 3, true>(kp, stream);   // ... 36 KB: four per CU
         else if (half == 7 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
         else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4, true>(kp, stream);
