@@ -447,7 +447,12 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
     // 6 = 3 slots / four per CU (7.7 ms); 7 = mode 1 on 4 slots
     static const int half = getenv("SBV2_BFS_HALF") ? atoi(getenv("SBV2_BFS_HALF")) : 5;
     if (p.W.f16) {   // the ring shapes of bf16x3 (same bytes per chunk), two accumulator sets
-        if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
+        static const int small_cfg = getenv("SBV2_BFS_SMALL") ? atoi(getenv("SBV2_BFS_SMALL")) : 0;   // experiments on the small-grid (single-utterance) products
+        if (!big && small_cfg == 1 && k32) launch_bfs_cfg<2, 1, 1, 2, 2, 2, 4, true>(kp, stream);        // two chunks per slot: a barrier every 32 k
+        else if (!big && small_cfg == 2) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 4, true>(kp, stream);           // 4 slots
+        else if (!big && small_cfg == 3) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 16, true>(kp, stream);          // 16 slots (128 KB: one workgroup per CU)
+        else if (!big && small_cfg == 4) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 12, true>(kp, stream);          // 12 slots
+        else if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
         else if ((half == 1 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) || half == 2) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);
         else if (half == 3 && blocks(128, 128) > 512 && blocks(128, 128) < 640) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);   // (the 544-workgroup product too)
         else if (half == 8 && k32) launch_bfs_cfg<2, 1, 2, 2, 2, 2, 2, true>(kp, stream);   // experiments: two chunks per slot (a barrier every 32 k), two slots: 48 KB
