@@ -898,9 +898,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned lds_k0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)fq_smem);
     const unsigned lds_v0 = lds_k0 + 2 * IMG;
     const unsigned lds_dummy = lds_k0 + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32);   // NW x 64 floats
-    const unsigned lds_ql = lds_dummy + NW * 64 * 4;   // the lo parts of q as B fragments: [NW][KS][64 lanes][16 bytes]
+    // the lo parts of q: in LDS as B fragments [NW][KS][64 lanes][16 bytes] for the 4-wave workgroup (one wave per SIMD, the registers go to deeper
+    // fragment prefetch); in registers for the 8-wave one (two waves per SIMD hide each other's fragment latency; its LDS holds 18 KB of band state)
+    constexpr bool QL_LDS = NW == 4;
+    constexpr int QL_BYTES = QL_LDS ? NW * KS * 1024 : 0;
+    const unsigned lds_ql = lds_dummy + NW * 64 * 4;
     constexpr int kStampMax = 160;   // per wave
-    const unsigned lds_st = lds_ql + NW * KS * 1024;
+    const unsigned lds_st = lds_ql + QL_BYTES;
     int nst = 0;
     auto stamp = [&]() {
         if constexpr (DG) {
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     // q: the hi parts stay in registers; the lo parts live in LDS (24 registers the pipelined loop needs), read with the K fragments of their k-step
-    fa_bf16x8 qh[KS];
+    fa_bf16x8 qh[KS], qlr[QL_LDS ? 1 : KS];
     const unsigned ql_a = lds_ql + (wave * KS * 64 + lane) * 16;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -1032,7 +1036,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         fa_bf16x8 qlo;
         fa_split8(v, qh[s], qlo);
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ql_a), "v"(qlo), "n"(s * 1024) : "memory");
+        if constexpr (QL_LDS) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ql_a), "v"(qlo), "n"(s * 1024) : "memory");
+        else qlr[s] = qlo;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -1060,8 +1065,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         f.hh = fq_read_tr<s * 2048>(ahi);
         f.ll = fq_read_tr<PART + s * 2048>(alo);
         f.lh = fq_read_tr<PART + s * 2048>(ahi);
-        const unsigned qa = ql_a;   // (a local: an asm operand cannot name a captured variable)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ql) : "v"(qa), "n"(s * 1024));
+        if constexpr (QL_LDS) {
+            const unsigned qa = ql_a;   // (a local: an asm operand cannot name a captured variable)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ql) : "v"(qa), "n"(s * 1024));
+        }
     };
     auto read_v = [&](VF& f, auto dtc, unsigned a0, unsigned a1) {
         constexpr int dt = decltype(dtc)::value;
@@ -1088,7 +1095,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     // the reads are asm the compiler does not count: waits are explicit and tied to the registers they release
     auto wait_k = [](KF& f, auto nc) {
-        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f.hl), "+v"(f.hh), "+v"(f.ll), "+v"(f.lh), "+v"(f.ql) : "n"(decltype(nc)::value));
+        if constexpr (QL_LDS) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f.hl), "+v"(f.hh), "+v"(f.ll), "+v"(f.lh), "+v"(f.ql) : "n"(decltype(nc)::value));
+        else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.hl), "+v"(f.hh), "+v"(f.ll), "+v"(f.lh) : "n"(decltype(nc)::value));
     };
     auto wait_v = [](VF& f, auto nc) {
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.h0), "+v"(f.h1), "+v"(f.l0), "+v"(f.l1) : "n"(decltype(nc)::value));
@@ -1142,7 +1150,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if constexpr (s + 1 < KS) read_k(kf[(s + 1) % 2], std::integral_constant<int, s + 1>{}, alo, ahi);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_lo(f), qh[s], acc, 0, 0, 0);
             } else if constexpr (term == 1) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), f.ql, acc, 0, 0, 0);
+                if constexpr (QL_LDS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), f.ql, acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), qlr[s], acc, 0, 0, 0);
             } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_hi(f), qh[s], acc, 0, 0, 0);
             }
@@ -1374,7 +1383,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if constexpr (DG) {
         __syncthreads();
         if (blockIdx.x == 0 && blockIdx.y == 0 && stamps)
-            for (int q = threadIdx.x; q < NW * kStampMax; q += NTH) stamps[q] = q % kStampMax < nst ? reinterpret_cast<unsigned long long*>(fq_smem + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + NW * KS * 1024)[q] : 0ull;
+            for (int q = threadIdx.x; q < NW * kStampMax; q += NTH) stamps[q] = q % kStampMax < nst ? reinterpret_cast<unsigned long long*>(fq_smem + 4 * IMG + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + QL_BYTES)[q] : 0ull;
     }
     if (!active) return;
 
@@ -1399,7 +1408,7 @@ template <int DT, int NW>
 void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0, int v_row0, float* ctx,
                       int ldc, int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
     constexpr int DR = DT * 32;
-    constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + NW * (DR / 16) * 1024;
+    constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + (NW == 4 ? NW * (DR / 16) * 1024 : 0);
     const __bf16* base = static_cast<const __bf16*>(kv.p);
     const dim3 grid((maxT + 32 * NW - 1) / (32 * NW), ngroups);
     static const char* stamp_file = getenv("SBV2_FLASH_Q_STAMPS");
@@ -1446,6 +1455,12 @@ void launch_flash_x3p(dim3 grid, const AttnGroup* groups, const float* Q, int ld
 }
 }  // namespace
 
+// the software-pipelined kernel (k_vits_flash_x3q) wherever its DMA blocks fit (head dimensions that are multiples of 8); SBV2_FLASH_Q=0: never
+bool flash_pipelined_usable(int dk) {
+    static const int use_q = getenv("SBV2_FLASH_Q") ? atoi(getenv("SBV2_FLASH_Q")) : 1;
+    return use_q != 0 && (dk & 7) == 0 && dk <= 96;
+}
+
 // keys / values from bf16 hi / lo planes (rows k_row0 .. + heads dk and v_row0 .. of kv: two bf16 parts, the columns of Q's plane)
 void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
                                 int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
@@ -1454,10 +1469,15 @@ void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, 
     SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
     SBV2_REQUIRE(kv.parts == 2 && !kv.f16 && (kv.ld & 3) == 0, "flash attention: keys / values must be two bf16 parts");
     if (ngroups <= 0 || maxT <= 0) return;
-    // the software-pipelined kernel (k_vits_flash_x3q) wherever its DMA blocks fit (head dimensions that are multiples of 8); SBV2_FLASH_Q=0: k_vits_flash_x3p
-    static const int use_q = getenv("SBV2_FLASH_Q") ? atoi(getenv("SBV2_FLASH_Q")) : 1;
-    if (use_q && pipelined && (dk & 7) == 0) {
-        if (dk <= 32) launch_flash_x3q<1, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+    if (pipelined && flash_pipelined_usable(dk)) {
+        // 128-query workgroups (4 waves, one per SIMD) while they leave at most one workgroup per CU; beyond, 256-query workgroups of 8 waves (two per SIMD)
+        static const int q8_min = getenv("SBV2_FLASH_Q8_MIN_WGS") ? atoi(getenv("SBV2_FLASH_Q8_MIN_WGS")) : 257;
+        const bool wide = (int64_t)((maxT + 127) / 128) * ngroups >= q8_min;
+        if (wide) {
+            if (dk <= 32) launch_flash_x3q<1, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+            else if (dk <= 64) launch_flash_x3q<2, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+            else launch_flash_x3q<3, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        } else if (dk <= 32) launch_flash_x3q<1, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
         else if (dk <= 64) launch_flash_x3q<2, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
         else launch_flash_x3q<3, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
         HIP_CHECK(hipGetLastError());

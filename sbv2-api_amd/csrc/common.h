@@ -305,6 +305,8 @@ struct GemmBfsParams {
     float* Y = nullptr;     // f32 result plane [M][ldy] (may be null when only the split copy is wanted)
     int ldy = 0;
     SplitPlanes Ys;         // optional split copy of the result (parts = 0: none)
+    int y_rows = 0x7fffffff;   // the f32 plane receives rows < y_rows only ...
+    int ys_row0 = 0;           // ... and the split copy rows >= ys_row0 (the flow's q | k | v product: q as f32, k and v as parts for the attention)
     const float* bias = nullptr;   // per row
     int act = ACT_NONE;
     float alpha = 1.0f, beta = 1.0f;

@@ -357,8 +357,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
                     x *= p.beta;
                     v[e] = keep[e] ? x : 0.f;
                 }
-                if (p.Y) *reinterpret_cast<f32x4v*>(p.Y + (int64_t)m * p.ldy + n) = f32x4v{v[0], v[1], v[2], v[3]};
-                if (p.Ys.parts) split_store4(p.Ys, (int64_t)m * p.Ys.ld + n, v);
+                if (p.Y && m < p.y_rows) *reinterpret_cast<f32x4v*>(p.Y + (int64_t)m * p.ldy + n) = f32x4v{v[0], v[1], v[2], v[3]};
+                if (p.Ys.parts && m >= p.ys_row0) split_store4(p.Ys, (int64_t)m * p.Ys.ld + n, v);
             }
         }
 }

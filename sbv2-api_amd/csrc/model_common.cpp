@@ -333,7 +333,7 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 
 // 1x1 product on the bf16 matrix cores with pre-split operands (gemm_bfs.hip); y and / or ys receive the result.
 void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
-              hipStream_t s, int act, const Plane* res, float alpha, float beta) {
+              hipStream_t s, int act, const Plane* res, float alpha, float beta, int y_rows, int ys_row0) {
     SBV2_REQUIRE(w.bfs.parts && w.k == 1 && xs.C == w.cin && xs.parts == w.bfs.parts && xs.f16 == w.bfs.f16, "conv_bfs: operands were not prepared for the split-bf16 kernel");
     GemmBfsParams p;
     p.W = w.bfs;
@@ -360,6 +360,8 @@ void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const 
     }
     p.mask = mask;
     p.mask_div = mask_div;
+    if (y_rows >= 0) p.y_rows = y_rows;
+    p.ys_row0 = ys_row0;
     launch_gemm_bfs(p, s);
 }
 

@@ -99,7 +99,8 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
                 int accumulate = 0);
 // 1x1 product with pre-split bf16 operands (gemm_bfs.hip): y (f32 plane) and / or ys (bf16 parts) receive act(W x + b) * alpha (+ res) * beta
 void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
-              hipStream_t s, int act = ACT_NONE, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f);
+              hipStream_t s, int act = ACT_NONE, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f, int y_rows = -1, int ys_row0 = 0);
+// (y_rows >= 0: only rows < y_rows go to y; ys_row0: only rows >= ys_row0 go to ys)
 // y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
 bool conv_km_to_cl(const PackedConv& w, Plane x, float* y, int ldy, int dil, int pad_l, const unsigned char* mask, int mask_div,
                    hipStream_t s);

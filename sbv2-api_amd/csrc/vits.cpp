@@ -403,17 +403,17 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     }
     // the split-bf16 attention reads its keys / values as bf16 hi / lo planes written by the q | k | v product's epilogue next to the f32
     // plane (attn_flash.hip, k_vits_flash_x3p: no conversion per key tile; the same bits as converting while staging)
-    // Measured (one MI355X, same box): at 897 frames x 32 utterances the pre-split kernel is SLOWER (138 against 124 us per launch, + 4 us for the
-    // product's extra parts: step 87.1 against 86.6 ms); at 14 001 frames it wins (first PCM of the 2000-phoneme stream 44.3 -> 41.9 ms, whole
-    // sequence 78.5 -> 76.9 ms): what it saves, one conversion of every key tile per 128-query workgroup, grows with T / 128.  The bits are the
-    // same, so the choice is made by length (SBV2_FLASH_PARTS_MIN_T, default 4096 frames; set_flash_parts(2) = every length, for the test).
+    // Which kernel (same bits, so the choice is free).  The software-pipelined kernel on pre-split tiles (k_vits_flash_x3q, attn_flash.hip) at every size when
+    // the head dimension fits its DMA blocks: 4-wave workgroups while they leave at most one per CU (a single utterance: 58 us per launch at 897 frames
+    // against 84 for k_vits_flash_x3p and ~80 for the converting kernel), 8-wave workgroups beyond (32 x 897 frames: 84 us against 113; the q | k | v product
+    // then writes q as f32 and k / v as parts only: the same bytes).  Otherwise the un-pipelined pre-split kernel from SBV2_FLASH_PARTS_MIN_T frames (4096: at 897
+    // frames x 32 it is slower than converting, 138 against 124 us; at 14 001 it wins) and for launches of <= 64 workgroups; the converting kernel for the rest.
+    // set_flash_parts: 2 = parts at every length, 3 = ... on the un-pipelined kernel, 0 = never (the tests).
     static const int parts_min_t = getenv("SBV2_FLASH_PARTS_MIN_T") ? atoi(getenv("SBV2_FLASH_PARTS_MIN_T")) : 4096;
-    // ... and by grid size: a launch of at most one workgroup per CU (a single utterance: 16) is a serial chain of key steps per workgroup, which the
-    // software-pipelined kernel on pre-split tiles (k_vits_flash_x3q, one workgroup per CU by its LDS) walks in 58 us at 897 frames against 84 (x3p) and
-    // ~80 (converting kernel): 12.67 -> 11.9 ms per call for one 128-phoneme utterance.  Larger launches (two workgroups per CU) stay on the converting kernel.
-    static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 256;
+    static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 64;
     const int64_t attn_wgs = (int64_t)((pl.maxT + 127) / 128) * pl.ng;
-    const bool kv_parts = SP && split_attn && flash_parts_enabled() && (pl.maxT >= parts_min_t || attn_wgs <= parts_max_wgs || flash_parts_mode() >= 2);
+    const bool kv_parts = SP && split_attn && flash_parts_enabled() &&
+                          ((flash_parts_mode() != 3 && flash_pipelined_usable(dk)) || pl.maxT >= parts_min_t || attn_wgs <= parts_max_wgs || flash_parts_mode() >= 2);
     if (kv_parts) QKVs = alloc_split(ar, 2, 3 * H, N);
     // Large batches: the FFN pair on conv_clx.hip (pre-split chunk-major operands by LDS-DMA instead of conv_cl's transposing register staging):
     // x is split once per layer from its k-major plane (split_cl_km), conv_1's epilogue writes relu(.) as conv_2's operand parts, conv_2 writes
@@ -432,7 +432,9 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             if (SP) split_planes(x, Xs, stream_);
         }
         if (fused) {
-            if (SP) conv_bfs(L.attn.qkv, Xs, &QKV, kv_parts ? &QKVs : nullptr, nullptr, 1, stream_);
+            // (keys / values as parts: q goes to the f32 plane, k and v to the parts only: the bytes of the one-format product)
+            if (SP && kv_parts) conv_bfs(L.attn.qkv, Xs, &QKV, &QKVs, nullptr, 1, stream_, ACT_NONE, nullptr, 1.0f, 1.0f, H, H);
+            else if (SP) conv_bfs(L.attn.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_);
             else conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
             if (kv_parts)
                 vits_flash_attention_parts(pl.d_ag, pl.ng, pl.maxT, Q.p, Q.ld, QKVs, H, 2 * H, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window,
