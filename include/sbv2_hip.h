@@ -228,7 +228,8 @@ int sbv2_debug_set_skinny_max(int workgroups);
 int sbv2_debug_set_clx(int on);
 /* the flow's attention on keys / values pre-split by the q | k | v product: 1 (default) for sequences of >= 4096 frames and launches of <= 64
    workgroups, 2 at every length, 3 at every length on the un-pipelined kernel (k_vits_flash_x3p, the fallback for head dimensions that are no multiple
-   of 8), 0 never (converted per key tile inside the attention kernel); bit-identical; returns the previous setting (SBV2_FLASH_PARTS) */
+   of 8), 4 at every length on the pipelined kernel's 8-wave shape (the batch shape, forced for the test), 0 never (converted per key tile inside the
+   attention kernel); bit-identical; returns the previous setting (SBV2_FLASH_PARTS) */
 int sbv2_debug_set_flash_parts(int on);
 /* Same contract as sbv2_debug_conv1d_cl (mode 1) through conv_clx.hip: x is split into bf16 parts of lrelu(x, pre_slope) first (split_cl), the
    convolution reads the parts; y = (conv + bias + res) * beta; ys_sum (optional) = hi + lo of the parts of lrelu(y, 0.1) the epilogue emits. */

@@ -543,13 +543,16 @@ def test_flow_attention_on_presplit_keys_values_same_bits():
             a = model.synthesize_batch(s, utts, forced=True)
             lib.sbv2_debug_set_flash_parts(3)         # ... on the un-pipelined kernel k_vits_flash_x3p
             c = model.synthesize_batch(s, utts, forced=True)
+            lib.sbv2_debug_set_flash_parts(4)         # ... on the 8-wave (256-query) shape large batches take
+            e = model.synthesize_batch(s, utts, forced=True)
             lib.sbv2_debug_set_flash_parts(0)
             b = model.synthesize_batch(s, utts, forced=True)
         finally:
             lib.sbv2_debug_set_flash_parts(prev)
-        for x, y, z in zip(a, b, c):
+        for x, y, z, v in zip(a, b, c, e):
             np.testing.assert_array_equal(x, y)
             np.testing.assert_array_equal(z, y)
+            np.testing.assert_array_equal(v, y)
         s.close()
 
 
