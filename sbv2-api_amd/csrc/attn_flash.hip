@@ -880,7 +880,7 @@ __device__ __forceinline__ void fq_wait_vm() {
 template <int DT, int NW, bool DG = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vits_flash_x3q(const AttnGroup* groups, const float* Q, int ld, const __bf16* Kp, const __bf16* Vp,
                                                               int64_t pstride, int ldp, float* ctx, int ldc, int dk, const float* erk, const float* erv,
-                                                              int w, float qscale, SplitPlanes cs, unsigned long long* stamps = nullptr) {
+                                                              int w, float qscale, unsigned long long* stamps = nullptr) {
     constexpr int DR = DT * 32;
     constexpr int KS = DR / 16;            // bf16 k-steps over the head dimension
     constexpr int NB8 = DR / 8;            // 8-row DMA blocks per part (1 KB each)
@@ -1123,7 +1123,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             else fq_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
         }
-        // requests: odd t (and -1): K tile (t + 3) / 2; even t: V tile t / 2 + 1
+        // requests: odd t (and -1): K tile (t + 3) / 2; even t: V tile t / 2 + 1.  (Dealt into the step's first MFMA gaps instead they cost more than they hid:
+        // 58 -> 76 us per launch for a single utterance: address arithmetic and a uniform branch per request inside the in-order MFMA / softmax stream.)
         if (t & 1) {
             const int u = (t + 3) / 2;
             if (u < ntiles) dma_k(u);
@@ -1400,17 +1401,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             float v = cacc[dt][r] * inv;
 #pragma unroll
             for (int b = 0; b < kFaBand; ++b) v = fmaf(pb[b], erv_s[b * DR + d], v);
-            if (i < T && d < dk) {
-                // (cs: the context as the operand parts of the output projection, written here instead of a split pass over an f32 plane)
-                if (cs.parts) split_store1(cs, ((int64_t)g.head * dk + d) * cs.ld + g.col0 + i, v);
-                else Cg[(int64_t)d * ldc + i] = v;
-            }
+            if (i < T && d < dk) Cg[(int64_t)d * ldc + i] = v;
         }
 }
 
 template <int DT, int NW>
 void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0, int v_row0, float* ctx,
-                      int ldc, int dk, const float* erk, const float* erv, int window, float qscale, const SplitPlanes& cs, hipStream_t s) {
+                      int ldc, int dk, const float* erk, const float* erv, int window, float qscale, hipStream_t s) {
     constexpr int DR = DT * 32;
     constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + (NW == 4 ? NW * (DR / 16) * 1024 : 0);
     const __bf16* base = static_cast<const __bf16*>(kv.p);
@@ -1424,7 +1421,7 @@ void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const floa
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) HIP_CHECK(hipMalloc(&dbuf, n * sizeof(unsigned long long)));
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds + n * 8, s, groups, Q, ld, base + (int64_t)k_row0 * kv.ld, base + (int64_t)v_row0 * kv.ld, kv.pstride,
-                           kv.ld, ctx, ldc, dk, erk, erv, window, qscale, cs, dbuf);
+                           kv.ld, ctx, ldc, dk, erk, erv, window, qscale, dbuf);
         HIP_CHECK(hipStreamSynchronize(s));
         std::vector<unsigned long long> h(n);
         HIP_CHECK(hipMemcpy(h.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1442,7 +1439,7 @@ void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const floa
     static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, groups, Q, ld, base + (int64_t)k_row0 * kv.ld, base + (int64_t)v_row0 * kv.ld, kv.pstride, kv.ld,
-                       ctx, ldc, dk, erk, erv, window, qscale, cs, (unsigned long long*)nullptr);
+                       ctx, ldc, dk, erk, erv, window, qscale, (unsigned long long*)nullptr);
 }
 
 template <int DT>
@@ -1466,34 +1463,32 @@ bool flash_pipelined_usable(int dk) {
 }
 
 // keys / values from bf16 hi / lo planes (rows k_row0 .. + heads dk and v_row0 .. of kv: two bf16 parts, the columns of Q's plane)
-bool vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
+void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
                                 int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
-                                hipStream_t s, int pipelined, const SplitPlanes* ctx_parts) {
+                                hipStream_t s, int pipelined) {
     SBV2_REQUIRE(window <= kFaMaxWin, "relative attention window larger than the compiled maximum");
     SBV2_REQUIRE(dk >= 2 && dk <= 96 && (dk & 1) == 0, "flash attention: head dimension must be even and <= 96");
     SBV2_REQUIRE(kv.parts == 2 && !kv.f16 && (kv.ld & 3) == 0, "flash attention: keys / values must be two bf16 parts");
-    if (ngroups <= 0 || maxT <= 0) return false;
+    if (ngroups <= 0 || maxT <= 0) return;
     if (pipelined && flash_pipelined_usable(dk)) {
-        const SplitPlanes cs = ctx_parts ? *ctx_parts : SplitPlanes{};
         // 128-query workgroups (4 waves, one per SIMD) while they leave at most one workgroup per CU; beyond, 256-query workgroups of 8 waves (two per SIMD)
         static const int q8_min = getenv("SBV2_FLASH_Q8_MIN_WGS") ? atoi(getenv("SBV2_FLASH_Q8_MIN_WGS")) : 257;
         const bool wide = pipelined == 2 || (int64_t)((maxT + 127) / 128) * ngroups >= q8_min;   // (2: the test forces the 8-wave shape on small batches)
         if (wide) {
-            if (dk <= 32) launch_flash_x3q<1, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, cs, s);
-            else if (dk <= 64) launch_flash_x3q<2, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, cs, s);
-            else launch_flash_x3q<3, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, cs, s);
-        } else if (dk <= 32) launch_flash_x3q<1, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, cs, s);
-        else if (dk <= 64) launch_flash_x3q<2, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, cs, s);
-        else launch_flash_x3q<3, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, cs, s);
+            if (dk <= 32) launch_flash_x3q<1, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+            else if (dk <= 64) launch_flash_x3q<2, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+            else launch_flash_x3q<3, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        } else if (dk <= 32) launch_flash_x3q<1, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        else if (dk <= 64) launch_flash_x3q<2, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
+        else launch_flash_x3q<3, 4>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
         HIP_CHECK(hipGetLastError());
-        return ctx_parts != nullptr;   // the context went out as parts
+        return;
     }
     const dim3 grid((maxT + 127) / 128, ngroups);
     if (dk <= 32) launch_flash_x3p<1>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
     else if (dk <= 64) launch_flash_x3p<2>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
     else launch_flash_x3p<3>(grid, groups, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
     HIP_CHECK(hipGetLastError());
-    return false;
 }
 
 void vits_flash_attention(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, const float* V, int ld, float* ctx,

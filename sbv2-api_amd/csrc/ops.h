@@ -47,9 +47,9 @@ void vits_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, cons
                   const float* erk, int window, float qscale, float* pwin, hipStream_t s);
 // fused QK^T + relative-key term + online softmax + PV + relative-value term (attn_flash.hip); Q, K, V, ctx: k-major planes
 bool flash_pipelined_usable(int dk);   // attn_flash.hip: k_vits_flash_x3q takes this head dimension (and SBV2_FLASH_Q != 0)
-bool vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
+void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
                                 int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
-                                hipStream_t s, int pipelined = 1, const SplitPlanes* ctx_parts = nullptr);   // pipelined: 0 = k_vits_flash_x3p, 1 = k_vits_flash_x3q (shape by grid), 2 = ... 8-wave shape;   // -> true: the context was written as ctx_parts (no f32 plane);   // keys / values pre-split into two bf16 parts (rows of kv); same bits as the split variant below
+                                hipStream_t s, int pipelined = 1);   // pipelined: 0 = k_vits_flash_x3p, 1 = k_vits_flash_x3q (shape by grid), 2 = ... 8-wave shape;   // keys / values pre-split into two bf16 parts (rows of kv); same bits as the split variant below
 void vits_flash_attention(const AttnGroup* groups, int ngroups, int maxT, const float* Q, const float* K, const float* V, int ld, float* ctx,
                           int ldc, int dk, const float* erk, const float* erv, int window, float qscale, bool split_bf16, hipStream_t s);
 void vits_relv_add(const AttnGroup* groups, int ngroups, int maxT, float* ctx, int ldc, int dk, const float* erv,

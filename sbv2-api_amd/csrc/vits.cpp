@@ -409,7 +409,6 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     // then writes q as f32 and k / v as parts only: the same bytes).  Otherwise the un-pipelined pre-split kernel from SBV2_FLASH_PARTS_MIN_T frames (4096: at 897
     // frames x 32 it is slower than converting, 138 against 124 us; at 14 001 it wins) and for launches of <= 64 workgroups; the converting kernel for the rest.
     // set_flash_parts: 2 = parts at every length, 3 = ... on the un-pipelined kernel, 0 = never (the tests).
-    static const int ctx_parts_on = getenv("SBV2_FLASH_CTX_PARTS") ? atoi(getenv("SBV2_FLASH_CTX_PARTS")) : 1;   // the attention writes the context as the output projection's operand parts (A/B)
     static const int parts_min_t = getenv("SBV2_FLASH_PARTS_MIN_T") ? atoi(getenv("SBV2_FLASH_PARTS_MIN_T")) : 4096;
     static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 64;
     const int64_t attn_wgs = (int64_t)((pl.maxT + 127) / 128) * pl.ng;
@@ -432,15 +431,14 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             add_segvec(x, spk_vec, H, lay.d_seg_of, 1, lay.d_mask, stream_);
             if (SP) split_planes(x, Xs, stream_);
         }
-        bool ctx_split = false;
         if (fused) {
             // (keys / values as parts: q goes to the f32 plane, k and v to the parts only: the bytes of the one-format product)
             if (SP && kv_parts) conv_bfs(L.attn.qkv, Xs, &QKV, &QKVs, nullptr, 1, stream_, ACT_NONE, nullptr, 1.0f, 1.0f, H, H);
             else if (SP) conv_bfs(L.attn.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_);
             else conv_plain(L.attn.qkv, x, QKV, 1, 0, nullptr, 1, stream_);
             if (kv_parts)
-                ctx_split = vits_flash_attention_parts(pl.d_ag, pl.ng, pl.maxT, Q.p, Q.ld, QKVs, H, 2 * H, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window,
-                                                       qscale, stream_, flash_parts_mode() == 3 ? 0 : (flash_parts_mode() == 4 ? 2 : 1), SP && ctx_parts_on ? &Cs : nullptr);
+                vits_flash_attention_parts(pl.d_ag, pl.ng, pl.maxT, Q.p, Q.ld, QKVs, H, 2 * H, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window,
+                                           qscale, stream_, flash_parts_mode() == 3 ? 0 : (flash_parts_mode() == 4 ? 2 : 1));
             else
                 vits_flash_attention(pl.d_ag, pl.ng, pl.maxT, Q.p, K.p, Vp.p, Q.ld, ctx.p, ctx.ld, dk, L.attn.erk, L.attn.erv, cfg_.window, qscale,
                                      split_attn, stream_);
@@ -454,7 +452,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             vits_relv_add(pl.d_ag, pl.ng, pl.maxT, ctx.p, ctx.ld, dk, L.attn.erv, cfg_.window, pl.PW, stream_);
         }
         if (SP) {
-            if (!ctx_split) split_planes(ctx, Cs, stream_);   // (the pipelined attention writes the parts itself)
+            split_planes(ctx, Cs, stream_);
             conv_bfs(L.attn.o, Cs, &Y, nullptr, nullptr, 1, stream_, ACT_NONE, &x);
         } else {
             conv_plain(L.attn.o, ctx, Y, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &x);
