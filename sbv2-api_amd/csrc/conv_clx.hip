@@ -84,11 +84,14 @@ __device__ __forceinline__ bf16x8 clx_read_b128o(unsigned addr) {
 // WM = 2: 8 waves, 128 rows x 256 positions (both 64-row wave groups read the one staged window), one workgroup per CU.
 // WM = 1: 4 waves, 64 rows; <= 80 KB of LDS so that TWO workgroups share a CU: their barriers, prologues and epilogues interleave.
 // kClxWR weight ring slots, kClxXB window buffers.
-template <int NTAPS, int WM, int kClxWR, int kClxXB, int XR = kClxXR>
+template <int NTAPS, int WM, int kClxWR, int kClxXB, int XR = kClxXR, bool FRONT = false>
 __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 1 && kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
     constexpr int NW = 4 * WM;                 // waves
     constexpr int kClxPW = 20 / (NW / 2);      // window DMA pieces per window wave and chunk (2 parts x 10 pieces of 32 rows)
-    constexpr int PPT = (kClxPW + NTAPS - 2) / (NTAPS - 1);   // ... per tap (the last tap of a chunk carries none)
+    // ... per tap (the last tap of a chunk carries none).  FRONT: as many as a tap's gaps hold (8) from the chunk's first tap on, so that the LAST piece of the next
+    // window has the rest of the chunk to land (spread evenly its lead is one or two steps at every k)
+    constexpr int PPT = FRONT ? (kClxPW < 8 ? kClxPW : 8) : (kClxPW + NTAPS - 2) / (NTAPS - 1);
+    static_assert(PPT * (NTAPS - 1) >= kClxPW, "the chunk's taps hold its window pieces");
     static_assert(PPT <= 8, "a tap's MFMA gaps hold its window pieces");
     constexpr int WSLOT = 2 * WM * 2 * 1024;   // one (chunk, tap): 2 WM row tiles x 2 parts x 1 KB
     constexpr int WBYTES = kClxWR * WSLOT;
@@ -516,7 +519,7 @@ bool conv_clx_usable(const ConvClxParams& p) {
     return p.N >= 1 && p.X.N == p.N;
 }
 
-template <int NTAPS, int WM, int WR, int XB, int XR = kClxXR>
+template <int NTAPS, int WM, int WR, int XB, int XR = kClxXR, bool FRONT = false>
 static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     const ConvClxParams& p = kp.p;
     SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
@@ -524,7 +527,7 @@ static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     static const int contig = getenv("SBV2_CLX_CONTIG") ? atoi(getenv("SBV2_CLX_CONTIG")) : 0;
     kp.contig = contig;
     const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * XR * 32, (size_t)4 * WM * 64 * 36 * sizeof(float));
-    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB, XR>;
+    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB, XR, FRONT>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     const int ntx = round_up((p.N + kClxNT - 1) / kClxNT, 8);
@@ -560,15 +563,21 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     // buffers, 56 KB) stays at two per CU.  7 = the same without k = 11; 1 = two per CU for every k (round 3); 2 = 128-row workgroups (one per CU); 3 / 4 / 6
     // = other ring shapes (measured, slower: DESIGN 5.3)
     static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 8;
+    static const int front = getenv("SBV2_CLX_FRONT") ? atoi(getenv("SBV2_CLX_FRONT")) : 0;
     if (cfg == 2 && (p.M & 127) == 0 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
         else launch_clx<11, 2, 8, 3>(kp, stream);
+    } else if (cfg == 8 && front && kp.xrows <= 288 && p.ntaps != 3) {   // (experiment: window pieces front-loaded)
+        if (p.ntaps == 5) launch_clx<5, 1, 4, 2, 288, true>(kp, stream);
+        else if (p.ntaps == 7) launch_clx<7, 1, 4, 2, 288, true>(kp, stream);
+        else launch_clx<11, 1, 4, 2, 288, true>(kp, stream);
     } else if (cfg == 8 && kp.xrows <= 288 && p.ntaps == 11) {   // k = 11 at dilations 1 and 3 (and every conv2) fits the 288-row buffers too
         launch_clx<11, 1, 4, 2, 288>(kp, stream);
     } else if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8) && kp.xrows <= 288 && p.ntaps != 11 && (p.ntaps != 5 || cfg >= 7)) {
         // 4-slot weight ring + two 288-row window buffers (tap spans <= 32: k = 3 and k = 7 at every dilation of the model): 52 KB, THREE workgroups per CU
-        if (p.ntaps == 3) launch_clx<3, 1, 4, 2, 288>(kp, stream);
+        if (p.ntaps == 3 && front) launch_clx<3, 1, 4, 2, 288, true>(kp, stream);
+        else if (p.ntaps == 3) launch_clx<3, 1, 4, 2, 288>(kp, stream);
         else if (p.ntaps == 5) launch_clx<5, 1, 4, 2, 288>(kp, stream);
         else launch_clx<7, 1, 4, 2, 288>(kp, stream);
     } else if (cfg == 6 && p.ntaps == 11) {
