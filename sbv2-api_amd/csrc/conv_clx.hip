@@ -84,14 +84,20 @@ __device__ __forceinline__ bf16x8 clx_read_b128o(unsigned addr) {
 // WM = 2: 8 waves, 128 rows x 256 positions (both 64-row wave groups read the one staged window), one workgroup per CU.
 // WM = 1: 4 waves, 64 rows; <= 80 KB of LDS so that TWO workgroups share a CU: their barriers, prologues and epilogues interleave.
 // kClxWR weight ring slots, kClxXB window buffers.
-template <int NTAPS, int WM, int kClxWR, int kClxXB, int XR = kClxXR, bool FRONT = false>
-__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 1 && kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
+// TN: 32-position tiles per wave (2: 256 positions per workgroup; 1: 128, an experiment: 36 KB and <= 128 registers = FOUR workgroups per CU)
+template <int NTAPS, int WM, int kClxWR, int kClxXB, int XR = kClxXR, bool FRONT = false, int TN = 2>
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 1 && kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 40 * 1024 ? 4 : (WM == 1 && kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2)))) void conv_clx_kernel(const ClxKernelParams kp) {
+    constexpr int NPW = 32 * TN;               // positions per wave
+    constexpr int NTW = 4 * NPW;               // positions per workgroup
+    constexpr int NMF = 6 * TN;                // MFMAs per wave and step
+    constexpr int NRD = 4 + 2 * TN;            // fragment reads per wave and step
+    constexpr int G0 = NRD / 2;                // first MFMA gap without fragment reads
     constexpr int NW = 4 * WM;                 // waves
-    constexpr int kClxPW = 20 / (NW / 2);      // window DMA pieces per window wave and chunk (2 parts x 10 pieces of 32 rows)
+    constexpr int kClxPW = (2 * (XR / 32) + NW / 2 - 1) / (NW / 2);   // window DMA pieces per window wave and chunk (2 parts x XR / 32 pieces of 32 rows)
     // ... per tap (the last tap of a chunk carries none).  FRONT: as many as a tap's gaps hold (8) from the chunk's first tap on, so that the LAST piece of the next
     // window has the rest of the chunk to land (spread evenly its lead is one or two steps at every k)
     constexpr int PPT = FRONT ? (kClxPW < 8 ? kClxPW : 8) : (kClxPW + NTAPS - 2) / (NTAPS - 1);
-    static_assert(PPT * (NTAPS - 1) >= kClxPW, "the chunk's taps hold its window pieces");
+    static_assert(PPT * (NTAPS - 1) >= kClxPW && PPT <= NMF - G0, "the chunk's taps and their MFMA gaps hold its window pieces");
     static_assert(PPT <= 8, "a tap's MFMA gaps hold its window pieces");
     constexpr int WSLOT = 2 * WM * 2 * 1024;   // one (chunk, tap): 2 WM row tiles x 2 parts x 1 KB
     constexpr int WBYTES = kClxWR * WSLOT;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     // position tiles: round-robin over the XCDs (rounds 3: neighbours on different L2s re-fetch each other's halo rows from HBM), or (contig) a
     // contiguous range per XCD
     const int bx = kp.contig ? xcd * ((int)gridDim.x / (8 * kp.gy)) + slot / kp.gy : (slot / kp.gy) * 8 + xcd;
-    const int n0 = bx * kClxNT;
+    const int n0 = bx * NTW;
     if (n0 >= p.N) return;
     const int m0 = (by * WM + wm) * 64;        // first output row of this WAVE's tile
     const int M = p.M, N = p.N;
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
 
     // ---- fragments
     struct Frags {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+        bf16x8 ah[2], al[2], bh[TN], bl[TN];
     };
     const int lcol = lane & 31, lh = lane >> 5;
     const unsigned abase = lds0 + (wm * 2) * 2048 + lane * 16;
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     unsigned boff0[NTAPS];
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
-        const int r0 = wq * 64 + lcol + kp.sh0 + t * kp.sh_step;
+        const int r0 = wq * NPW + lcol + kp.sh0 + t * kp.sh_step;
         boff0[t] = lds0 + WBYTES + r0 * 32 + (((lh ^ (r0 >> 3)) & 1) << 4);
     }
     auto read_frag = [&](Frags& f, auto rc, unsigned aaddr, unsigned b0) {
@@ -193,23 +199,23 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         else if constexpr (r == 3) f.al[1] = clx_read_b128o<3072>(aaddr);
         else if constexpr (r == 4) f.bh[0] = clx_read_b128o<0>(b0);
         else if constexpr (r == 5) f.bl[0] = clx_read_b128o<XPART>(b0);
-        else if constexpr (r == 6) f.bh[1] = clx_read_b128o<1024>(b0);
-        else f.bl[1] = clx_read_b128o<XPART + 1024>(b0);
+        else if constexpr (r == 6 && TN == 2) f.bh[TN - 1] = clx_read_b128o<1024>(b0);
+        else if constexpr (TN == 2) f.bl[TN - 1] = clx_read_b128o<XPART + 1024>(b0);
     };
     unsigned wroff = 0;        // ring offset of the weight slot the NEXT fragment reads take (step s + 1 while step s runs)
     unsigned xroff = 0;        // buffer offset of the window those reads take
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // MFMA n of a step: term-major (lo*hi for the four tiles, hi*lo, hi*hi): per accumulator the order of conv_cl
     auto mfma_one = [&](const Frags& f, auto nc) {
         constexpr int n = decltype(nc)::value;
-        constexpr int t = n / 4, i = (n & 3) >> 1, j = n & 1;
+        constexpr int t = n / (2 * TN), i = (n % (2 * TN)) / TN, j = n % TN;
         if constexpr (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
         else if constexpr (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     }
     __builtin_amdgcn_s_barrier();
     Frags fa, fb;
-    clx_static_for<0, 8>([&](auto rc) { read_frag(fa, rc, abase, boff0[0]); });
+    clx_static_for<0, NRD>([&](auto rc) { read_frag(fa, rc, abase, boff0[0]); });
     wroff = WSLOT == WBYTES ? 0 : WSLOT;
 
     // One step: tap `tap` of chunk `chunk` (s = chunk * NTAPS + tap).  LAST = the step's successor opens a new chunk.
@@ -257,26 +263,26 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
         const bool stw = wwave && s + kClxWR < S;
         const bool stx = !wwave && chunk + kClxXB - 1 < nchunks;
-        clx_static_for<0, 12>([&](auto nc) {
+        clx_static_for<0, NMF>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             mfma_one(cur, nc);
-            if constexpr (n < 4) {
+            if constexpr (n < G0) {
                 if (rd) {
                     read_frag(nxt, std::integral_constant<int, 2 * n>{}, aaddr, b0);
                     read_frag(nxt, std::integral_constant<int, 2 * n + 1>{}, aaddr, b0);
                 }
             } else {
-                if constexpr (n == 5) {
+                if constexpr (n == (TN == 2 ? 5 : G0)) {
                     if (stw) dma_w();   // the blocks of step s + kClxWR, into the slot of step s (released by this step's barrier)
                 }
                 // window pieces of chunk + kClxXB - 1 (its buffer held chunk - 1): PPT per tap, one per gap, none with the chunk's last tap
-                if constexpr (tap < NTAPS - 1 && n - 4 < PPT) {
-                    constexpr int i = tap * PPT + (n - 4);
+                if constexpr (tap < NTAPS - 1 && n - G0 < PPT) {
+                    constexpr int i = tap * PPT + (n - G0);
                     if constexpr (i < kClxPW) {
                         if (stx) dma_x(std::integral_constant<int, i>{});
                     }
                 }
-                if constexpr (LAST && n == 4) {
+                if constexpr (LAST && n == G0) {
                     if (stx) next_window();
                 }
             }
@@ -316,31 +322,31 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     // is 32 consecutive positions of one channel = a 128-byte run of the plane; bias, mask and residual of a row tile are requested before its
     // first store (conv_cl's k-major epilogue)
     if (p.Ykm) {
-        int nn[2];
-        bool nok[2], keepn[2];
+        int nn[TN];
+        bool nok[TN], keepn[TN];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            nn[j] = n0 + wq * 64 + j * 32 + lcol;
+        for (int j = 0; j < TN; ++j) {
+            nn[j] = n0 + wq * NPW + j * 32 + lcol;
             nok[j] = nn[j] < N;
             const int nc = min(nn[j], N - 1);
             keepn[j] = !p.mask || p.mask[nc >> p.mask_shift] != 0;
         }
         clx_static_for<0, 2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            float brow[16], rr[16][2];
+            float brow[16], rr[16][TN];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mc = min(m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
                 brow[r] = p.bias ? p.bias[mc] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) rr[r][j] = p.Rkm ? p.Rkm[(int64_t)mc * p.ldrkm + min(nn[j], N - 1)] : 0.f;
+                for (int j = 0; j < TN; ++j) rr[r][j] = p.Rkm ? p.Rkm[(int64_t)mc * p.ldrkm + min(nn[j], N - 1)] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= M) continue;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TN; ++j) {
                     if (!nok[j]) continue;
                     float v = acc[i][j][r] + brow[r];
                     if (p.Rkm) v += rr[r][j];
@@ -355,17 +361,17 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
 
     // ---- epilogue (conv_cl's channels-last epilogue): each wave transposes its 32 x 64 sub-tiles through a private LDS tile [64 positions][36]
     // so that 8 consecutive lanes hold one full 128-byte line of a row; everything read from global memory is requested before the first store.
-    float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
+    float* tile = reinterpret_cast<float*>(smem) + wave * (NPW * 36);
     const float beta = p.beta;
     const int64_t yplane = (int64_t)(p.Ys.front + p.Ys.N + p.Ys.back) * 32;
     const int c4 = (lane & 7) * 4;
-    const int nfirst = n0 + wq * 64 + (lane >> 3);
+    const int nfirst = n0 + wq * NPW + (lane >> 3);
     const float* trow = tile + (lane >> 3) * 36 + c4;
     const float sl = p.ys_slope;
     clx_static_for<0, 2>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
@@ -375,10 +381,10 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         const bool mok = m < M;
         const int mc = mok ? m : 0;
         const f32x4v b4 = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + mc) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        f32x4v rold[8], rres[8];
-        unsigned char keep[8];
+        f32x4v rold[4 * TN], rres[4 * TN];
+        unsigned char keep[4 * TN];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 4 * TN; ++it) {
             const int64_t pp = min(nfirst + it * 8, N - 1);
             if (p.accumulate) rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + mc);
             if (p.R) rres[it] = *reinterpret_cast<const f32x4v*>(p.R + pp * p.ldr + mc);
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         // bf16 parts of lrelu(result), chunk-major (4 channels = 8 bytes of a 32-byte row; the lo plane follows the hi plane)
         char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nfirst) * 32 + (m & 15) * 2 : nullptr;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 4 * TN; ++it) {
             const int n = nfirst + it * 8;
             const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
             if (n < N && mok) {
@@ -519,18 +525,20 @@ bool conv_clx_usable(const ConvClxParams& p) {
     return p.N >= 1 && p.X.N == p.N;
 }
 
-template <int NTAPS, int WM, int WR, int XB, int XR = kClxXR, bool FRONT = false>
+template <int NTAPS, int WM, int WR, int XB, int XR = kClxXR, bool FRONT = false, int TN = 2>
 static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
+    constexpr int NTW = 128 * TN;
+    kp.xrows += NTW - kClxNT;
     const ConvClxParams& p = kp.p;
     SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
     kp.gy = p.M / (64 * WM);
     static const int contig = getenv("SBV2_CLX_CONTIG") ? atoi(getenv("SBV2_CLX_CONTIG")) : 0;
     kp.contig = contig;
-    const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * XR * 32, (size_t)4 * WM * 64 * 36 * sizeof(float));
-    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB, XR, FRONT>;
+    const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * XR * 32, (size_t)4 * WM * 32 * TN * 36 * sizeof(float));
+    auto kern = conv_clx_kernel<NTAPS, WM, WR, XB, XR, FRONT, TN>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
-    const int ntx = round_up((p.N + kClxNT - 1) / kClxNT, 8);
+    const int ntx = round_up((p.N + NTW - 1) / NTW, 8);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = conv_prof_active();
     if (prof) {
@@ -564,10 +572,17 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     // = other ring shapes (measured, slower: DESIGN 5.3)
     static const int cfg = getenv("SBV2_CLX_CFG") ? atoi(getenv("SBV2_CLX_CFG")) : 8;
     static const int front = getenv("SBV2_CLX_FRONT") ? atoi(getenv("SBV2_CLX_FRONT")) : 0;
+    // SBV2_CLX_NT128: mask of kernel sizes (1: k = 3, 2: k = 5, 4: k = 7, 8: k = 11) that run on 128-position workgroups (36 KB, <= 110 registers: four per CU)
+    static const int nt128 = getenv("SBV2_CLX_NT128") ? atoi(getenv("SBV2_CLX_NT128")) : 0;
     if (cfg == 2 && (p.M & 127) == 0 && p.ntaps != 5) {
         if (p.ntaps == 3) launch_clx<3, 2, 8, 3>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 2, 8, 3>(kp, stream);
         else launch_clx<11, 2, 8, 3>(kp, stream);
+    } else if (cfg == 8 && kp.xrows <= 288 && ((nt128 >> (p.ntaps == 3 ? 0 : p.ntaps == 5 ? 1 : p.ntaps == 7 ? 2 : 3)) & 1)) {   // 128-position workgroups, four per CU, for the kernel sizes of the mask
+        if (p.ntaps == 3) launch_clx<3, 1, 4, 2, 160, false, 1>(kp, stream);
+        else if (p.ntaps == 5) launch_clx<5, 1, 4, 2, 160, false, 1>(kp, stream);
+        else if (p.ntaps == 7) launch_clx<7, 1, 4, 2, 160, false, 1>(kp, stream);
+        else launch_clx<11, 1, 4, 2, 160, false, 1>(kp, stream);
     } else if (cfg == 8 && front && kp.xrows <= 288 && p.ntaps != 3) {   // (experiment: window pieces front-loaded)
         if (p.ntaps == 5) launch_clx<5, 1, 4, 2, 288, true>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 1, 4, 2, 288, true>(kp, stream);
