@@ -240,6 +240,12 @@ int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const floa
    d s_memrealtime x 100 (median over workgroups), ms per launch, shader cycles of a workgroup's chunk loop, workgroups stamped}.
    abl: 0 = the kernel, 1 = without its MFMAs, 2 = its MFMAs only, 3 = staging + barriers only. */
 int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int abl, double seconds, double* out4);
+/* Diagnostics: the life of a conv_clx workgroup (the ResBlock convolutions of the 128- / 256-channel decoder stages: scripts/convert/convert_model.py:97-110
+   exports them; no reference counterpart).  kind 1 = conv1 (parts in, parts out), 2 = conv2 (+ residual in, f32 + parts out), 3 = a branch's last conv2
+   (accumulating).  `seconds` of back-to-back launches, then the stamps of one more: 8 words per workgroup {loop start / end in shader cycles and in
+   100 MHz ticks, kernel entry, last store issued, stores acknowledged (100 MHz), HW_ID | XCC_ID << 32}; *ms_per_launch is of the un-stamped kernel. */
+int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int kind, int variant, double seconds, uint64_t* stamps,
+                            int64_t capacity_words, int64_t* workgroups, double* ms_per_launch);
 /* Diagnostics for the f16x3 operand format (DeBERTa's and the flow's 1x1 products): the split of an activation into the f16 hi / scaled-lo pair clamps
    finite values beyond +-65504 (NaN and infinities propagate).  enable = 1 / 0 switches the device-side counter of clamped values on / off for planes
    allocated from then on (-1: leave as is; the SBV2_F16X3_SATCOUNT=1 environment variable switches it on from the start); *count (optional) receives the

@@ -99,6 +99,8 @@ SYMBOLS = {
     "sbv2_debug_conv1d_clx": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                         C.c_int64, f32p, f32p, f32p]),
     "sbv2_debug_conv_cl_clock": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "sbv2_debug_clx_timeline": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_uint64), C.c_int64,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sbv2_debug_set_respair_clx": (C.c_int, [C.c_int]),
     "sbv2_debug_f16x3_saturation": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "sbv2_debug_respair": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_int,

@@ -606,8 +606,8 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
         nwg *= 2;   // (64-row workgroups at most)
     }
     unsigned long long* d_st = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 4 * nwg));
-    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 4 * nwg));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 8 * nwg));
+    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 8 * nwg));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -633,14 +633,15 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     HIP_CHECK(hipEventSynchronize(e1));
     float t50 = 0.f;
     HIP_CHECK(hipEventElapsedTime(&t50, e0, e1));
-    std::vector<unsigned long long> hs((size_t)4 * nwg);
+    std::vector<unsigned long long> hs((size_t)8 * nwg);
     HIP_CHECK(hipMemcpy(hs.data(), d_st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
     (void)hipFree(d_st);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     std::vector<double> mhz, cyc;
     for (int g = 0; g < nwg; ++g) {
-        const unsigned long long t0 = hs[4 * g], r0 = hs[4 * g + 1], t1 = hs[4 * g + 2], r1 = hs[4 * g + 3];
+        const int sg = abl == 10 ? 8 * g : 4 * g;   // (conv_clx keeps 8 words per workgroup)
+        const unsigned long long t0 = hs[sg], r0 = hs[sg + 1], t1 = hs[sg + 2], r1 = hs[sg + 3];
         if (r1 > r0 && t1 > t0) {
             mhz.push_back((double)(t1 - t0) / (double)(r1 - r0) * 100.0);
             cyc.push_back((double)(t1 - t0));
@@ -653,6 +654,110 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     out4[1] = t50 / 50.0;                    // ms per launch
     out4[2] = cyc[cyc.size() / 2];           // shader cycles of one workgroup's chunk loop (median)
     out4[3] = (double)mhz.size();
+    API_END
+}
+
+// Diagnostics: where a conv_clx workgroup's life goes.  Launches the ResBlock convolution of a wide decoder stage in the form the decoder launches it
+// (kind 1 = conv1: parts in, parts out; 2 = conv2: parts in, residual in, f32 + parts out; 3 = a branch's last conv2: residual + accumulate, f32 out)
+// back to back for `seconds`, then returns the stamps of the last launch: 8 words per workgroup {loop start (shader clock), loop start (100 MHz),
+// loop end (shader clock), loop end (100 MHz), kernel entry (100 MHz), last store issued, stores acknowledged, HW_ID | XCC_ID << 32}.
+int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int kind, int variant, double seconds, uint64_t* stamps,
+                            int64_t capacity_words, int64_t* workgroups, double* ms_per_launch) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(stamps && workgroups && ms_per_launch && C >= 64 && (C & 63) == 0 && k >= 1 && k <= kMaxTaps && L >= 256 && kind >= 1 && kind <= 3, "bad arguments");
+    std::vector<float> w((size_t)C * C * k), bias((size_t)C, 0.1f), x((size_t)L * C);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() {
+        float a = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            a += (float)((st >> 40) * (1.0 / 16777216.0)) - 0.5f;
+        }
+        return a * 1.7320508f;
+    };
+    for (auto& v : w) v = rnd() / std::sqrt((float)(C * k));
+    for (auto& v : x) v = rnd();
+    Blob b = one_conv_blob(w.data(), bias.data(), {C, C, k}, C);
+    WeightStore ws(b);
+    ClConv c = pack_cl(ws, w.data(), (int)C, (int)C, (int)k, 2, bias.data());
+    DevBuf dx(x.size()), dy(x.size()), dr(x.size());
+    HIP_CHECK(hipMemcpy(dx.p, x.data(), sizeof(float) * x.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dr.p, x.data(), sizeof(float) * x.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dy.p, 0, sizeof(float) * x.size()));
+    DevBuf dxs(split_cl_bytes((int)C, L) / 4 + 4), dys(split_cl_bytes((int)C, L) / 4 + 4);
+    SplitClPlanes xs = make_split_cl(dxs.p, (int)C, L, nullptr), ysp = make_split_cl(dys.p, (int)C, L, nullptr);
+    split_cl(dx.p, (int)C, L, (int)C, 0.1f, xs, nullptr);
+    unsigned char* dm = nullptr;
+    const size_t nm = (size_t)((L + 63) / 64);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dm), nm));
+    HIP_CHECK(hipMemset(dm, 1, nm));
+    ConvClxParams p;
+    p.X = xs;
+    p.W = c.w;
+    p.nmt = c.nmt;
+    p.M = (int)C;
+    p.N = (int)L;
+    p.K = (int)C;
+    p.ntaps = (int)k;
+    p.shift0 = (int)(-dilation * (k - 1) / 2);
+    p.shift_step = (int)dilation;
+    p.bias = c.bias;
+    p.mask = dm;
+    p.mask_shift = 6;
+    p.variant = variant;
+    if (kind == 1) {
+        p.Ys = ysp;
+        p.ys_slope = 0.1f;
+    } else {
+        p.Y = dy.p;
+        p.ldy = (int)C;
+        p.R = dr.p;
+        p.ldr = (int)C;
+        if (kind == 2) {
+            p.Ys = ysp;
+            p.ys_slope = 0.1f;
+        } else {
+            p.beta = 1.0f / 3.0f;
+            p.accumulate = 1;
+        }
+    }
+    SBV2_REQUIRE(conv_clx_usable(p), "conv_clx: shape");
+    const int64_t nwg = clx_grid_workgroups(p);
+    SBV2_REQUIRE(capacity_words >= 8 * nwg, "stamp buffer too small");
+    unsigned long long* d_st = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 8 * nwg));
+    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 8 * nwg));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    ConvClxParams pq = p;   // timed launches carry no stamps (the product kernel as the decoder runs it)
+    launch_conv_clx(pq, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 10; ++i) launch_conv_clx(pq, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t10 = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t10, e0, e1));
+    const int reps = std::max(10, (int)(seconds * 1e3 / std::max(t10 / 10.f, 1e-3f)));
+    for (int i = 0; i < reps; ++i) launch_conv_clx(pq, nullptr);
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 30; ++i) launch_conv_clx(pq, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    p.stamps = d_st;
+    launch_conv_clx(p, nullptr);
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t30 = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t30, e0, e1));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(stamps, d_st, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost));
+    (void)hipFree(d_st);
+    (void)hipFree(dm);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *workgroups = nwg;
+    *ms_per_launch = t30 / 30.0;
     API_END
 }
 

@@ -406,8 +406,10 @@ struct ConvClxParams {
     int accumulate = 0;         // Y += result
     const unsigned char* mask = nullptr;   // position n is kept iff mask[n >> mask_shift]
     int mask_shift = -1;
-    unsigned long long* stamps = nullptr;  // diagnostics: per workgroup {s_memtime, s_memrealtime} before / after the step loop
+    unsigned long long* stamps = nullptr;  // diagnostics: 8 words per workgroup (sbv2_debug_clx_timeline)
+    int variant = 0;            // diagnostics: kernel variant under test (0 = the product configuration)
 };
+int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv_clx starts for p
 bool conv_clx_usable(const ConvClxParams& p);
 bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
 int set_clx(int on);  // returns the previous setting

@@ -22,6 +22,10 @@
 
 #include "common.h"
 
+// No floating-point contraction in this file: the epilogue's (sum) * beta + previous contents must round like conv_cl's (two roundings), whatever shape
+// the surrounding control flow has (an fma there moved the waveform by 9e-7 against the conv_cl path)
+#pragma clang fp contract(off)
+
 namespace sbv2 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
 
+    const unsigned long long st_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostics only)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 3, wm = wave >> 2;
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         st_t0 = __builtin_amdgcn_s_memtime();
         st_r0 = __builtin_amdgcn_s_memrealtime();
     }
+    if (p.variant & 4) __builtin_amdgcn_s_setprio(2);   // (experiment) the step loop's instructions outrank the other workgroups' prologues / epilogues
     for (int chunk = 0; chunk < nchunks; chunk += 2) {
         // two chunks per iteration: NTAPS is odd, the fragment register sets ping-pong per step
         const int s0 = chunk * NTAPS;
@@ -313,9 +319,13 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     }
     if (p.stamps && tid == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
         o[0] = st_t0; o[1] = st_r0; o[2] = t1; o[3] = r1;
+        o[4] = st_entry;
+        // where this workgroup ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
+    if (p.variant & 4) __builtin_amdgcn_s_setprio(0);
     __syncthreads();   // the epilogue re-uses the rings as its transpose tiles
 
     // ---- k-major result (the flow's second FFN convolution: Y[m][n] = (conv + b + R[m][n]) * mask): one accumulator register of a half-wave
@@ -368,6 +378,87 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
     const int nfirst = n0 + wq * NPW + (lane >> 3);
     const float* trow = tile + (lane >> 3) * 36 + c4;
     const float sl = p.ys_slope;
+    // ---- interior tiles (every position and row of the tile exists; all but the batch's last tile): no per-lane conditions, and EVERY global read of both
+    // row tiles (mask bytes: one load per lane + a ballot, bias, residual rows) is requested before the first store.  Round 4's epilogue took 14 (conv1) to
+    // 22-30 us (conv2) of a workgroup's 34-85 us (profiles/r05a_clx_timeline.jsonl): sixteen mask-byte loads each followed by s_waitcnt vmcnt(0), the
+    // second row tile's loads queued behind the first one's stores (a load's data returns behind every older store's acknowledgement), and an
+    // s_waitcnt vmcnt(0) at the join behind every conditional store.
+    if (!(p.variant & 2) && n0 + NTW <= N) {
+        // lane (group g = lane >> 3, j = lane & 7) loads the flag of position nfirst + 8 j; bit 8 g + it of the ballot is this lane's flag of iteration it
+        unsigned mv = 1u;
+        if (p.mask) mv = p.mask[(nfirst + (lane & 7) * 8) >> p.mask_shift];
+        // two sets of 4 TN rows: the residual rows of both row tiles; or, for an accumulating launch (a branch's last step: 4 of a step's 36 launches),
+        // residual + previous contents of ONE row tile (the second tile's are requested behind the first one's stores)
+        f32x4v b4[2], ld[2][4 * TN];
+        const bool acc_y = p.accumulate != 0;
+        auto load_rows = [&](int set, const float* base, int ldb, int m) {
+            const float* rp = base + (int64_t)nfirst * ldb + m;
+#pragma unroll
+            for (int it = 0; it < 4 * TN; ++it) ld[set][it] = *reinterpret_cast<const f32x4v*>(rp + (int64_t)it * 8 * ldb);
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b4[i] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + m0 + i * 32 + c4) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (p.R) load_rows(0, p.R, p.ldr, m0 + c4);
+        if (acc_y) load_rows(1, p.Y, p.ldy, m0 + c4);
+        else if (p.R) load_rows(1, p.R, p.ldr, m0 + 32 + c4);
+        unsigned mbits = 0xFFu;
+        bool allkeep = true;
+        clx_static_for<0, 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *reinterpret_cast<f32x4v*>(tile + (j * 32 + lcol) * 36 + 8 * q + 4 * lh) = v;
+                }
+            if constexpr (i == 0) {
+                asm volatile("" : "+v"(mv));   // (the compare stays behind the LDS writes: hoisted to the load, it waits for the load there)
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(mv != 0);
+                allkeep = bal == ~0ull;
+                mbits = (unsigned)(bal >> ((lane >> 3) * 8)) & 0xFFu;
+            }
+            const int m = m0 + i * 32 + c4;
+            if constexpr (i == 1) {
+                if (acc_y) {
+                    if (p.R) load_rows(0, p.R, p.ldr, m);
+                    load_rows(1, p.Y, p.ldy, m);
+                }
+            }
+            float* yp = p.Y ? p.Y + (int64_t)nfirst * p.ldy + m : nullptr;
+            const int64_t ystep = (int64_t)8 * p.ldy;
+            char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nfirst) * 32 + (m & 15) * 2 : nullptr;
+#pragma unroll
+            for (int it = 0; it < 4 * TN; ++it) {
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
+                f32x4v v = a + b4[i];
+                if (p.R) v += acc_y ? ld[0][it] : ld[i][it];
+                v *= beta;   // (x 1.0f is exact: the generic path's test for beta != 1 changes no bit)
+                if (acc_y) v += ld[1][it];
+                if (!allkeep && !((mbits >> it) & 1u)) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (yp) *reinterpret_cast<f32x4v*>(yp + it * ystep) = v;
+                if (qs) {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[e] >= 0.f ? v[e] : v[e] * sl;
+                        h[e] = (__bf16)x;
+                        l[e] = (__bf16)(x - (float)h[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(qs + it * 256) = h;
+                    *reinterpret_cast<bf16x4*>(qs + it * 256 + yplane) = l;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (p.stamps && tid == 0) {
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+            o[5] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            o[6] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
     clx_static_for<0, 2>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -422,6 +513,12 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         }
         __builtin_amdgcn_sched_barrier(0);   // (the second row tile's loads stay behind this one's stores: hoisted, the two tiles' registers spill)
     });
+    if (p.stamps && tid == 0) {   // (diagnostics) last store issued / every store of this wave acknowledged
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        o[5] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        o[6] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- f32 channels-last plane -> chunk-major bf16 parts of lrelu(x) (a stage input; every other operand is written by an epilogue) ----------------
@@ -525,6 +622,8 @@ bool conv_clx_usable(const ConvClxParams& p) {
     return p.N >= 1 && p.X.N == p.N;
 }
 
+static thread_local int64_t* g_clx_grid_only = nullptr;   // clx_grid_workgroups: report the grid instead of launching
+
 template <int NTAPS, int WM, int WR, int XB, int XR = kClxXR, bool FRONT = false, int TN = 2>
 static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     constexpr int NTW = 128 * TN;
@@ -533,7 +632,11 @@ static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
     kp.gy = p.M / (64 * WM);
     static const int contig = getenv("SBV2_CLX_CONTIG") ? atoi(getenv("SBV2_CLX_CONTIG")) : 0;
-    kp.contig = contig;
+    kp.contig = contig || (p.variant & 1);
+    if (g_clx_grid_only) {
+        *g_clx_grid_only = (int64_t)round_up((p.N + NTW - 1) / NTW, 8) * kp.gy;
+        return;
+    }
     const size_t lds = std::max<size_t>((size_t)WR * (2 * WM * 2 * 1024) + (size_t)XB * 2 * XR * 32, (size_t)4 * WM * 32 * TN * 36 * sizeof(float));
     auto kern = conv_clx_kernel<NTAPS, WM, WR, XB, XR, FRONT, TN>;
     static std::atomic<uint64_t> lds_allowed{0};
@@ -554,10 +657,25 @@ static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
     }
 }
 
+int64_t clx_grid_workgroups(const ConvClxParams& p) {
+    int64_t g = 0;
+    g_clx_grid_only = &g;
+    try {
+        launch_conv_clx(p, nullptr);
+    } catch (...) {
+        g_clx_grid_only = nullptr;
+        throw;
+    }
+    g_clx_grid_only = nullptr;
+    return g;
+}
+
 void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     SBV2_REQUIRE(conv_clx_usable(p), "conv_clx: operands do not fit the pre-split channels-last kernel");
     ClxKernelParams kp;
     kp.p = p;
+    static const int env_variant = getenv("SBV2_CLX_VARIANT") ? atoi(getenv("SBV2_CLX_VARIANT")) : 0;   // (round-5 experiments; see ConvClxParams::variant)
+    kp.p.variant |= env_variant;
     const int step = p.shift_step;
     const int smin = step >= 0 ? p.shift0 : p.shift0 + (p.ntaps - 1) * step;
     const int smax = step >= 0 ? p.shift0 + (p.ntaps - 1) * step : p.shift0;
