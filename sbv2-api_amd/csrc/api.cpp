@@ -486,7 +486,7 @@ int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const floa
     split_cl(dx.p, (int)cin, L, (int)cin, pre_slope, xs, nullptr);
     ConvClxParams p;
     p.X = xs;
-    p.W = c.w;
+    p.W = c.wx;
     p.nmt = c.nmt;
     p.M = (int)cout;
     p.N = (int)L;
@@ -591,7 +591,7 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
         SplitClPlanes xs = make_split_cl(dxs.p, (int)C, L, nullptr);
         split_cl(dx.p, (int)C, L, (int)C, 0.1f, xs, nullptr);
         px.X = xs;
-        px.W = c.w;
+        px.W = c.wx;
         px.nmt = c.nmt;
         px.M = (int)C;
         px.N = (int)L;
@@ -694,7 +694,7 @@ int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, 
     HIP_CHECK(hipMemset(dm, 1, nm));
     ConvClxParams p;
     p.X = xs;
-    p.W = c.w;
+    p.W = c.wx;
     p.nmt = c.nmt;
     p.M = (int)C;
     p.N = (int)L;

@@ -76,7 +76,31 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
             }
     c.w = ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
     if (bias) c.bias = ws.upload(bias, (size_t)M);
+    if (c.parts == 2 && (M & 63) == 0 && (K & 31) == 0) c.wx = pack_clx16(ws, w, M, K, k);   // the shapes conv_clx.hip takes
     return c;
+}
+
+// The same split-bf16 weights as A fragments of v_mfma_f32_16x16x32_bf16 whose 32-deep K dimension carries [hi | lo] of one 16-channel chunk (conv_clx.hip):
+// 1 KB blocks [chunk][row tile of 64][tap][row tile of 16], lane l of a block (row l & 15, k group g = l >> 4) holds
+// hi (g < 2) or lo (g >= 2) of W[m = 64 mt + 16 rt + (l & 15)][k = 16 chunk + 8 (g & 1) + j][tap], j = 0 .. 7.
+void* pack_clx16(WeightStore& ws, const float* w, int M, int K, int k) {
+    const int nchunks = K / 16, nmt = M / 64;
+    std::vector<uint16_t> h((size_t)nchunks * nmt * k * 4 * 512, 0);
+    for (int ch = 0; ch < nchunks; ++ch)
+        for (int mt = 0; mt < nmt; ++mt)
+            for (int t = 0; t < k; ++t)
+                for (int rt = 0; rt < 4; ++rt) {
+                    uint16_t* blk = h.data() + ((((size_t)ch * nmt + mt) * k + t) * 4 + rt) * 512;
+                    for (int l = 0; l < 64; ++l) {
+                        const int m = mt * 64 + rt * 16 + (l & 15), g = l >> 4;
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = w[((size_t)m * K + ch * 16 + 8 * (g & 1) + j) * k + t];
+                            const uint16_t hi = f32_to_bf16_rne(v);
+                            blk[l * 8 + j] = g < 2 ? hi : f32_to_bf16_rne(v - bf16_to_f32(hi));
+                        }
+                    }
+                }
+    return ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
 }
 
 // 16 -> 16 channel convolution as A fragments of v_mfma_f32_16x16x32_bf16 whose 32-deep K dimension carries two taps: block (pair tp, part), lane l
@@ -98,19 +122,40 @@ void* pack_cl_pairs(WeightStore& ws, const float* w, int k) {
     return ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
 }
 
+// pack_cl's precision code of a decoder arithmetic (dec_mode_ / ClStage::mode)
+static int cl_parts_of(int mode) { return mode == 1 ? 2 : (mode == 2 ? 1 : 3); }
+
 void VitsModel::load_decoder_cl(const Blob& blob) {
-    auto conv = [&](const std::string& prefix) {
+    auto conv = [&](const std::string& prefix, int mode) {
         const HostTensor& t = blob.get(prefix + ".weight");
         const float* b = blob.has(prefix + ".bias") ? blob.get(prefix + ".bias").data : nullptr;
-        ClConv c = pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], dec_mode_ == 1 ? 2 : (dec_mode_ == 2 ? 1 : 3), b);
-        if (dec_mode_ == 1 && t.dims[0] == 16 && t.dims[1] == 16) c.wp = pack_cl_pairs(*ws_, t.data, (int)t.dims[2]);
+        ClConv c = pack_cl(*ws_, t.data, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2], cl_parts_of(mode), b);
+        if (mode == 1 && t.dims[0] == 16 && t.dims[1] == 16) c.wp = pack_cl_pairs(*ws_, t.data, (int)t.dims[2]);
         return c;
     };
-    cl_pre_ = conv("dec.conv_pre");
+    // SBV2_DECODER_STAGES = one arithmetic per upsampling stage ("f16,f16,bf16x3,bf16x3,bf16x3"): the per-stage precision map of profiles/r05_precision_map.json.
+    // An experiment knob: the default is SBV2_DECODER's arithmetic for every stage.
+    std::vector<int> stage_mode(cfg_.up_rates.size(), dec_mode_);
+    if (const char* e = getenv("SBV2_DECODER_STAGES")) {
+        std::string v(e);
+        size_t pos = 0;
+        for (size_t i = 0; i < stage_mode.size() && pos <= v.size(); ++i) {
+            const size_t q = v.find(',', pos);
+            const std::string tok = v.substr(pos, q == std::string::npos ? std::string::npos : q - pos);
+            if (tok == "bf16x3") stage_mode[i] = 1;
+            else if (tok == "bf16") stage_mode[i] = 2;
+            else if (tok == "f16") stage_mode[i] = 3;
+            else SBV2_REQUIRE(tok.empty(), "SBV2_DECODER_STAGES: bf16x3, bf16 or f16 per stage");
+            if (q == std::string::npos) break;
+            pos = q + 1;
+        }
+    }
+    cl_pre_ = conv("dec.conv_pre", dec_mode_);
     int C = cfg_.up_initial;
     const int nk = (int)cfg_.res_kernels.size();
     for (size_t i = 0; i < cfg_.up_rates.size(); ++i) {
         ClStage st;
+        st.mode = stage_mode[i];
         st.rate = cfg_.up_rates[i];
         st.cin = C;
         C /= 2;
@@ -150,7 +195,7 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
                 }
             for (int ti = 0; ti < g.ntaps; ++ti) g.shift[ti] = -tsets[r][ti];
             for (int pi = 0; pi < kMaxPhases; ++pi) g.phase_off[pi] = pi < g.nph ? phases[pi] : 0;
-            g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, dec_mode_ == 1 ? 2 : (dec_mode_ == 2 ? 1 : 3), bias.data());
+            g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, cl_parts_of(st.mode), bias.data());
             st.up.push_back(g);
         }
         for (int j = 0; j < nk; ++j) {
@@ -159,8 +204,8 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
             rb.dil = cfg_.res_dilations[j];
             const std::string p = "dec.resblocks." + std::to_string(i * nk + j) + ".";
             for (size_t n = 0; n < rb.dil.size(); ++n) {
-                rb.c1.push_back(conv(p + "convs1." + std::to_string(n)));
-                rb.c2.push_back(conv(p + "convs2." + std::to_string(n)));
+                rb.c1.push_back(conv(p + "convs1." + std::to_string(n), st.mode));
+                rb.c2.push_back(conv(p + "convs2." + std::to_string(n), st.mode));
             }
             st.branches.push_back(rb);
         }
@@ -190,8 +235,8 @@ void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float*
     p.W = c.w;
     p.nmt = c.nmt;
     p.tm = c.tm;
-    p.split = dec_mode_ == 1;
-    p.f16 = dec_mode_ == 3;
+    p.split = c.parts == 2;   // (the arithmetic the weights were packed for)
+    p.f16 = c.parts == 3;
     p.M = c.M;
     p.N = N;
     p.K = c.K;
@@ -243,10 +288,10 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         // (large launches only: a single utterance or a streaming window has too few tiles to pay for the extra split / halo launches; the two
         // paths give the same bits, so the choice is free)
         static const int clx_min_c = getenv("SBV2_CLX_MINC") ? atoi(getenv("SBV2_CLX_MINC")) : 128;   // A/B knob
-        bool clx = clx_enabled() && dec_mode_ == 1 && C >= clx_min_c && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
+        bool clx = clx_enabled() && st.mode == 1 && C >= clx_min_c && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
         for (int j = 0; j < nk && clx; ++j) {
             const ClBranch& rb = st.branches[j];
-            if (!(rb.k == 3 || rb.k == 7 || rb.k == 11)) clx = false;
+            if (!(rb.k == 3 || rb.k == 7 || rb.k == 11) || !rb.c1[0].wx) clx = false;
             for (int d : rb.dil)
                 if (d * (rb.k - 1) > 64 || d * (rb.k - 1) / 2 > kClxFront) clx = false;
         }
@@ -270,8 +315,8 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             p.W = g.c.w;
             p.nmt = g.c.nmt;
             p.tm = g.c.tm;
-            p.split = dec_mode_ == 1;
-            p.f16 = dec_mode_ == 3;
+            p.split = st.mode == 1;
+            p.f16 = st.mode == 3;
             p.M = g.c.M;
             p.N = (int)Lcur;
             p.K = st.cin;
@@ -310,7 +355,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                 if (clx) {
                     ConvClxParams p1;
                     p1.X = *ys;
-                    p1.W = rb.c1[q].w;
+                    p1.W = rb.c1[q].wx;
                     p1.nmt = rb.c1[q].nmt;
                     p1.M = C;
                     p1.N = (int)Lo;
@@ -326,7 +371,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                     launch_conv_clx(p1, stream_);
                     ConvClxParams p2;
                     p2.X = T1s;
-                    p2.W = rb.c2[q].w;
+                    p2.W = rb.c2[q].wx;
                     p2.nmt = rb.c2[q].nmt;
                     p2.M = C;
                     p2.N = (int)Lo;
@@ -368,8 +413,8 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                     rp.N = (int)Lo;
                     rp.k = rb.k;
                     rp.dil = d;
-                    rp.split = dec_mode_ == 1;
-                    rp.f16 = dec_mode_ == 3;
+                    rp.split = st.mode == 1;
+                    rp.f16 = st.mode == 3;
                     rp.slope = 0.1f;
                     rp.beta = last ? 1.0f / nk : 1.0f;
                     rp.accumulate = last && j > 0;

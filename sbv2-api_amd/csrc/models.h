@@ -11,6 +11,7 @@ namespace sbv2 {
 // A convolution packed for conv_cl.hip (bf16 MFMA fragment blocks); parts = 2 keeps a bf16 hi and a bf16 lo copy.
 struct ClConv {
     void* w = nullptr;
+    void* wx = nullptr;    // split-bf16, M % 64 == 0, K % 32 == 0: the same weights as [hi | lo] fragments of the 16x16x32 MFMA (pack_clx16; conv_clx.hip), else null
     void* wp = nullptr;    // 16 x 16 convolutions of the fused ResBlock step: tap-pair fragments [pair][part][64 lanes][8] (pack_cl_pairs), else null
     float* bias = nullptr;
     int M = 0, K = 0, k = 1, nmt = 0, tm = 1, parts = 0;
@@ -59,6 +60,7 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
 class WeightStore;
 // w is [M][K][k] (Conv1d layout); K is zero-padded to a multiple of 16
 ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
+void* pack_clx16(WeightStore& ws, const float* w, int M, int K, int k);
 void* pack_cl_pairs(WeightStore& ws, const float* w, int k);   // w [16][16][k] -> tap-pair fragments (split-bf16) for respair_clx's 16-channel kernel
 // w is [M][K] (Linear / 1x1 conv): bf16 parts (2 = hi + lo, 3 = hi + mid + lo) as MFMA A fragments; K must be a multiple of 16
 BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts);
@@ -292,6 +294,7 @@ class VitsModel {
         std::vector<ClUpGroup> up;
         std::vector<ClBranch> branches;
         int cin, ch, rate;
+        int mode = 1;   // the stage's arithmetic (dec_mode_ codes 1 .. 3; SBV2_DECODER_STAGES)
     };
     void load_decoder_cl(const Blob& blob);
     void run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const float* cond_vec);

@@ -466,7 +466,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             split_cl_km(x, 1.0f, XsC, stream_);
             ConvClxParams p1;
             p1.X = XsC;
-            p1.W = L.ffn1.cl.w;
+            p1.W = L.ffn1.cl.wx;
             p1.nmt = L.ffn1.cl.nmt;
             p1.M = Fc;
             p1.N = N;
@@ -482,7 +482,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
             launch_conv_clx(p1, stream_);
             ConvClxParams p2;
             p2.X = FsC;
-            p2.W = L.ffn2.cl.w;
+            p2.W = L.ffn2.cl.wx;
             p2.nmt = L.ffn2.cl.nmt;
             p2.M = H;
             p2.N = N;

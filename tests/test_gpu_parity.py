@@ -45,10 +45,11 @@ def test_conv1d_kernel(cin, cout, k, dil, L):
 
 @pytest.mark.parametrize("C,k,dil,L", [(128, 3, 1, 700), (128, 7, 3, 1500), (128, 11, 5, 1030), (256, 7, 1, 515), (256, 11, 3, 300), (256, 3, 5, 257),
                                        (128, 7, 5, 256), (128, 11, 1, 8200)])
-def test_conv1d_clx_kernel_same_bits_as_conv_cl(C, k, dil, L):
-    """conv_clx.hip (pre-split operands, LDS-DMA rings, one barrier per tap) gives the SAME bits as conv_cl.hip's split-bf16 path: same
-    fragments, same MFMA order.  Also with a residual and beta, and the bf16 parts of lrelu(result) it emits for the next convolution
-    are exactly the split conv_cl would compute while staging."""
+def test_conv1d_clx_kernel_agrees_with_conv_cl(C, k, dil, L):
+    """conv_clx.hip (pre-split operands, LDS-DMA rings, v_mfma_f32_16x16x32_bf16 with both cross terms of the split in one instruction) against conv_cl.hip's
+    split-bf16 path (32x32x16, lo*hi, hi*lo, hi*hi per tap): the same products in another summation order, so f32-rounding apart (1e-5), not bit for bit
+    (rounds 3-4 ran both on one MFMA shape and held them bit-equal; round 5 moved conv_clx to the shape the chip sustains at a higher clock).  Also with a
+    residual and beta, and the bf16 parts of lrelu(result) it emits for the next convolution are the split of its own f32 result."""
     rng = np.random.default_rng(C + k + dil + L)
     x = rng.standard_normal((C, L)).astype(np.float32)
     w = (rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
@@ -60,13 +61,13 @@ def test_conv1d_clx_kernel_same_bits_as_conv_cl(C, k, dil, L):
     _lib.check(lib.sbv2_debug_conv1d_cl(0, P(x), P(w), P(b), C, C, k, L, dil, 0.1, 1, 0, P(ref), None))
     got, ys = np.empty((C, L), np.float32), np.empty((C, L), np.float32)
     _lib.check(lib.sbv2_debug_conv1d_clx(0, P(x), P(w), P(b), None, C, C, k, L, dil, 0.1, 1.0, 0, P(got), P(ys), None))
-    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_allclose(got, ref, atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(got, O.conv1d_same(O.leaky_relu(x, 0.1), w, b, dil), atol=3e-5, rtol=1e-5)
-    lr = np.where(ref >= 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    lr = np.where(got >= 0, got, got * np.float32(0.1)).astype(np.float32)
     assert float(np.abs(ys - lr).max()) <= 2.0 ** -16 * float(np.abs(lr).max())
     got2 = np.empty((C, L), np.float32)
     _lib.check(lib.sbv2_debug_conv1d_clx(0, P(x), P(w), P(b), P(r), C, C, k, L, dil, 0.1, 1.0 / 3, 0, P(got2), None, None))
-    np.testing.assert_array_equal(got2, ((ref + r) * np.float32(1.0 / 3)).astype(np.float32))
+    np.testing.assert_array_equal(got2, ((got + r) * np.float32(1.0 / 3)).astype(np.float32))   # (the epilogue's arithmetic on the kernel's own sum: exact)
 
 
 def _respair(x, w1, w2, b1, b2, k, dil, mask, mask_div, beta, prev, variant):
@@ -485,9 +486,10 @@ def test_vits_full_small_utterance():
     s.close()
 
 
-def test_decoder_clx_path_same_bits_as_conv_cl_path():
-    """Full JP-Extra shape: the wide decoder stages on conv_clx.hip (pre-split operands written by the producing epilogues, LDS-DMA rings:
-    the default) against the same stages on conv_cl.hip (sbv2_debug_set_clx(0)): every sample of a mixed batch identical, bit for bit."""
+def test_decoder_clx_path_agrees_with_conv_cl_path():
+    """Full JP-Extra shape: the wide decoder stages on conv_clx.hip (pre-split operands written by the producing epilogues, LDS-DMA rings, 16x16x32 MFMAs:
+    the default for large launches) against the same stages on conv_cl.hip (sbv2_debug_set_clx(0); what a single utterance and a streaming window run): the
+    same products in another summation order.  The waveforms (peak ~0.1) agree to 2e-6; the oracle tolerance of the decoder tests is 5e-5."""
     cfg, W = weights("vits", "full")
     s = model.load_model(blob("vits", "full"), False)
     utts = make_utts([12, 31, 5], O.DEBERTA_FULL, cfg, seed0=77)
@@ -500,7 +502,7 @@ def test_decoder_clx_path_same_bits_as_conv_cl_path():
     finally:
         lib.sbv2_debug_set_clx(prev)
     for x, y in zip(a, b):
-        np.testing.assert_array_equal(x, y)
+        np.testing.assert_allclose(x, y, atol=2e-6, rtol=0)
     s.close()
 
 
@@ -688,7 +690,10 @@ def test_config1_b1_u128_fp32_full_path():
 
 def test_config2_b32_u128_default_path():
     """BASELINE configs[2] (the bench workload): batch 32 x 128 phonemes, default arithmetic (split-bf16 MFMA decoder).  Every one of the
-    32 waveforms: length, finiteness, |x| < 1 and BIT-equality with a batch-1 call of the same utterance; two of them vs the oracle."""
+    32 waveforms: length, finiteness, |x| < 1 and agreement with a batch-1 call of the same utterance; two of them vs the oracle, all 32 vs the C oracle.
+    Batch row vs single call: since round 5 the wide decoder stages of a LARGE launch run on conv_clx.hip's 16x16x32 MFMAs (another summation order than
+    conv_cl.hip's, which small launches keep): the two agree to f32 rounding (measured 1.9e-6 on these 0.1-peak waveforms; tolerance 5e-6), and bit for
+    bit when the batch is kept on conv_cl too (sbv2_debug_set_clx(0): the rounds 1-4 invariant, still held on that path)."""
     bc, bw = weights("bert", "full")
     vc, vw = weights("vits", "full")
     bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
@@ -698,11 +703,24 @@ def test_config2_b32_u128_default_path():
     pipe.run(b)
     pcms = pipe.fetch(b)
     assert len(pcms) == 32
+    lib = _lib.lib()
+    prev = lib.sbv2_debug_set_clx(0)
+    try:
+        b0 = pipe.prepare(utts, forced=True)
+        pipe.run(b0)
+        pcms_cl = pipe.fetch(b0)
+    finally:
+        lib.sbv2_debug_set_clx(prev)
+    worst_row = 0.0
     for i, (u, got) in enumerate(zip(utts, pcms)):
         assert got.shape == (512 * 897,) and np.isfinite(got).all() and np.abs(got).max() < 1.0
         b1 = pipe.prepare([u], forced=True)
         pipe.run(b1)
-        np.testing.assert_array_equal(pipe.fetch(b1)[0], got)
+        single = pipe.fetch(b1)[0]
+        np.testing.assert_array_equal(single, pcms_cl[i])
+        worst_row = max(worst_row, float(np.abs(single - got).max()))
+    print(f"configs[2]: batch row (conv_clx) vs single call (conv_cl), worst max-abs {worst_row:.3e}")
+    assert worst_row < 5e-6
     O.set_conv_backend("torch")
     try:
         for i in (0, 17):
@@ -868,7 +886,7 @@ def test_config3_b256_mixed_lengths_sharded_8_ways():
     """BASELINE configs[3]: batch 256 of mixed 32..512-phoneme utterances, utterance-sharded 8 ways.  One GPU is all a test box has, so the
     eight shards run on eight execution contexts of that GPU (the library's deal, threads, gather and permutation are the ones an 8-GPU
     node uses; only ncclSend / ncclRecv are replaced by device-to-device copies).  Every utterance: length and finiteness; 6 of them
-    bit-equal to a batch-1 call; 2 of them vs the oracle."""
+    against a batch-1 call (5e-6); 2 of them vs the oracle."""
     bc, bw = weights("bert", "full")
     vc, vw = weights("vits", "full")
     bb, vb = blob("bert", "full"), blob("vits", "full")
@@ -889,10 +907,10 @@ def test_config3_b256_mixed_lengths_sharded_8_ways():
         assert np.isfinite(g).all() and np.abs(g).max() < 1.0
     bs, vs = model.load_model(bb, True), model.load_model(vb, False)
     pipe = model.Pipeline(bs, vs)
-    for i in (0, 5, 77, 100, 200, 255):
+    for i in (0, 5, 77, 100, 200, 255):   # (shard rows on conv_clx's 16x16x32 MFMAs vs single calls on conv_cl: f32 rounding apart, see test_config2)
         b1 = pipe.prepare([utts[i]], forced=True)
         pipe.run(b1)
-        np.testing.assert_array_equal(pipe.fetch(b1)[0], got[i])
+        np.testing.assert_allclose(pipe.fetch(b1)[0], got[i], atol=5e-6, rtol=0)
     O.set_conv_backend("torch")
     try:
         for i in (5, int(np.argmin(np.abs(np.array(ns) - 128)))):
