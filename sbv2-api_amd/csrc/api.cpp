@@ -606,8 +606,8 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
         nwg *= 2;   // (64-row workgroups at most)
     }
     unsigned long long* d_st = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 8 * nwg));
-    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 8 * nwg));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * kClxStampWords * nwg));
+    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * kClxStampWords * nwg));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -633,14 +633,14 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
     HIP_CHECK(hipEventSynchronize(e1));
     float t50 = 0.f;
     HIP_CHECK(hipEventElapsedTime(&t50, e0, e1));
-    std::vector<unsigned long long> hs((size_t)8 * nwg);
+    std::vector<unsigned long long> hs((size_t)kClxStampWords * nwg);
     HIP_CHECK(hipMemcpy(hs.data(), d_st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
     (void)hipFree(d_st);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     std::vector<double> mhz, cyc;
     for (int g = 0; g < nwg; ++g) {
-        const int sg = abl == 10 ? 8 * g : 4 * g;   // (conv_clx keeps 8 words per workgroup)
+        const int sg = abl == 10 ? kClxStampWords * g : 4 * g;   // (conv_clx keeps kClxStampWords per workgroup)
         const unsigned long long t0 = hs[sg], r0 = hs[sg + 1], t1 = hs[sg + 2], r1 = hs[sg + 3];
         if (r1 > r0 && t1 > t0) {
             mhz.push_back((double)(t1 - t0) / (double)(r1 - r0) * 100.0);
@@ -659,8 +659,9 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
 
 // Diagnostics: where a conv_clx workgroup's life goes.  Launches the ResBlock convolution of a wide decoder stage in the form the decoder launches it
 // (kind 1 = conv1: parts in, parts out; 2 = conv2: parts in, residual in, f32 + parts out; 3 = a branch's last conv2: residual + accumulate, f32 out)
-// back to back for `seconds`, then returns the stamps of the last launch: 8 words per workgroup {loop start (shader clock), loop start (100 MHz),
-// loop end (shader clock), loop end (100 MHz), kernel entry (100 MHz), last store issued, stores acknowledged, HW_ID | XCC_ID << 32}.
+// back to back for `seconds`, then returns the stamps of the last launch: 12 words per workgroup {loop start (shader clock), loop start (100 MHz),
+// loop end (shader clock), loop end (100 MHz), kernel entry (100 MHz), last store issued, stores acknowledged, HW_ID | XCC_ID << 32, epilogue: behind
+// the post-loop barrier, its global reads arrived, the first half's stores issued (100 MHz), 0}.
 int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int kind, int variant, double seconds, uint64_t* stamps,
                             int64_t capacity_words, int64_t* workgroups, double* ms_per_launch) {
     API_BEGIN
@@ -724,10 +725,10 @@ int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, 
     }
     SBV2_REQUIRE(conv_clx_usable(p), "conv_clx: shape");
     const int64_t nwg = clx_grid_workgroups(p);
-    SBV2_REQUIRE(capacity_words >= 8 * nwg, "stamp buffer too small");
+    SBV2_REQUIRE(capacity_words >= kClxStampWords * nwg, "stamp buffer too small");
     unsigned long long* d_st = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 8 * nwg));
-    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * 8 * nwg));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * kClxStampWords * nwg));
+    HIP_CHECK(hipMemset(d_st, 0, sizeof(unsigned long long) * kClxStampWords * nwg));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -751,7 +752,7 @@ int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, 
     float t30 = 0.f;
     HIP_CHECK(hipEventElapsedTime(&t30, e0, e1));
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemcpy(stamps, d_st, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(stamps, d_st, sizeof(unsigned long long) * kClxStampWords * nwg, hipMemcpyDeviceToHost));
     (void)hipFree(d_st);
     (void)hipFree(dm);
     (void)hipEventDestroy(e0);

@@ -373,6 +373,7 @@ __device__ __forceinline__ void split_store1(const SplitPlanes& sp, int64_t off,
 // ---------------------------------------------------------------------------------------------
 // conv_clx.hip: the ResBlock convolutions of the wide decoder stages on pre-split, pre-activated operands (LDS-DMA only, no staging registers)
 // ---------------------------------------------------------------------------------------------
+constexpr int kClxStampWords = 12;   // sbv2_debug_clx_timeline: words per workgroup
 constexpr int kClxFront = 64;    // zero rows in front of every (chunk, part) plane: the left zero padding of the first tile's window
 constexpr int kClxBack = 384;    // ... and behind it: right padding + the last position tile's overhang + DMA piece rounding
 struct SplitClPlanes {           // bf16 hi / lo of a channels-last activation, chunk-major: [C / 16][2 parts][front + N + back][16] bf16
@@ -406,7 +407,7 @@ struct ConvClxParams {
     int accumulate = 0;         // Y += result
     const unsigned char* mask = nullptr;   // position n is kept iff mask[n >> mask_shift]
     int mask_shift = -1;
-    unsigned long long* stamps = nullptr;  // diagnostics: 8 words per workgroup (sbv2_debug_clx_timeline)
+    unsigned long long* stamps = nullptr;  // diagnostics: kClxStampWords per workgroup (sbv2_debug_clx_timeline)
     int variant = 0;            // diagnostics: kernel variant under test (0 = the product configuration)
 };
 int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv_clx starts for p

@@ -33,6 +33,12 @@
 // control flow has (an fma there moved the waveform by 9e-7 between two epilogue variants that promise the same bits)
 #pragma clang fp contract(off)
 
+// CLX_ABL (diagnostic builds only, tests/clx_ablate.sh; results WRONG for 1-3): 1 = the weight waves do not wait for their DMAs at a pair's TOP, 2 = no
+// v_permlane32_swap (M2 takes a's M1 fragments), 3 = both and the window waves never wait, 4 = M2's B fragments requested in M1(b)'s first gaps
+#ifndef CLX_ABL
+#define CLX_ABL 0
+#endif
+
 namespace sbv2 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -85,6 +91,10 @@ __device__ __forceinline__ bf16x8 clx_read_b128o(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
     return v;
 }
+__device__ __forceinline__ unsigned clx_opaque(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ void clx_mfma16(f32x4v& c, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
@@ -104,7 +114,10 @@ __device__ __forceinline__ void clx_halves(const bf16x8& a, const bf16x8& b, bf1
 
 // 4 waves, 64 rows x 256 positions per workgroup (wave: 64 rows x 64 positions = 4 x 4 accumulator tiles of 16 x 16); kClxWR weight ring slots (4 KB: one
 // step), kClxXB window buffers of XR rows (both parts).  <= 53 KB of LDS and <= 168 registers: THREE workgroups per CU.
-template <int NTAPS, int kClxWR, int kClxXB, int XR>
+// EDGE: the launch has a partial last position tile (N % 256 != 0): its guarded epilogue is compiled in.  (Compiled into every instance, that rarely taken
+// path set the register allocation of the whole kernel and the interior epilogue spilled in the middle of its load burst; the decoder's frame layout is
+// rounded so that the wide stages' planes are whole tiles.)
+template <int NTAPS, int kClxWR, int kClxXB, int XR, bool EDGE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
     constexpr int NPW = 64;                    // positions per wave
     constexpr int NTW = 256;                   // positions per workgroup
@@ -260,13 +273,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
             constexpr int tapa = ra % NTAPS, bufa = (ra / NTAPS) & 1, tapb = rb % NTAPS, bufb = (rb / NTAPS) & 1, tapn = rn % NTAPS, bufn = (rn / NTAPS) & 1;
             // ---- TOP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (wwave) clx_wait_vm<0>();
-            else if constexpr (j == J0 || j == NTAPS - 1) clx_wait_vm<0>();
+            if (wwave) {
+                if (CLX_ABL != 1 && CLX_ABL != 3) clx_wait_vm<0>();
+            } else if constexpr (j == J0 || j == NTAPS - 1) {
+                if (CLX_ABL != 3) clx_wait_vm<0>();
+            }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // ---- M1(a); fragments of b
             {
-                const unsigned aaddr = abase + wroff, b0 = blane + (unsigned)(tapb * shs32 + bufb * XBUF);
+                // (fragment addresses are formed where they are used, from an opaque copy of the lane base: hoisted out of the loop - they are loop
+                // invariant, three per pair - they took up to 33 registers and came back as scratch reloads + s_waitcnt vmcnt(0) between the MFMAs)
+                const unsigned aaddr = abase + wroff, b0 = clx_opaque(blane) + (unsigned)(tapb * shs32 + bufb * XBUF);
                 wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
                 const bool w3 = wwave && s0 + 2 * j + 3 < S, w4 = wwave && s0 + 2 * j + 4 < S;
                 clx_static_for<0, 16>([&](auto nc) {
@@ -293,11 +311,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                 // B operand of the pair's hi x hi product [X_hi(a) ; X_hi(b)]: k groups 0, 1 read the hi plane at tap a, 2, 3 at tap b (four more fragment
                 // reads per pair, into the registers of a's B fragments: swapped out of the M1 fragments like the A operand, they cost 16 more
                 // v_permlane32_swap per pair, and the pair's 32 swaps were a fifth of the loop's cycles)
-                const unsigned bh0 = bhlane + (unsigned)(lg < 2 ? tapa * shs32 + bufa * XBUF : tapb * shs32 + bufb * XBUF);
+                const unsigned bh0 = clx_opaque(bhlane) + (unsigned)(lg < 2 ? tapa * shs32 + bufa * XBUF : tapb * shs32 + bufb * XBUF);
                 clx_static_for<0, 16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     mfma_one(fo.a, fo.b, nc);
-                    if constexpr (j != J0 && n >= 10 && n < 14) hb[n - 10] = clx_read_b128o<(n - 10) * 512>(bh0);
+                    constexpr int HB0 = CLX_ABL == 4 ? 0 : 10;
+                    if constexpr (j != J0 && n >= HB0 && n < HB0 + 4) hb[n - HB0] = clx_read_b128o<(n - HB0) * 512>(bh0);
                     if constexpr (j < NTAPS - 1 && n < PPP) {
                         constexpr int i = jj * PPP + n;
                         if constexpr (i < kClxPW) {
@@ -313,19 +332,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
             // ---- A operand of the pair's hi x hi product [W_hi(a) | W_hi(b)]: the low halves of both M1 fragments (one v_permlane32_swap per register)
             bf16x8 ha[4], dump;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) clx_halves(fe.a[i], fo.a[i], ha[i], dump);
-            if constexpr (j == J0) {
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (CLX_ABL == 2 || CLX_ABL == 3) ha[i] = fe.a[i];
+                else clx_halves(fe.a[i], fo.a[i], ha[i], dump);
+            }
+            if constexpr (j == J0 && CLX_ABL != 2 && CLX_ABL != 3) {
                 // (the pair that spans the chunk boundary: window `chunk` is being overwritten by window chunk + 2 since this pair's TOP, so its B operand
                 // comes out of the M1 fragments, which were read before)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) clx_halves(fe.b[i], fo.b[i], dump, hb[i]);
+            }
+            if constexpr (j == J0 && (CLX_ABL == 2 || CLX_ABL == 3)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hb[i] = fo.b[i];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // hb
             __builtin_amdgcn_sched_barrier(0);
             // ---- M2; fragments of the next pair's a (unconditional, also behind the last step, where they fetch a ring slot nobody uses: a conditional
             // read would keep the old contents of `fe` alive across the swaps, and every swap would first copy its operand)
             {
-                const unsigned aaddr = abase + wroff, b0 = blane + (unsigned)(tapn * shs32 + bufn * XBUF);
+                const unsigned aaddr = abase + wroff, b0 = clx_opaque(blane) + (unsigned)(tapn * shs32 + bufn * XBUF);
                 wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
                 clx_static_for<0, 16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
@@ -338,13 +364,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     }
     if (p.stamps && tid == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * kClxStampWords;
         o[0] = st_t0; o[1] = st_r0; o[2] = t1; o[3] = r1;
         o[4] = st_entry;
         // where this workgroup ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
     __syncthreads();   // the epilogue re-uses the rings as its transpose tiles
+    unsigned long long st_e0 = 0, st_e1 = 0, st_e2 = 0;   // (diagnostics) behind the barrier / mask + bias + residual rows arrived / first half's stores issued
+    if (p.stamps) st_e0 = __builtin_amdgcn_s_memrealtime();
 
     // accumulator tile [it][jt]: lane (column l16 = position 16 jt + l16 of the wave's 64, row group lg) holds rows 16 it + 4 lg .. + 3
     // ---- k-major result (the flow's second FFN convolution: Y[m][n] = (conv + b + R[m][n]) * mask): one accumulator register of a 16-lane group is 16
@@ -407,114 +435,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     // halves (mask bytes: one load per lane + a ballot, bias, residual rows) is requested before the first store.  Round 4's epilogue took 14 (conv1) to
     // 22-30 us (conv2) of a workgroup's 34-85 us (profiles/r05a_clx_timeline_before.jsonl): sixteen mask-byte loads each followed by s_waitcnt vmcnt(0),
     // the second half's loads queued behind the first one's stores (a load's data returns behind every older store's acknowledgement), and an
-    // s_waitcnt vmcnt(0) at the join behind every conditional store.
-    if (n0 + NTW <= N) {
-        // lane (group g = lane >> 3, j = lane & 7) loads the flag of position nfirst + 8 j; bit 8 g + it of the ballot is this lane's flag of iteration it
+    // s_waitcnt vmcnt(0) at the join behind every conditional store.  A lane owns EIGHT channels of a position (4 lanes per 128-byte line, 16 positions per
+    // iteration): its bf16 parts are one 16-byte store per part instead of two 8-byte ones (the store tail is bound by the number of store instructions:
+    // with the step loop 15 % shorter the epilogue of the same bytes got 25 % LONGER, profiles/r05j_clx_ablate.txt).
+    if (!EDGE || n0 + NTW <= N) {
+        const int c8 = (lane & 3) * 8;
+        const int nf16 = n0 + wq * NPW + (lane >> 2);
+        const float* trow8 = tile + (lane >> 2) * 36 + c8;
+        // lane (group g = lane >> 2, j = lane & 3) loads the flag of position nf16 + 16 j; bit 4 g + it of the ballot is this lane's flag of iteration it
         unsigned mv = 1u;
-        if (p.mask) mv = p.mask[(nfirst + (lane & 7) * 8) >> p.mask_shift];
-        // two sets of 8 rows: the residual rows of both halves; or, for an accumulating launch (a branch's last step: 4 of a step's 36 launches), residual +
-        // previous contents of ONE half (the second half's are requested behind the first one's stores)
-        f32x4v b4[2], ld[2][8];
+        if (p.mask) mv = p.mask[(nf16 + (lane & 3) * 16) >> p.mask_shift];
+        // two sets of 4 x 2 quads: the residual rows of both halves; or, for an accumulating launch (a branch's last step: 4 of a step's 36 launches),
+        // residual + previous contents of ONE half (the second half's are requested behind the first one's stores)
+        f32x4v b8[2][2], ld[2][4][2];
         const bool acc_y = p.accumulate != 0;
         auto load_rows = [&](int set, const float* base, int ldb, int m) {
-            const float* rp = base + (int64_t)nfirst * ldb + m;
+            const float* rp = base + (int64_t)nf16 * ldb + m;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) ld[set][it] = *reinterpret_cast<const f32x4v*>(rp + (int64_t)it * 8 * ldb);
+            for (int it = 0; it < 4; ++it) {
+                ld[set][it][0] = *reinterpret_cast<const f32x4v*>(rp + (int64_t)it * 16 * ldb);
+                ld[set][it][1] = *reinterpret_cast<const f32x4v*>(rp + (int64_t)it * 16 * ldb + 4);
+            }
         };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) b4[i] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + m0 + i * 32 + c4) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (p.R) load_rows(0, p.R, p.ldr, m0 + c4);
-        if (acc_y) load_rows(1, p.Y, p.ldy, m0 + c4);
-        else if (p.R) load_rows(1, p.R, p.ldr, m0 + 32 + c4);
-        unsigned mbits = 0xFFu;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                b8[i][h] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + m0 + i * 32 + c8 + 4 * h) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (p.R) load_rows(0, p.R, p.ldr, m0 + c8);
+        unsigned mbits = 0xFu;
         bool allkeep = true;
         clx_static_for<0, 2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_sched_barrier(0);
             tile_write(ic);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (i == 0) {
+                // the second set of rows goes into the registers the first half's accumulators just left (requested with the first set, the 64 + 64 + 16
+                // registers of both halves' accumulators, rows and bias spilled in the middle of the load burst)
+                if (acc_y) load_rows(1, p.Y, p.ldy, m0 + c8);
+                else if (p.R) load_rows(1, p.R, p.ldr, m0 + 32 + c8);
                 asm volatile("" : "+v"(mv));   // (the compare stays behind the LDS writes: hoisted to the load, it waits for the load there)
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(mv != 0);
                 allkeep = bal == ~0ull;
-                mbits = (unsigned)(bal >> ((lane >> 3) * 8)) & 0xFFu;
+                mbits = (unsigned)(bal >> ((lane >> 2) * 4)) & 0xFu;
+                if (p.stamps) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_e1 = __builtin_amdgcn_s_memrealtime();
+                }
             }
-            const int m = m0 + i * 32 + c4;
+            const int m = m0 + i * 32 + c8;
             if constexpr (i == 1) {
                 if (acc_y) {
                     if (p.R) load_rows(0, p.R, p.ldr, m);
                     load_rows(1, p.Y, p.ldy, m);
                 }
             }
-            float* yp = p.Y ? p.Y + (int64_t)nfirst * p.ldy + m : nullptr;
-            const int64_t ystep = (int64_t)8 * p.ldy;
-            char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nfirst) * 32 + (m & 15) * 2 : nullptr;
+            float* yp = p.Y ? p.Y + (int64_t)nf16 * p.ldy + m : nullptr;
+            const int64_t ystep = (int64_t)16 * p.ldy;
+            // bf16 parts of lrelu(result), chunk-major: 8 channels = 16 bytes of a 32-byte row; the lo plane follows the hi plane
+            char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nf16) * 32 + (m & 15) * 2 : nullptr;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
-                f32x4v v = a + b4[i];
-                if (p.R) v += acc_y ? ld[0][it] : ld[i][it];
-                v *= beta;   // (x 1.0f is exact)
-                if (acc_y) v += ld[1][it];
-                if (!allkeep && !((mbits >> it) & 1u)) v = f32x4v{0.f, 0.f, 0.f, 0.f};
-                if (yp) *reinterpret_cast<f32x4v*>(yp + it * ystep) = v;
-                if (qs) {
-                    bf16x4 h, l;
+            for (int it = 0; it < 4; ++it) {
+                f32x4v v[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = v[e] >= 0.f ? v[e] : v[e] * sl;
-                        h[e] = (__bf16)x;
-                        l[e] = (__bf16)(x - (float)h[e]);
-                    }
-                    *reinterpret_cast<bf16x4*>(qs + it * 256) = h;
-                    *reinterpret_cast<bf16x4*>(qs + it * 256 + yplane) = l;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4v a = *reinterpret_cast<const f32x4v*>(trow8 + it * 16 * 36 + 4 * h);
+                    v[h] = a + b8[i][h];
+                    if (p.R) v[h] += acc_y ? ld[0][it][h] : ld[i][it][h];
+                    v[h] *= beta;   // (x 1.0f is exact)
+                    if (acc_y) v[h] += ld[1][it][h];
+                    if (!allkeep && !((mbits >> it) & 1u)) v[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
                 }
+                if (yp) {
+                    *reinterpret_cast<f32x4v*>(yp + it * ystep) = v[0];
+                    *reinterpret_cast<f32x4v*>(yp + it * ystep + 4) = v[1];
+                }
+                if (qs) {
+                    bf16x8 h8, l8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float ve = v[e >> 2][e & 3];
+                        const float x = fmaxf(ve, ve * sl);   // leaky ReLU for 0 <= slope <= 1 (the same value as the select, one instruction less)
+                        h8[e] = (__bf16)x;
+                        l8[e] = (__bf16)(x - (float)h8[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(qs + it * 512) = h8;
+                    *reinterpret_cast<bf16x8*>(qs + it * 512 + yplane) = l8;
+                }
+            }
+            if constexpr (i == 0) {
+                if (p.stamps) st_e2 = __builtin_amdgcn_s_memrealtime();
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         if (p.stamps && tid == 0) {   // (diagnostics) last store issued / every store of this wave acknowledged
-            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * kClxStampWords;
+            o[8] = st_e0; o[9] = st_e1; o[10] = st_e2;
             o[5] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             o[6] = __builtin_amdgcn_s_memrealtime();
         }
         return;
     }
-    // ---- the batch's last position tile: the same arithmetic with clamped reads and guarded stores
-    clx_static_for<0, 2>([&](auto ic) {
+    // ---- the batch's last position tile: the same arithmetic with clamped reads and guarded stores, one row at a time (a handful of workgroups per launch)
+    if constexpr (EDGE) clx_static_for<0, 2>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         tile_write(ic);
         const int m = m0 + i * 32 + c4;
-        const bool mok = m < M;
-        const int mc = mok ? m : 0;
-        const f32x4v b4 = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + mc) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        f32x4v rold[8], rres[8];
-        unsigned char keep[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int64_t pp = min(nfirst + it * 8, N - 1);
-            if (p.accumulate) rold[it] = *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + mc);
-            if (p.R) rres[it] = *reinterpret_cast<const f32x4v*>(p.R + pp * p.ldr + mc);
-            keep[it] = p.mask ? p.mask[pp >> p.mask_shift] : 1;
-        }
-        float* yp = p.Y ? p.Y + (int64_t)nfirst * p.ldy + m : nullptr;
-        const int64_t ystep = (int64_t)8 * p.ldy;
-        // bf16 parts of lrelu(result), chunk-major (4 channels = 8 bytes of a 32-byte row; the lo plane follows the hi plane)
-        char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nfirst) * 32 + (m & 15) * 2 : nullptr;
-#pragma unroll
+        const f32x4v b4 = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + m) : f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
         for (int it = 0; it < 8; ++it) {
             const int n = nfirst + it * 8;
+            const int64_t pp = min(n, N - 1);
             const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
-            if (n < N && mok) {
-                f32x4v v = a + b4;
-                if (p.R) v += rres[it];
-                v *= beta;
-                if (p.accumulate) v += rold[it];
-                if (!keep[it]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
-                if (yp) *reinterpret_cast<f32x4v*>(yp) = v;
-                if (qs) {
+            f32x4v v = a + b4;
+            if (p.R) v += *reinterpret_cast<const f32x4v*>(p.R + pp * p.ldr + m);
+            v *= beta;
+            if (p.accumulate) v += *reinterpret_cast<const f32x4v*>(p.Y + pp * p.ldy + m);
+            if (p.mask && !p.mask[pp >> p.mask_shift]) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+                if (p.Y) *reinterpret_cast<f32x4v*>(p.Y + (int64_t)n * p.ldy + m) = v;
+                if (p.Ys.p) {   // bf16 parts of lrelu(result), chunk-major (4 channels = 8 bytes of a 32-byte row; the lo plane follows the hi plane)
+                    char* qs = static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + n) * 32 + (m & 15) * 2;
                     bf16x4 h, l;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = v[e] >= 0.f ? v[e] : v[e] * sl;
+                        const float x = fmaxf(v[e], v[e] * sl);
                         h[e] = (__bf16)x;
                         l[e] = (__bf16)(x - (float)h[e]);
                     }
@@ -522,10 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                     *reinterpret_cast<bf16x4*>(qs + yplane) = l;
                 }
             }
-            if (yp) yp += ystep;
-            if (qs) qs += 8 * 32;
         }
-        __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -632,8 +676,17 @@ bool conv_clx_usable(const ConvClxParams& p) {
 
 static thread_local int64_t* g_clx_grid_only = nullptr;   // clx_grid_workgroups: report the grid instead of launching
 
+template <int NTAPS, int WR, int XB, int XR, bool EDGE>
+static void launch_clx_e(ClxKernelParams kp, hipStream_t stream);
+
 template <int NTAPS, int WR, int XB, int XR>
-static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
+static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
+    if (kp.p.N % kClxNT == 0 && !kp.p.Ykm) launch_clx_e<NTAPS, WR, XB, XR, false>(kp, stream);
+    else launch_clx_e<NTAPS, WR, XB, XR, true>(kp, stream);
+}
+
+template <int NTAPS, int WR, int XB, int XR, bool EDGE>
+static void launch_clx_e(ClxKernelParams kp, hipStream_t stream) {
     const ConvClxParams& p = kp.p;
     SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
     kp.gy = p.M / 64;
@@ -643,7 +696,7 @@ static void launch_clx(ClxKernelParams kp, hipStream_t stream) {
         return;
     }
     const size_t lds = std::max<size_t>((size_t)WR * 4096 + (size_t)XB * 2 * XR * 32, (size_t)4 * 64 * 36 * sizeof(float));
-    auto kern = conv_clx_kernel<NTAPS, WR, XB, XR>;
+    auto kern = conv_clx_kernel<NTAPS, WR, XB, XR, EDGE>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;

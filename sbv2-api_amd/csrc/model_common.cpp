@@ -232,7 +232,7 @@ PackedUpsample WeightStore::upsample(const std::string& prefix, int stride, int 
     return u;
 }
 
-SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask) {
+SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask, int round_to) {
     SegLayout l;
     l.n = (int)lens.size();
     int pos = 0;
@@ -242,7 +242,7 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
         l.len.push_back(v);
         pos = st + v + gap;
     }
-    l.L = round_up(std::max(pos, 4), 4);
+    l.L = round_up(std::max(pos, 4), std::max(round_to, 4));   // (columns behind the last utterance are gap columns: masked, zero)
     std::vector<int> seg(l.L, -1);
     std::vector<unsigned char> mask(l.L, 0);
     size_t e = 0;

@@ -55,7 +55,7 @@ struct SegLayout {
         return m;
     }
 };
-SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask = nullptr);
+SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipStream_t stream, const unsigned char* extra_mask = nullptr, int round_to = 4);
 
 class WeightStore;
 // w is [M][K][k] (Conv1d layout); K is zero-padded to a multiple of 16

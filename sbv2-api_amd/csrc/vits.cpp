@@ -779,7 +779,9 @@ void VitsModel::forward(const VitsBatch& b) {
             Tf[u] = (int)std::max<int64_t>(sum, 1);  // torch.clamp_min(sum, 1)
         }
     }
-    fl_ = make_layout(Tf, kFrameGap, ar, stream_);
+    // (frame count rounded to 32: every plane of the decoder's wide stages - 8 and 64 positions per frame - is then a whole number of conv_clx's 256-position
+    // tiles, and the kernel instance without the guarded last-tile epilogue applies)
+    fl_ = make_layout(Tf, kFrameGap, ar, stream_, nullptr, 32);
     const SegLayout& fl = fl_;
     const int Lf = fl.L;
     std::vector<int> tok(Lf, -1);

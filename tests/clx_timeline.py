@@ -16,11 +16,11 @@ KINDS = [int(v) for v in os.environ.get("CLX_TL_KINDS", "1,2").split(",")]
 for (c, k, d, L) in SHAPES:
     for kind in KINDS:
         for var in variants:
-            cap = 8 * 40000
+            cap = 12 * 40000
             buf = (C.c_uint64 * cap)()
             nwg, ms = C.c_int64(), C.c_double()
             _lib.check(l.sbv2_debug_clx_timeline(0, c, k, d, L, kind, var, 0.6, buf, cap, C.byref(nwg), C.byref(ms)))
-            a = np.frombuffer(buf, dtype=np.uint64, count=8 * nwg.value).reshape(-1, 8).astype(np.int64)
+            a = np.frombuffer(buf, dtype=np.uint64, count=12 * nwg.value).reshape(-1, 12).astype(np.int64)
             a = a[a[:, 4] > 0]                      # workgroups that ran (padding tiles return early)
             ent, l0, l1, ex, dr = a[:, 4], a[:, 1], a[:, 3], a[:, 5], a[:, 6]
             hw = a[:, 7]
@@ -41,7 +41,8 @@ for (c, k, d, L) in SHAPES:
             r = {"C": c, "k": k, "dil": d, "kind": {1: "conv1", 2: "conv2", 3: "conv2-last"}[kind], "variant": var, "ms_per_launch": round(ms.value, 4),
                  "workgroups": int(len(a)), "cus_seen": int(len(np.unique(cu))), "loop_clock_mhz": round(float(clock), 0),
                  "prologue_us": round(us(l0 - ent), 2), "loop_us": round(us(l1 - l0), 2), "epilogue_issue_us": round(us(ex - l1), 2),
-                 "store_drain_us": round(us(dr - ex), 2), "life_us": round(us(dr - ent), 2),
+                 "epi_barrier_us": round(us(a[:, 8] - l1), 2), "epi_reads_us": round(us(a[:, 9] - a[:, 8]), 2), "epi_half0_us": round(us(a[:, 10] - a[:, 9]), 2),
+                 "epi_half1_us": round(us(ex - a[:, 10]), 2), "store_drain_us": round(us(dr - ex), 2), "life_us": round(us(dr - ent), 2),
                  "gap_exit_to_next_entry_us": round(float(np.median(gaps)) / 100.0, 2) if gaps else None,
                  "avg_workgroups_in_loop_per_cu": round(float(np.mean(inloop)), 2), "avg_workgroups_resident_per_cu": round(float(np.mean(resident)), 2),
                  "launch_span_us": round(float(dr.max() - ent.min()) / 100.0, 1)}
