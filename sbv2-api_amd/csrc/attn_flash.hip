@@ -1412,29 +1412,8 @@ void launch_flash_x3q(const AttnGroup* groups, int ngroups, int maxT, const floa
     constexpr size_t lds = 4 * 2 * DR * 128 + sizeof(float) * (2 * kFaBand * DR + 2 * NW * kFaBand * 32) + NW * 64 * 4 + (NW == 4 ? NW * (DR / 16) * 1024 : 0);
     const __bf16* base = static_cast<const __bf16*>(kv.p);
     const dim3 grid((maxT + 32 * NW - 1) / (32 * NW), ngroups);
-    static const char* stamp_file = getenv("SBV2_FLASH_Q_STAMPS");
-    if (stamp_file && DT == 3) {   // builder's timeline run: every launch appends the stamps of workgroup (0, 0)
-        auto kern = k_vits_flash_x3q<DT, NW, true>;
-        static std::atomic<uint64_t> lds_allowed_dg{0};
-        allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed_dg);
-        constexpr int n = NW * 160;
-        static unsigned long long* dbuf = nullptr;
-        if (!dbuf) HIP_CHECK(hipMalloc(&dbuf, n * sizeof(unsigned long long)));
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds + n * 8, s, groups, Q, ld, base + (int64_t)k_row0 * kv.ld, base + (int64_t)v_row0 * kv.ld, kv.pstride,
-                           kv.ld, ctx, ldc, dk, erk, erv, window, qscale, dbuf);
-        HIP_CHECK(hipStreamSynchronize(s));
-        std::vector<unsigned long long> h(n);
-        HIP_CHECK(hipMemcpy(h.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(stamp_file, "a")) {
-            for (int wv = 0; wv < NW; ++wv) {
-                fprintf(f, "T %d wave %d:", maxT, wv);
-                for (int q = 0; q < 160 && h[wv * 160 + q]; ++q) fprintf(f, " %llu", h[wv * 160 + q] - h[0]);
-                fprintf(f, "\n");
-            }
-            fclose(f);
-        }
-        return;
-    }
+    // (the timeline instantiation <DT, NW, true> of round 4 - s_memtime stamps at every phase boundary, profiles/r04i_flash_attention_timeline.txt - is not
+    // launched by the library any more)
     auto kern = k_vits_flash_x3q<DT, NW>;
     static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
@@ -1456,11 +1435,8 @@ void launch_flash_x3p(dim3 grid, const AttnGroup* groups, const float* Q, int ld
 }
 }  // namespace
 
-// the software-pipelined kernel (k_vits_flash_x3q) wherever its DMA blocks fit (head dimensions that are multiples of 8); SBV2_FLASH_Q=0: never
-bool flash_pipelined_usable(int dk) {
-    static const int use_q = getenv("SBV2_FLASH_Q") ? atoi(getenv("SBV2_FLASH_Q")) : 1;
-    return use_q != 0 && (dk & 7) == 0 && dk <= 96;
-}
+// the software-pipelined kernel (k_vits_flash_x3q) wherever its DMA blocks fit (head dimensions that are multiples of 8)
+bool flash_pipelined_usable(int dk) { return (dk & 7) == 0 && dk <= 96; }
 
 // keys / values from bf16 hi / lo planes (rows k_row0 .. + heads dk and v_row0 .. of kv: two bf16 parts, the columns of Q's plane)
 void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
@@ -1472,8 +1448,7 @@ void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, 
     if (ngroups <= 0 || maxT <= 0) return;
     if (pipelined && flash_pipelined_usable(dk)) {
         // 128-query workgroups (4 waves, one per SIMD) while they leave at most one workgroup per CU; beyond, 256-query workgroups of 8 waves (two per SIMD)
-        static const int q8_min = getenv("SBV2_FLASH_Q8_MIN_WGS") ? atoi(getenv("SBV2_FLASH_Q8_MIN_WGS")) : 257;
-        const bool wide = pipelined == 2 || (int64_t)((maxT + 127) / 128) * ngroups >= q8_min;   // (2: the test forces the 8-wave shape on small batches)
+        const bool wide = pipelined == 2 || (int64_t)((maxT + 127) / 128) * ngroups > 256;   // (2: the test forces the 8-wave shape on small batches)
         if (wide) {
             if (dk <= 32) launch_flash_x3q<1, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
             else if (dk <= 64) launch_flash_x3q<2, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);

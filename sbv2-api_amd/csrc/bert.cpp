@@ -47,6 +47,7 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(blob.kind == 1, "weight container is not a DeBERTa (kind 1) model");
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));  // never serialised against the NULL stream (e.g. RCCL launched by the caller)
+    f16x3_sat_prepare();
     const std::string& js = blob.config_json;
     cfg_.vocab = (int)json_number(js, "vocab_size");
     cfg_.hidden = (int)json_number(js, "hidden");

@@ -251,8 +251,17 @@ static unsigned long long* sat_ptr(bool create) {
     g_sat_ctr[dev] = p;
     return p;
 }
-unsigned long long* f16x3_sat_counter() { return g_sat_on.load(std::memory_order_relaxed) ? sat_ptr(true) : nullptr; }
-int f16x3_sat_enable(int on) { return g_sat_on.exchange(on); }
+// (the counter is created by f16x3_sat_prepare - model creation, sbv2_debug_f16x3_saturation - never lazily here: alloc_split calls this inside the
+// streaming decoder's hipGraph capture, where a hipMalloc is illegal)
+unsigned long long* f16x3_sat_counter() { return g_sat_on.load(std::memory_order_relaxed) ? sat_ptr(false) : nullptr; }
+void f16x3_sat_prepare() {
+    if (g_sat_on.load(std::memory_order_relaxed)) (void)sat_ptr(true);
+}
+int f16x3_sat_enable(int on) {
+    const int prev = g_sat_on.exchange(on);
+    if (on) (void)sat_ptr(true);
+    return prev;
+}
 unsigned long long f16x3_sat_read(bool reset) {
     unsigned long long* p = sat_ptr(false);
     if (!p) return 0;

@@ -279,6 +279,7 @@ struct SplitPlanes {        // [part][C][ld] 16-bit, the column axis contiguous;
 // DeBERTa checkpoint with outlier channels should be run once with SBV2_F16X3_SATCOUNT=1 (fallback: SBV2_BERT_GEMM=bf16x6, bf16's range).
 unsigned long long* f16x3_sat_counter();
 int f16x3_sat_enable(int on);                        // returns the previous setting
+void f16x3_sat_prepare();   // creates the current device's counter if counting is on (call at model creation, outside any stream capture)
 unsigned long long f16x3_sat_read(bool reset);       // current device
 inline SplitPlanes alloc_split(Arena& ar, int code, int C, int L) {   // same pitch rule as Arena::plane; code as in set_bfs_parts
     SplitPlanes s;
@@ -290,7 +291,9 @@ inline SplitPlanes alloc_split(Arena& ar, int code, int C, int L) {   // same pi
     s.L = L;
     s.ld = round_up(L, 64);
     s.pstride = (int64_t)C * s.ld;
-    s.p = ar.alloc((size_t)parts * C * s.ld * 2);
+    // (+ 32 bytes: k_vits_flash_x3q's clamped 16-byte reads of an utterance shorter than 8 frames may start 4 columns before the end of the last row.  Its
+    // LDS-DMA sources are 8-byte aligned - segment starts and pitches are multiples of 4 elements - which the hardware's unaligned access mode serves.)
+    s.p = ar.alloc((size_t)parts * C * s.ld * 2 + 32);
     return s;
 }
 struct BfsWeights {         // W as MFMA A fragments: [K / 16][nmt][parts][64 lanes][8] bf16 (lane l: row 32 mt + (l & 31), k = 16 c + 8 (l >> 5) + j)
@@ -440,7 +443,8 @@ struct ResPairParams {
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
 void launch_respair_cl_diag(const ResPairParams& p, hipStream_t stream);
-// respair_clx.hip: the same step, split-bf16, k in {3, 7, 11}, rebuilt around its instruction count (round 4); bit-identical to respair_cl
+// respair_clx.hip: the same step, split-bf16, k in {3, 7, 11}, rebuilt around its instruction count (round 4); bit-identical to respair_cl at C = 32 / 64,
+// f32-grade (two taps per 16x16x32 MFMA: another summation order; tests hold 1e-5) at C = 16
 bool respair_clx_usable(const ResPairParams& p);          // p.mask_shift set
 void launch_respair_clx(const ResPairParams& p, hipStream_t stream);
 void launch_respair_clx_diag(const ResPairParams& p, hipStream_t stream);

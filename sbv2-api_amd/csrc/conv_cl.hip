@@ -469,6 +469,41 @@ __global__ __launch_bounds__(kClThreads * WM) void conv_cl_kernel(const ClKernel
                 if (rp) rres[it] = *reinterpret_cast<const f32x4v*>(p.R + pp * p.ldr + cc);   // the residual rows as well
             }
         }
+        // Interior sub-tiles with the mask staged in LDS (round 5): no per-lane conditions around the stores.  In the loop below every iteration's store sits
+        // in a divergent branch, behind which hipcc cannot count the outstanding stores: it waits s_waitcnt vmcnt(0) at the first use of a pre-loaded
+        // residual row in the NEXT iteration, i.e. one exposed store acknowledgement per row group, eight per sub-tile.  Same arithmetic per element.
+        if (staged && nfirst - (lane >> 3) + 64 <= N && m0 + i * 32 + 32 <= M) {
+            const bool has_r = rp != nullptr, has_acc = p.accumulate != 0;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(trow + it * 8 * 36);
+                float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+                if (has_r) {
+                    v.x += rres[it][0]; v.y += rres[it][1]; v.z += rres[it][2]; v.w += rres[it][3];
+                }
+                if (beta != 1.0f) { v.x *= beta; v.y *= beta; v.z *= beta; v.w *= beta; }
+                if (has_acc) {
+                    v.x += rold[it][0]; v.y += rold[it][1]; v.z += rold[it][2]; v.w += rold[it][3];
+                }
+                if (!mask_s[nfirst + it * 8 - n0]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(yp + it * ystep) = v;
+                if (YS && p.ys_p) {   // bf16 parts of lrelu(result): 4 channels = 8 bytes of a 32-byte row of chunk co >> 4; the lo plane follows the hi plane
+                    typedef __bf16 cl_bf16x4 __attribute__((ext_vector_type(4)));
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    cl_bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = vv[e] >= 0.f ? vv[e] : vv[e] * p.ys_slope;
+                        h[e] = (__bf16)x;
+                        l[e] = (__bf16)(x - (float)h[e]);
+                    }
+                    char* qs = static_cast<char*>(p.ys_p) + ((int64_t)(co >> 4) * 2 * p.ys_rows + p.ys_front + pos + it * pstep) * 32 + (co & 15) * 2;
+                    *reinterpret_cast<cl_bf16x4*>(qs) = h;
+                    *reinterpret_cast<cl_bf16x4*>(qs + p.ys_rows * 32) = l;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int n = nfirst + it * 8;
@@ -537,8 +572,6 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
             lds += 128 * sizeof(float) + kClNT;
         }
     }
-    static const int pad_lds = getenv("SBV2_CL_PADLDS") ? atoi(getenv("SBV2_CL_PADLDS")) : 0;   // occupancy experiments only
-    lds += pad_lds;
     SBV2_REQUIRE(lds <= 160 * 1024, "conv_cl: LDS budget exceeded");
     auto kern = conv_cl_kernel<TM, PREC, IN_KM, OUT_KM, WM>;
     static std::atomic<uint64_t> lds_allowed{0};   // per (kernel instantiation, device)
@@ -571,8 +604,7 @@ static void launch_cl(ClKernelParams kp, hipStream_t stream) {
 
 // 128-row workgroups (two 64-row wave groups sharing one staged window) when the row tiles pair up and the grid still covers the chip
 static bool wide_rows(const ClKernelParams& kp) {
-    static const int knob = getenv("SBV2_CL_WM") ? atoi(getenv("SBV2_CL_WM")) : 2;
-    if (knob < 2 || (kp.nmt & 3) != 0) return false;
+    if ((kp.nmt & 3) != 0) return false;
     const int64_t wgs = (int64_t)round_up((kp.p.N + kClNT - 1) / kClNT, 8) * (kp.nmt / 4);
     return wgs >= 512;
 }
@@ -627,7 +659,9 @@ void launch_conv_cl(const ConvClParams& p, hipStream_t stream) {
     // small grids (single-utterance calls: the flow's FFN convs at 897 frames are 12 / 48 workgroups of 64 rows): 32-row tiles double the
     // workgroup count; the weights are packed per 32-row tile either way (nmt is a multiple of the packed tm)
     // ... and the channels-last -> k-major products of such calls run as independent waves fed by an LDS-DMA ring (conv_cl_small.hip: same bits)
-    if ((int64_t)((p.N + kClNT - 1) / kClNT) * std::max(1, p.nmt / 2) < small_grid_max() && launch_conv_cl_small(p, kp.mask_shift, stream)) return;
+    // (a launch that must also write the result's bf16 parts never takes the small-grid kernel, which has no parts epilogue: should conv_cl_parts_ok drift
+    // from this dispatch, the SBV2_REQUIRE in launch_cl refuses the launch instead of leaving the parts unwritten)
+    if (!p.ys_p && (int64_t)((p.N + kClNT - 1) / kClNT) * std::max(1, p.nmt / 2) < small_grid_max() && launch_conv_cl_small(p, kp.mask_shift, stream)) return;
     int tm = p.tm;
     if (tm == 2 && (int64_t)((p.N + kClNT - 1) / kClNT) * (p.nmt / 2) < 128) tm = 1;
     if (p.split) {

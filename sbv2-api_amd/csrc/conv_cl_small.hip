@@ -284,8 +284,7 @@ bool launch_conv_cl_small(const ConvClParams& p, int mask_shift, hipStream_t str
     kp.mask_shift = mask_shift;
     kp.slot_bytes = p.ntaps * 2048 + kp.xg * 1024;
     const int per = 2 * p.ntaps + kp.xg;
-    static const int ahead_max = getenv("SBV2_CLS_AHEAD") ? atoi(getenv("SBV2_CLS_AHEAD")) : 4;   // experiments
-    kp.ahead = std::max(2, std::min(std::min(kSlots - 2, ahead_max), 62 / per));   // one wave holds every outstanding load: 6-bit vmcnt
+    kp.ahead = std::max(2, std::min(std::min(kSlots - 2, 4), 62 / per));   // one wave holds every outstanding load: 6-bit vmcnt
     const size_t lds = (size_t)kSlots * kp.slot_bytes + 4 * (size_t)kp.xrows * 32;
     if (lds > 160 * 1024) return false;
     auto kern = conv_cl_small_kernel<TN>;

@@ -33,7 +33,7 @@
 // control flow has (an fma there moved the waveform by 9e-7 between two epilogue variants that promise the same bits)
 #pragma clang fp contract(off)
 
-// CLX_ABL (diagnostic builds only, tests/clx_ablate.sh; results WRONG for 1-3): 1 = the weight waves do not wait for their DMAs at a pair's TOP, 2 = no
+// CLX_ABL (diagnostic builds only, tools/clx_ablate.sh; results WRONG for 1-3): 1 = the weight waves do not wait for their DMAs at a pair's TOP, 2 = no
 // v_permlane32_swap (M2 takes a's M1 fragments), 3 = both and the window waves never wait, 4 = M2's B fragments requested in M1(b)'s first gaps
 #ifndef CLX_ABL
 #define CLX_ABL 0
@@ -117,8 +117,10 @@ __device__ __forceinline__ void clx_halves(const bf16x8& a, const bf16x8& b, bf1
 // EDGE: the launch has a partial last position tile (N % 256 != 0): its guarded epilogue is compiled in.  (Compiled into every instance, that rarely taken
 // path set the register allocation of the whole kernel and the interior epilogue spilled in the middle of its load burst; the decoder's frame layout is
 // rounded so that the wide stages' planes are whole tiles.)
-template <int NTAPS, int kClxWR, int kClxXB, int XR, bool EDGE>
+// ... and the k-major epilogue (the flow's second FFN convolution) is an instance of its own (EPI 2; 1 = EDGE, 0 = whole tiles).
+template <int NTAPS, int kClxWR, int kClxXB, int XR, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
+    constexpr bool EDGE = EPI == 1;
     constexpr int NPW = 64;                    // positions per wave
     constexpr int NTW = 256;                   // positions per workgroup
     constexpr int NW = 4;                      // waves
@@ -142,8 +144,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     const int xcd = bid & 7, slot = bid >> 3;
     const int by = slot % kp.gy;
     const int bx = (slot / kp.gy) * 8 + xcd;
-    const int n0 = bx * NTW;
-    if (n0 >= p.N) return;
+    if (bx * NTW >= p.N) return;
+    // EPI 0 with a ragged N (launched only when nothing accumulates): the last tile is moved left to end at N; the positions it shares with its neighbour are
+    // computed twice from the same operands in the same order, and stored twice with the same bits
+    const int n0 = EPI == 0 ? min(bx * NTW, p.N - NTW) : bx * NTW;
     const int m0 = by * 64;                    // first output row of the workgroup (every wave: all 64 rows, its own 64 positions)
     const int M = p.M, N = p.N;
     const int nchunks = p.K >> 4;              // (even: K is a multiple of 32)
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     // accumulator tile [it][jt]: lane (column l16 = position 16 jt + l16 of the wave's 64, row group lg) holds rows 16 it + 4 lg .. + 3
     // ---- k-major result (the flow's second FFN convolution: Y[m][n] = (conv + b + R[m][n]) * mask): one accumulator register of a 16-lane group is 16
     // consecutive positions of one channel = a 64-byte run of the plane; bias, mask and residual of a row tile are requested before its first store
-    if (p.Ykm) {
+    if constexpr (EPI == 2) {
         int nn[4];
         bool nok[4], keepn[4];
 #pragma unroll
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
         });
         return;
     }
-
+    if constexpr (EPI != 2) {
     // ---- channels-last epilogue: each wave transposes its two 32-row halves through a private LDS tile [64 positions][36] so that 8 consecutive lanes hold
     // one full 128-byte line of a row
     float* tile = reinterpret_cast<float*>(smem) + wave * (NPW * 36);
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
             }
         }
     });
+    }   // EPI != 2
 }
 
 // ---- f32 channels-last plane -> chunk-major bf16 parts of lrelu(x) (a stage input; every other operand is written by an epilogue) ----------------
@@ -676,16 +681,17 @@ bool conv_clx_usable(const ConvClxParams& p) {
 
 static thread_local int64_t* g_clx_grid_only = nullptr;   // clx_grid_workgroups: report the grid instead of launching
 
-template <int NTAPS, int WR, int XB, int XR, bool EDGE>
+template <int NTAPS, int WR, int XB, int XR, int EPI>
 static void launch_clx_e(ClxKernelParams kp, hipStream_t stream);
 
 template <int NTAPS, int WR, int XB, int XR>
 static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
-    if (kp.p.N % kClxNT == 0 && !kp.p.Ykm) launch_clx_e<NTAPS, WR, XB, XR, false>(kp, stream);
-    else launch_clx_e<NTAPS, WR, XB, XR, true>(kp, stream);
+    if (kp.p.Ykm) launch_clx_e<NTAPS, WR, XB, XR, 2>(kp, stream);
+    else if (kp.p.N % kClxNT == 0 || (!kp.p.accumulate && kp.p.N >= kClxNT)) launch_clx_e<NTAPS, WR, XB, XR, 0>(kp, stream);
+    else launch_clx_e<NTAPS, WR, XB, XR, 1>(kp, stream);
 }
 
-template <int NTAPS, int WR, int XB, int XR, bool EDGE>
+template <int NTAPS, int WR, int XB, int XR, int EPI>
 static void launch_clx_e(ClxKernelParams kp, hipStream_t stream) {
     const ConvClxParams& p = kp.p;
     SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
@@ -696,7 +702,7 @@ static void launch_clx_e(ClxKernelParams kp, hipStream_t stream) {
         return;
     }
     const size_t lds = std::max<size_t>((size_t)WR * 4096 + (size_t)XB * 2 * XR * 32, (size_t)4 * 64 * 36 * sizeof(float));
-    auto kern = conv_clx_kernel<NTAPS, WR, XB, XR, EDGE>;
+    auto kern = conv_clx_kernel<NTAPS, WR, XB, XR, EPI>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;

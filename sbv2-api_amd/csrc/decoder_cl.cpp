@@ -49,8 +49,7 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
     c.M = M;
     c.K = K;
     c.k = k;
-    static const int tm_min = getenv("SBV2_CL_TM2_MIN") ? atoi(getenv("SBV2_CL_TM2_MIN")) : 64;   // experiments
-    c.tm = M >= tm_min ? 2 : 1;
+    c.tm = M >= 64 ? 2 : 1;
     c.nmt = round_up((M + 31) / 32, c.tm);
     c.parts = parts;                      // precision code: 1 = bf16, 2 = bf16 hi + lo, 3 = fp16
     const bool f16 = parts == 3;
@@ -217,8 +216,9 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
 static std::atomic<int> g_clx{getenv("SBV2_CLX") ? atoi(getenv("SBV2_CLX")) : 1};
 bool clx_enabled() { return g_clx.load(std::memory_order_relaxed) != 0; }
 static int64_t clx_min_tiles() {
-    static const int64_t v = getenv("SBV2_CLX_MIN_TILES") ? atoll(getenv("SBV2_CLX_MIN_TILES")) : 1024;
-    return g_clx.load(std::memory_order_relaxed) == 2 ? 0 : v;   // set_clx(2): every size (the bit-equality test runs small batches)
+    // 128 tiles: a single 128-phoneme utterance's 128-channel stage (448 tiles) takes conv_clx, its 256-channel stage (112) stays on conv_cl: 11.93 -> 11.79 ms
+    // per call (profiles/r05k_b1_clx_min_tiles.txt); rounds 3-4 required 1024 tiles.
+    return g_clx.load(std::memory_order_relaxed) == 2 ? 0 : 128;   // set_clx(2): every size (the bit-equality test runs small batches)
 }
 bool clx_wanted(int64_t tiles, int64_t min_tiles) {
     const int m = g_clx.load(std::memory_order_relaxed);
@@ -285,10 +285,10 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
         int ushift = 0;
         while ((1 << ushift) < U) ++ushift;
-        // (large launches only: a single utterance or a streaming window has too few tiles to pay for the extra split / halo launches; the two
-        // paths give the same bits, so the choice is free)
-        static const int clx_min_c = getenv("SBV2_CLX_MINC") ? atoi(getenv("SBV2_CLX_MINC")) : 128;   // A/B knob
-        bool clx = clx_enabled() && st.mode == 1 && C >= clx_min_c && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
+        // (launches of at least clx_min_tiles() tiles: smaller ones do not pay for the extra halo launches.  The two paths agree to f32 rounding,
+        // tests/test_gpu_parity.py::test_decoder_clx_path_agrees_with_conv_cl_path.  The 64-channel stage stays on the fused step: unfused on conv_clx it
+        // moves three times the bytes, measured in round 3.)
+        bool clx = clx_enabled() && st.mode == 1 && C >= 128 && (C & 63) == 0 && (1 << ushift) == U && (Lo / 256) * (C / 64) >= clx_min_tiles();
         for (int j = 0; j < nk && clx; ++j) {
             const ClBranch& rb = st.branches[j];
             if (!(rb.k == 3 || rb.k == 7 || rb.k == 11) || !rb.c1[0].wx) clx = false;
@@ -303,10 +303,8 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             YsA = make_split_cl(ar.alloc(sb), C, Lo, stream_);
             YsB = make_split_cl(ar.alloc(sb), C, Lo, stream_);
         }
-        // (the stage input's parts are written by the transposed convolution's own epilogue below: no separate split pass over XU;
-        // SBV2_CLX_UPSPLIT=0 restores the pass, same bits)
-        static const int up_split = getenv("SBV2_CLX_UPSPLIT") ? atoi(getenv("SBV2_CLX_UPSPLIT")) : 1;
-        bool parts_done = clx && up_split != 0;   // every phase group's launch wrote its share of XUs
+        // (the stage input's parts are written by the transposed convolution's own epilogue below: no separate split pass over XU)
+        bool parts_done = clx;   // every phase group's launch wrote its share of XUs
         for (const auto& g : st.up) {
             ConvClParams p;
             p.X = cur;
@@ -331,7 +329,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             p.out_stride = st.rate;
             p.phase_rows = C;
             for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
-            if (clx && up_split && conv_cl_parts_ok(p)) {
+            if (clx && conv_cl_parts_ok(p)) {
                 p.ys_p = XUs.p;
                 p.ys_rows = (int64_t)XUs.front + XUs.N + XUs.back;
                 p.ys_front = XUs.front;
@@ -351,7 +349,6 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                 const int d = rb.dil[q];
                 const bool last = q + 1 == nd;
                 float* yn = last ? XS : ((y == YA) ? YB : YA);
-                static const int fuse_max_c = getenv("SBV2_FUSE_PAIRS_MAXC") ? atoi(getenv("SBV2_FUSE_PAIRS_MAXC")) : 64;   // A/B knob
                 if (clx) {
                     ConvClxParams p1;
                     p1.X = *ys;
@@ -398,7 +395,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                     y = yn;
                     continue;
                 }
-                if (fuse_pairs_ && C <= fuse_max_c && C <= 64 && (U & (U - 1)) == 0) {
+                if (fuse_pairs_ && C <= 64 && (U & (U - 1)) == 0) {
                     // stages of <= 64 channels are HBM bound: conv1 -> conv2 fused, the intermediate stays in LDS (respair_cl.hip)
                     ResPairParams rp;
                     rp.X = y;

@@ -84,7 +84,7 @@ __device__ __forceinline__ int bfs_swz(int k) {
 }
 
 template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM * TN >= 4 ? 2 : 1))) void gemm_bfs_kernel(const BfsKernelParams kp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM * TN >= 4 ? 2 : (TM * TN == 2 && NSLOT <= 4 ? 3 : 1)))) void gemm_bfs_kernel(const BfsKernelParams kp) {
     static_assert(!F16 || PARTS == 2, "f16x3 has two planes");
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN, RB = NT * 2;
@@ -314,6 +314,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 36);
     const int lcol = lane & 31, lh = lane >> 5;
     const int lrow = lane >> 3, c4 = (lane & 7) * 4;
+    // Interior tiles whose output formats are the kernel's own (round 5): no per-lane conditions and no loops around the stores, the global reads of sub-tile
+    // s + 1 requested before the first store of sub-tile s.  In the generic path below hipcc cannot count the stores of split_store4's loop over the parts,
+    // so every use of a loaded value behind them waits s_waitcnt vmcnt(0): three exposed store acknowledgements per 32 x 32 sub-tile, on top of the loads
+    // queued behind the previous sub-tile's stores.  Same arithmetic in the same order: same bits.
+    const bool ys_own = !p.Ys.parts || (p.Ys.parts == PARTS && (p.Ys.f16 != 0) == F16 && !p.Ys.sat);
+    if (m0 + MT <= M && n0 + NT <= N && ys_own && (p.y_rows & 31) == 0 && (p.ys_row0 & 31) == 0 && (!p.mask || kp.mask_shift == 0)) {
+        constexpr int NS = TM * TN;
+        f32x4v rr[2][4];
+        float brow[2][4];
+        unsigned mk[2];
+        auto loads = [&](int s, int buf) {
+            const int i = s / TN, j = s % TN;
+            const int n = n0 + (wn * TN + j) * 32 + c4, mb = m0 + (wm * TM + i) * 32 + lrow;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                brow[buf][ps] = p.bias ? p.bias[mb + ps * 8] : 0.f;
+                if (p.R) rr[buf][ps] = *reinterpret_cast<const f32x4v*>(p.R + (int64_t)(mb + ps * 8) * p.ldr + n);
+            }
+            mk[buf] = p.mask ? *reinterpret_cast<const unsigned*>(p.mask + n) : 0x01010101u;   // four keep flags (n is a multiple of 4)
+        };
+        loads(0, 0);
+        static_for<0, NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, i = s / TN, j = s % TN, buf = s & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lcol] = F16 ? acc[i][j][r] + accx[i][j][r] * (1.0f / kF16LoScale) : acc[i][j][r];
+            if constexpr (s + 1 < NS) loads(s + 1, buf ^ 1);
+            const int n = n0 + (wn * TN + j) * 32 + c4, mb = m0 + (wm * TM + i) * 32 + lrow;
+            const int mt0 = m0 + (wm * TM + i) * 32;                       // (uniform) first row of the sub-tile
+            const bool toY = p.Y && mt0 < p.y_rows, toYs = p.Ys.parts && mt0 >= p.ys_row0;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const f32x4v av = *reinterpret_cast<const f32x4v*>(tile + (ps * 8 + lrow) * 36 + c4);
+                const int m = mb + ps * 8;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = av[e] + brow[buf][ps];
+                    if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (p.act == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                    else if (p.act == ACT_TANH) x = tanhf(x);
+                    x *= p.alpha;
+                    if (p.R) x += rr[buf][ps][e];
+                    x *= p.beta;
+                    v[e] = ((mk[buf] >> (8 * e)) & 0xFFu) ? x : 0.f;
+                }
+                if (toY) *reinterpret_cast<f32x4v*>(p.Y + (int64_t)m * p.ldy + n) = f32x4v{v[0], v[1], v[2], v[3]};
+                if (toYs) {
+                    const int64_t off = (int64_t)m * p.Ys.ld + n;
+                    if constexpr (F16) {
+                        typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                        f16x4v h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {   // split_store4's f16 pair: finite values beyond f16's range saturate, NaN / infinity pass through
+                            const float c = (v[e] != v[e] || fabsf(v[e]) == __builtin_inff()) ? v[e] : fminf(fmaxf(v[e], -65504.f), 65504.f);
+                            h[e] = (_Float16)c;
+                            l[e] = (_Float16)((c - (float)h[e]) * kF16LoScale);
+                        }
+                        *reinterpret_cast<f16x4v*>(static_cast<_Float16*>(p.Ys.p) + off) = h;
+                        *reinterpret_cast<f16x4v*>(static_cast<_Float16*>(p.Ys.p) + p.Ys.pstride + off) = l;
+                    } else {
+                        typedef __bf16 b16x4v __attribute__((ext_vector_type(4)));
+                        float res[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                        for (int pp = 0; pp < PARTS; ++pp) {
+                            b16x4v h;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                h[e] = (__bf16)res[e];
+                                res[e] -= (float)h[e];
+                            }
+                            *reinterpret_cast<b16x4v*>(static_cast<__bf16*>(p.Ys.p) + (int64_t)pp * p.Ys.pstride + off) = h;
+                        }
+                    }
+                }
+            }
+        });
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -432,53 +511,25 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
         kp.mask_shift = s;
     }
     auto blocks = [&](int mt, int nt) { return (int64_t)((p.M + mt - 1) / mt) * ((p.N + nt - 1) / nt); };
-    static const int force = getenv("SBV2_BFS_CFG") ? atoi(getenv("SBV2_BFS_CFG")) : 0;   // experiments: 1 = 128 x 128 always, 2 = 64 x 64 always
-    static const int slots = getenv("SBV2_BFS_SLOTS") ? atoi(getenv("SBV2_BFS_SLOTS")) : 0;   // experiments: ring depth of the 128 x 128 tiles
-    const bool big = force == 1 || (force != 2 && blocks(128, 128) >= 128);
+    const bool big = blocks(128, 128) >= 128;
     // Ring depth = bytes in flight per CU: a chunk's DMAs take ~1 us to land under load, a chunk's MFMAs 0.2 - 0.4 us.  Grids that leave one
     // workgroup per CU take the whole LDS (144 KB); larger grids run two workgroups per CU with 80 / 72 KB each.
     const bool lone = blocks(128, 128) <= 256;
     const bool k32 = (p.K & 31) == 0;
-    // configuration id (SBV2_BFS_SLOTS, experiments): tens = chunks per slot, units = slots
-    // Tile policy of the large f16x3 products (SBV2_BFS_HALF; same per-element summation order in every case).  5 (default, round 4): 64 x 128 tiles on a
-    // 4-slot ring = 48 KB and 99 registers: THREE workgroups per CU instead of two 128 x 128 ones (80 KB, 222 registers): gemm_bfs 8.07 -> 7.13 ms and the
-    // step -1.4 ms on the same box (the 128 x 128 grid of the 4096-row product is 544 workgroups on 512 slots, that of the 1024-row products 136).
-    // 0 = 128 x 128 everywhere (round 3); 1 = 64 x 128 (6 slots, two per CU) only where the 128 x 128 grid covers half the CUs; 2 = that tile everywhere;
-    // 6 = 3 slots / four per CU (7.7 ms); 7 = mode 1 on 4 slots
-    static const int half = getenv("SBV2_BFS_HALF") ? atoi(getenv("SBV2_BFS_HALF")) : 5;
-    if (p.W.f16) {   // the ring shapes of bf16x3 (same bytes per chunk), two accumulator sets
-        static const int small_cfg = getenv("SBV2_BFS_SMALL") ? atoi(getenv("SBV2_BFS_SMALL")) : 0;   // experiments on the small-grid (single-utterance) products
-        if (!big && small_cfg == 1 && k32) launch_bfs_cfg<2, 1, 1, 2, 2, 2, 4, true>(kp, stream);        // two chunks per slot: a barrier every 32 k
-        else if (!big && small_cfg == 2) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 4, true>(kp, stream);           // 4 slots
-        else if (!big && small_cfg == 3) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 16, true>(kp, stream);          // 16 slots (128 KB: one workgroup per CU)
-        else if (!big && small_cfg == 4) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 12, true>(kp, stream);          // 12 slots
-        else if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
-        else if ((half == 1 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) || half == 2) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);
-        else if (half == 3 && blocks(128, 128) > 512 && blocks(128, 128) < 640) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 6, true>(kp, stream);   // (the 544-workgroup product too)
-        else if (half == 8 && k32) launch_bfs_cfg<2, 1, 2, 2, 2, 2, 2, true>(kp, stream);   // experiments: two chunks per slot (a barrier every 32 k), two slots: 48 KB
-        else if (half == 9) launch_bfs_cfg<2, 2, 1, 2, 2, 1, 4, true>(kp, stream);          // experiments: 128 x 64 tiles, 48 KB
-        else if ((half == 10 || half == 11) && blocks(64, 128) < 400) {   // experiments: the 1024-row products (272 workgroups of 64 x 128) on 64 x 64 tiles: 544
-            if (half == 10) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 4, true>(kp, stream);   // 32 KB: four per CU
-            else launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);              // 64 KB: two per CU
-        }
-        else if (half == 5 || half == 8 || half == 9 || half == 10 || half == 11) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);   // 64 x 128 everywhere, 48 KB: three workgroups per CU
-        else if (half == 6) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 3, true>(kp, stream);   // ... 36 KB: four per CU
-        else if (half == 7 && blocks(128, 128) <= 160 && blocks(64, 128) >= 200) launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
-        else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4, true>(kp, stream);
-        else launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5, true>(kp, stream);
-    } else if (p.W.parts == 2) {
+    if (p.W.f16) {
+        // f16x3 (the default format): small grids (a single utterance) on 64 x 64 tiles with an 8-slot ring; everything else on 64 x 128 tiles with a 4-slot
+        // ring = 48 KB and 99 registers: THREE workgroups per CU instead of two 128 x 128 ones (80 KB, 222 registers): gemm_bfs 8.07 -> 7.13 ms per step in
+        // round 4.  Same per-element summation order on every tile.  (Rounds 3-4 measured the other tile / ring shapes behind knobs: 128 x 128 everywhere,
+        // 64 x 128 on 3 / 6 slots, 128 x 64, two chunks per barrier, 64 x 64 for the 1024-row products, 4 / 12 / 16 slots for small grids: all slower
+        // or equal; profiles/HISTORY.md.)
+        if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
+        else launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
+    } else if (p.W.parts == 2) {   // bf16x3 (opt-in)
         if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8>(kp, stream);
-        else if (slots == 15) launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5>(kp, stream);
-        else if (slots == 19) launch_bfs_cfg<2, 2, 2, 2, 2, 1, 9>(kp, stream);
-        else if (k32 && slots == 22) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 2>(kp, stream);
-        else if (k32 && slots == 24) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4>(kp, stream);
         else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4>(kp, stream);
         else launch_bfs_cfg<2, 2, 2, 2, 2, 1, 5>(kp, stream);
-    } else {
+    } else {                       // bf16x6 (the f16x3 fallback with bf16's exponent range)
         if (!big) launch_bfs_cfg<3, 1, 1, 2, 2, 1, 6>(kp, stream);
-        else if (slots == 13) launch_bfs_cfg<3, 2, 2, 2, 2, 1, 3>(kp, stream);
-        else if (slots == 16) launch_bfs_cfg<3, 2, 2, 2, 2, 1, 6>(kp, stream);
-        else if (k32 && slots == 23) launch_bfs_cfg<3, 2, 2, 2, 2, 2, 3>(kp, stream);
         else if (lone) launch_bfs_cfg<3, 2, 2, 2, 2, 1, 6>(kp, stream);
         else launch_bfs_cfg<3, 2, 2, 2, 2, 1, 3>(kp, stream);
     }

@@ -367,6 +367,50 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const KernelParams 
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
                     for (int r = 0; r < MM::NACC; ++r) tile[MM::row(lane, r) * 36 + lcol] = acc[i][j][r];
+                    // Interior sub-tiles (round 5): every global read of the four row groups (bias, residual, previous contents, the four keep flags as
+                    // one word) is requested before the first store, and the stores carry no per-lane conditions.  The loop below reads inside its
+                    // iterations: each of them opens with load round trips queued behind the previous iteration's store (loads and stores share the
+                    // in-order vmcnt queue).  Same arithmetic in the same order per element.
+                    if (m0 + wm0 + i * MF + 32 <= M && n0 + wn0 + j * MF + 32 <= N && (!p.mask || kp.mask_shift == 0)) {
+                        const int n = n0 + wn0 + j * MF + c4, mb = m0 + wm0 + i * MF + lrow;
+                        float brow[4];
+                        float4 rr[4], old[4];
+                        float bcv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias_mode == BIAS_COL) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) bcv[e] = p.bias[n + e];
+                        }
+                        const unsigned mk = p.mask ? *reinterpret_cast<const unsigned*>(p.mask + n) : 0x01010101u;
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int m = mb + ps * 8;
+                            brow[ps] = (p.bias_mode == BIAS_ROW) ? p.bias[m] : 0.f;
+                            rr[ps] = Rg ? *reinterpret_cast<const float4*>(Rg + (int64_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            old[ps] = p.accumulate ? *reinterpret_cast<const float4*>(Cg + (int64_t)m * p.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const float4 a = *reinterpret_cast<const float4*>(tile + (ps * 8 + lrow) * 36 + c4);
+                            const float av[4] = {a.x, a.y, a.z, a.w}, rv[4] = {rr[ps].x, rr[ps].y, rr[ps].z, rr[ps].w},
+                                        ov[4] = {old[ps].x, old[ps].y, old[ps].z, old[ps].w};
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = av[e] + brow[ps];
+                                if (p.bias_mode == BIAS_COL) x += bcv[e];
+                                if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                                else if (p.act == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                                else if (p.act == ACT_TANH) x = tanhf(x);
+                                x *= p.alpha;
+                                if (Rg) x += rv[e];
+                                x *= p.beta;
+                                if (p.accumulate) x += ov[e];
+                                v[e] = ((mk >> (8 * e)) & 0xFFu) ? x : 0.f;
+                            }
+                            *reinterpret_cast<float4*>(Cg + (int64_t)(mb + ps * 8) * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                        continue;
+                    }
                     for (int ps = 0; ps < 4; ++ps) {
                         const int row = ps * 8 + lrow;
                         const float4 a = *reinterpret_cast<const float4*>(tile + row * 36 + c4);
@@ -529,7 +573,7 @@ std::string conv_prof_end() {
     return out + "]";
 }
 
-static std::atomic<int> g_skinny_max{getenv("SBV2_SKINNY_MAX") ? atoi(getenv("SBV2_SKINNY_MAX")) : 128};   // 0 = off
+static std::atomic<int> g_skinny_max{128};   // sbv2_debug_set_skinny_max; 0 = off
 int set_skinny_max(int v) { return g_skinny_max.exchange(v); }
 int small_grid_max() { return g_skinny_max.load(std::memory_order_relaxed); }
 
@@ -592,17 +636,6 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
     const int64_t z = p.groups ? p.ngroups : 1;
     auto blocks = [&](int mt, int nt) { return z * ((Mx + mt - 1) / mt) * (int64_t)((Nx + nt - 1) / nt); };
     // tile choice: largest tile that still gives >= 2 workgroups per CU; 16-row MFMA for 16-row problems
-    static const int force = getenv("SBV2_CONV_CFG") ? atoi(getenv("SBV2_CONV_CFG")) : -1;   // experiments only
-    if (force >= 0 && Mx > 32) {
-        switch (force) {
-            case 3: return launch_cfg<32, 2, 4, 2, 2, 16>(kp, Mx, Nx, stream);
-            case 4: return launch_cfg<32, 2, 2, 2, 2, 16>(kp, Mx, Nx, stream);
-            case 5: return launch_cfg<32, 2, 2, 1, 4, 16>(kp, Mx, Nx, stream);
-            case 6: return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
-            case 7: return launch_cfg<32, 1, 1, 2, 2, 16>(kp, Mx, Nx, stream);
-            default: break;
-        }
-    }
     if (Mx <= 16) return launch_cfg<16, 1, 4, 1, 4, 16>(kp, Mx, Nx, stream);
     if (Mx <= 32) {
         if (blocks(32, 256) >= 512) return launch_cfg<32, 1, 2, 1, 4, 16>(kp, Mx, Nx, stream);
@@ -616,19 +649,15 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
         // long products pay the tiled kernel's per-chunk round trip 64 times or more, so their threshold is higher)
         const int skinny_max = g_skinny_max.load(std::memory_order_relaxed);
         if (blocks(64, 64) < (p.K >= 512 ? skinny_max + skinny_max / 2 : skinny_max) && launch_gemm_skinny(p, kp.mask_shift, stream)) return;
-        static const int ring_on = getenv("SBV2_GEMM_RING") ? atoi(getenv("SBV2_GEMM_RING")) : 2;   // 0 = off, 1 = ring with the register-staged tile policy, 2 = ring + its own tiles
-        const bool ring = ring_on && !p.groups && p.shift[0] == 0 && (p.K & 15) == 0 && p.K >= 48 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
+        const bool ring = !p.groups && p.shift[0] == 0 && (p.K & 15) == 0 && p.K >= 48 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
                           p.N <= p.nb && p.phase_rows >= (1 << 30);
         // 128 x 128 tiles (half the L2 bytes per FLOP; 64 KB of ring: two workgroups per CU) when they fill the chip in ONE round: 3072 x 2112 is
         // 408 workgroups on 512 slots (160 vs 177 us), 4096 x 2112 would be 544 = two rounds (251 vs 222 us)
-        if (ring && ring_on >= 2 && blocks(128, 128) >= 384 && blocks(128, 128) <= 512) return launch_cfg<32, 2, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
+        if (ring && blocks(128, 128) >= 384 && blocks(128, 128) <= 512) return launch_cfg<32, 2, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
         // ... and 64 x 64 tiles otherwise: 32 KB of ring = five workgroups per CU keep the MFMA pipe fed across the chunk barriers and quantise
         // better than 64 x 128 (4096 x 2112 x 1024: 211 vs 222 us; 768 x 28704 x 192: 113 vs 118)
-        if (ring && ring_on >= 2) return launch_cfg<32, 1, 1, 2, 2, 16, true>(kp, Mx, Nx, stream);
-        if (blocks(64, 128) >= 512) {
-            if (ring) return launch_cfg<32, 1, 2, 2, 2, 16, true>(kp, Mx, Nx, stream);
-            return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
-        }
+        if (ring) return launch_cfg<32, 1, 1, 2, 2, 16, true>(kp, Mx, Nx, stream);
+        if (blocks(64, 128) >= 512) return launch_cfg<32, 1, 2, 2, 2, 16>(kp, Mx, Nx, stream);
         // single-utterance calls (DeBERTa at 64 tokens: 16-64 workgroups of 64 rows on 256 CUs, 47 us per launch whatever the size):
         // 32-row tiles double the workgroup count; the per-element summation order does not depend on the tile, so batch rows stay
         // bit-identical to single calls

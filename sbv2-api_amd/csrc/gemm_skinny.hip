@@ -292,10 +292,8 @@ bool launch_gemm_skinny(const ConvParams& p, int mask_shift, hipStream_t stream)
     kp.mask_shift = mask_shift;
     // one wave per 16 x 16 tile while that is at most one wave per SIMD of the chip; 16 x 32 tiles beyond
     const int64_t waves = (int64_t)((p.M + 15) / 16) * ((p.N + 15) / 16);
-    static const int deep = getenv("SBV2_SKINNY_DEEP") ? atoi(getenv("SBV2_SKINNY_DEEP")) : 0;   // experiments
     if (waves <= 1024) {
-        if (deep && waves <= 512) launch_skinny<1, 32>(kp, stream);
-        else launch_skinny<1, 16>(kp, stream);
+        launch_skinny<1, 16>(kp, stream);
     } else {
         launch_skinny<2, 16>(kp, stream);
     }

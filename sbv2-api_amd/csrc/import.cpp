@@ -473,17 +473,35 @@ Named name_tensors(const OnnxGraph& g) {
                    op == "Div" || op == "Mul";
         };
         // the initializer behind `n`; swaps = Transpose nodes on the way that exchange the last two axes
-        auto const_side = [&](std::string n, int& swaps) -> const OnnxTensor* {
+        // On the CONSTANT side only value- and layout-preserving nodes may sit between the initializer and the MatMul: Identity, Unsqueeze / Squeeze (size-1
+        // axes), Tile / Expand (the batch repeat on the leading axis) and a Transpose of the last two axes (counted).  Anything else (a Mul / Div by a scale
+        // that was not folded, a Reshape that changes the layout, another permutation) would make the stored positions silently wrong: `bad` names it, and
+        // the caller refuses the file once the dynamic side has identified the MatMul as a position product.
+        auto const_side = [&](std::string n, int& swaps, std::string& bad) -> const OnnxTensor* {
             swaps = 0;
+            bad.clear();
             for (int hop = 0; hop < 8; ++hop) {
                 if (const OnnxTensor* t = init_of(n)) return is_float_tensor(*t) ? t : nullptr;
                 auto it = producer.find(n);
                 if (it == producer.end() || !pass_through(it->second->op) || it->second->in.empty()) return nullptr;
-                if (it->second->op == "Transpose")
-                    if (const OnnxAttr* pa = it->second->attr("perm")) {
+                const std::string& op = it->second->op;
+                if (op == "Transpose") {
+                    const OnnxAttr* pa = it->second->attr("perm");
+                    bool last_two = false, identity = pa != nullptr;
+                    if (pa) {
                         const size_t r = pa->ints.size();
-                        if (r >= 2 && pa->ints[r - 1] == (int64_t)r - 2 && pa->ints[r - 2] == (int64_t)r - 1) ++swaps;
+                        last_two = r >= 2 && pa->ints[r - 1] == (int64_t)r - 2 && pa->ints[r - 2] == (int64_t)r - 1;
+                        for (size_t a = 0; a < r; ++a) {
+                            const bool fixed = pa->ints[a] == (int64_t)a;
+                            if (!fixed) identity = false;
+                            if (!fixed && !(last_two && a + 2 >= r)) last_two = false;
+                        }
                     }
+                    if (last_two) ++swaps;
+                    else if (!identity && bad.empty()) bad = "Transpose (not a swap of the last two axes) at " + n;
+                } else if (!(op == "Identity" || op == "Unsqueeze" || op == "Squeeze" || op == "Tile" || op == "Expand")) {
+                    if (bad.empty()) bad = op + " at " + n;
+                }
                 n = it->second->in[0];
             }
             return nullptr;
@@ -514,7 +532,8 @@ Named name_tensors(const OnnxGraph& g) {
             if (nd.op != "MatMul" || nd.in.size() != 2) continue;
             for (int side = 0; side < 2; ++side) {
                 int swaps = 0;
-                const OnnxTensor* c = const_side(nd.in[side], swaps);
+                std::string bad;
+                const OnnxTensor* c = const_side(nd.in[side], swaps, bad);
                 if (!c || c->dims.size() < 3) continue;
                 std::vector<int64_t> d3;
                 for (int64_t v : c->dims)
@@ -523,6 +542,7 @@ Named name_tensors(const OnnxGraph& g) {
                 std::string lp;
                 bool isq = false;
                 if (!dyn_side(nd.in[1 - side], lp, isq)) continue;
+                SBV2_REQUIRE(bad.empty(), "ONNX import: the folded DeBERTa position constant of " + lp + " reaches its MatMul through a node that is not value- and layout-preserving: " + bad);
                 const std::string nm = lp + (isq ? "pos_key" : "pos_query");   // the QUERY meets the projected position KEYS (c2p) and vice versa
                 if (out.has(nm)) continue;
                 auto qb = out.dims.find(lp + "query_proj.bias");

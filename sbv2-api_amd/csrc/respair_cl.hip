@@ -465,7 +465,7 @@ void launch_respair_cl_diag(const ResPairParams& p0, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
-static std::atomic<int> g_rpx{getenv("SBV2_RESPAIR_CLX") ? atoi(getenv("SBV2_RESPAIR_CLX")) : 1};
+static std::atomic<int> g_rpx{1};   // sbv2_debug_set_respair_clx
 int set_respair_clx(int on) { return g_rpx.exchange(on); }
 
 void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
@@ -475,23 +475,20 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(!p.mask || (p.mask_div > 0 && (p.mask_div & (p.mask_div - 1)) == 0), "respair: mask_div must be a power of two");
     p.mask_shift = 0;
     while (p.mask && (1 << p.mask_shift) < p.mask_div) ++p.mask_shift;
-    static const int alias = getenv("SBV2_RESPAIR_ALIAS") ? atoi(getenv("SBV2_RESPAIR_ALIAS")) : 1;   // A/B knob: 0 = separate x1 / x2 windows
-    p.alias_x2 = alias;
+    p.alias_x2 = 1;
     p.abl = 0;   // (ablations exist in the diagnostic instantiation only: launch_respair_cl_diag)
     SBV2_REQUIRE(p.C == 16 || p.C == 32 || p.C == 64, "respair: only the 16-, 32- and 64-channel stages are fused");
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
     if (p.N <= 0) return;
-    if (g_rpx.load(std::memory_order_relaxed) && respair_clx_usable(p)) return launch_respair_clx(p, stream);   // the round-4 kernel (same bits)
-    static const int persist = getenv("SBV2_RESPAIR_PERSIST") ? atoi(getenv("SBV2_RESPAIR_PERSIST")) : 0;
+    if (g_rpx.load(std::memory_order_relaxed) && respair_clx_usable(p)) return launch_respair_clx(p, stream);   // the round-4 kernel (same bits at C = 32 / 64; C = 16 sums two taps per MFMA: f32 rounding apart)
     SBV2_REQUIRE(!(p.split && p.f16), "respair: split and f16 are exclusive");
     if (p.C == 64) {
         if (p.split) launch_rp<PREC_BF16X3, false, 2>(p, stream);
         else if (p.f16) launch_rp<PREC_F16, false, 2>(p, stream);
         else launch_rp<PREC_BF16, false, 2>(p, stream);
     } else if (p.split) {
-        if (persist) launch_rp<PREC_BF16X3, true, 1>(p, stream);
-        else launch_rp<PREC_BF16X3, false, 1>(p, stream);
+        launch_rp<PREC_BF16X3, false, 1>(p, stream);
     } else if (p.f16) {
         launch_rp<PREC_F16, false, 1>(p, stream);
     } else {

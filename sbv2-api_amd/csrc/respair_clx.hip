@@ -4,7 +4,8 @@
 //
 // (HifiGanResidualBlock.forward, transformers modeling_vits.py:455-463 = modules.ResBlock1 upstream; the graph scripts/convert/convert_model.py:97-110
 // exports.)  Same arithmetic, operand split and per-accumulator summation order (chunk, tap, lo*hi, hi*lo, hi*hi) as respair_cl.hip / conv_cl.hip:
-// bit-identical results.  What changed is everything around the MFMAs, after the measurements in profiles/r04a_respair_cl_*:
+// bit-identical results at C = 32 / 64 (C = 16 multiplies two taps per 16x16x32 MFMA: another summation order, f32-grade; the tests hold it to 1e-5).
+// What changed is everything around the MFMAs, after the measurements in profiles/r04a_respair_cl_*:
 //   * respair_cl issues 1700 vector instructions per wave and 256-position tile beside its 168 MFMAs; VALU issue (4 cycles each) + MFMA busy time fill
 //     the SIMD completely at C <= 32 (428k + 309k of 726k cycles per SIMD), i.e. the kernel is bound by its own instruction count, and at C = 64 its
 //     one 8-wave workgroup per CU (134 KB of LDS) runs its phases one after the other (SIMD 77 % busy, 37 % of wave time parked).
@@ -110,7 +111,7 @@ struct RpxCfg {
 
 // DG >= 0: diagnostic instantiation (phase stamps of thread 0 into p.stamps[16 per workgroup]; sbv2_debug_respair_clock)
 template <int C, int NTAPS, int DG, int GT, int WNP = 0>
-__global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdgpu_waves_per_eu(C == 64 && GT == 4 && WNP == 0 ? 2 : 3))) void respair_clx_kernel(const ResPairParams p) {
+__global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdgpu_waves_per_eu(3))) void respair_clx_kernel(const ResPairParams p) {
     using K = RpxCfg<C, NTAPS, GT, WNP>;
     constexpr int T = K::T, NW = K::NW, WN = K::WN, RB = K::RB;
     constexpr bool DIAG = DG >= 0;
@@ -588,32 +589,16 @@ bool respair_clx_usable(const ResPairParams& p) {
 
 template <int DG>
 static void launch_rpx_any(const ResPairParams& p, hipStream_t stream) {
-    // taps per weight group at C = 64: 2 (default) = 52 KB of LDS, three workgroups per CU; 4 = 70 KB, two per CU and half the barriers
-    // (same box: 11.75 vs 12.3 ms per step for the stage, profiles/r04b_*)
-    static const int g64 = getenv("SBV2_RPX_G64") ? atoi(getenv("SBV2_RPX_G64")) : 2;
+    // taps per weight group at C = 64: 2 = 52 KB of LDS, three workgroups per CU (11.75 vs 12.3 ms per step for the stage against groups of 4 / two per CU;
+    // wider tiles on 6-wave workgroups measured 20-30 % slower: profiles/HISTORY.md)
 #define RPX_CASE(CC, KK) \
     if (p.C == CC && p.k == KK) return launch_rpx<CC, KK, DG, 4>(p, stream);
-    // experiments (measured, slower): wider tiles on 6-wave workgroups, two per CU: a third less weight traffic per FLOP and less halo, the same 12 waves
-    // per CU, and 20-30 % MORE time (C = 64, k = 7: 0.62 -> 0.77 ms per half-size launch; C = 32: 0.36 -> 0.47): three independent workgroups in
-    // different phases are worth more than what two larger ones save
-    static const int wn64 = getenv("SBV2_RPX_WN64") ? atoi(getenv("SBV2_RPX_WN64")) : 0;   // 3 = 192-position tiles on 6 waves at C = 64
-    static const int wn32 = getenv("SBV2_RPX_WN32") ? atoi(getenv("SBV2_RPX_WN32")) : 0;   // 6 = 384-position tiles on 6 waves at C = 32
-    if (p.C == 64 && wn64 == 3) {
-        if (p.k == 3) return launch_rpx<64, 3, DG, 2, 3>(p, stream);
-        if (p.k == 7) return launch_rpx<64, 7, DG, 2, 3>(p, stream);
-        if (p.k == 11) return launch_rpx<64, 11, DG, 2, 3>(p, stream);
-    }
-    if (p.C == 32 && wn32 == 6) {
-        if (p.k == 3) return launch_rpx<32, 3, DG, 4, 6>(p, stream);
-        if (p.k == 7) return launch_rpx<32, 7, DG, 4, 6>(p, stream);
-        if (p.k == 11) return launch_rpx<32, 11, DG, 4, 6>(p, stream);
-    }
-    if (p.C == 64 && g64 == 2) {
+    if (p.C == 64) {
         if (p.k == 3) return launch_rpx<64, 3, DG, 2>(p, stream);
         if (p.k == 7) return launch_rpx<64, 7, DG, 2>(p, stream);
         if (p.k == 11) return launch_rpx<64, 11, DG, 2>(p, stream);
     }
-    RPX_CASE(16, 3) RPX_CASE(16, 7) RPX_CASE(16, 11) RPX_CASE(32, 3) RPX_CASE(32, 7) RPX_CASE(32, 11) RPX_CASE(64, 3) RPX_CASE(64, 7) RPX_CASE(64, 11)
+    RPX_CASE(16, 3) RPX_CASE(16, 7) RPX_CASE(16, 11) RPX_CASE(32, 3) RPX_CASE(32, 7) RPX_CASE(32, 11)
 #undef RPX_CASE
     SBV2_REQUIRE(false, "respair_clx: shape not instantiated");
 }
@@ -621,9 +606,8 @@ static void launch_rpx_any(const ResPairParams& p, hipStream_t stream) {
 // p.mask_shift must be set (launch_respair_cl does it)
 void launch_respair_clx(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(respair_clx_usable(p0), "respair_clx: operands do not fit the kernel");
-    static const int late = getenv("SBV2_RPX_RRES_LATE") ? atoi(getenv("SBV2_RPX_RRES_LATE")) : 0;
     ResPairParams p = p0;
-    p.rres_late = late;
+    p.rres_late = 0;
     launch_rpx_any<-1>(p, stream);
 }
 void launch_respair_clx_diag(const ResPairParams& p0, hipStream_t stream) {

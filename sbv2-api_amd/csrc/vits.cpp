@@ -16,10 +16,10 @@
 
 namespace sbv2 {
 
-// keys / values of the flow's attention as pre-split bf16 planes for long sequences (SBV2_FLASH_PARTS = 1: from SBV2_FLASH_PARTS_MIN_T frames,
-// 2: at every length, 3: at every length on the un-pipelined kernel k_vits_flash_x3p, 4: at every length on k_vits_flash_x3q's 8-wave shape, 0: never = converted per key tile inside the attention kernel;
-// bit-identical; sbv2_debug_set_flash_parts for the test)
-static std::atomic<int> g_flash_parts{getenv("SBV2_FLASH_PARTS") ? atoi(getenv("SBV2_FLASH_PARTS")) : 1};
+// keys / values of the flow's attention as pre-split bf16 planes (sbv2_debug_set_flash_parts, for the test that holds the attention kernels to each other:
+// 1 = the default policy below, 2: at every length, 3: at every length on the un-pipelined kernel k_vits_flash_x3p, 4: at every length on k_vits_flash_x3q's
+// 8-wave shape, 0: never = converted per key tile inside the attention kernel; bit-identical)
+static std::atomic<int> g_flash_parts{1};
 bool flash_parts_enabled() { return g_flash_parts.load(std::memory_order_relaxed) != 0; }
 static int flash_parts_mode() { return g_flash_parts.load(std::memory_order_relaxed); }
 int set_flash_parts(int on) { return g_flash_parts.exchange(on); }
@@ -150,6 +150,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(blob.kind == 2, "weight container is not a VITS (kind 2) model");
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));  // never serialised against the NULL stream (e.g. RCCL launched by the caller)
+    f16x3_sat_prepare();
     const std::string& js = blob.config_json;
     auto I = [&](const char* k) { return (int)json_number(js, k); };
     cfg_.n_vocab = I("n_vocab"); cfg_.n_tones = I("n_tones"); cfg_.n_langs = I("n_langs"); cfg_.n_speakers = I("n_speakers");
@@ -185,14 +186,9 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     ws_.reset(new WeightStore(blob, gemm_parts));
     WeightStore& w = *ws_;
     // The text side decides the INTEGER durations (ceil(exp(logw) * length_scale)): text encoder and both duration predictors run on
-    // the exact-f32 kernels whatever SBV2_GEMM says.  SBV2_TEXT_GEMM=bf16x3 puts their k = 3 convolutions on the split-bf16 matrix cores:
-    // an EXPERIMENT knob (tests/flip_rate.py measures how many integer durations that flips; the result is in DESIGN.md §5).
-    int text_parts = 0;
-    if (const char* m = getenv("SBV2_TEXT_GEMM")) {
-        SBV2_REQUIRE(std::string(m) == "bf16x3" || std::string(m) == "f32" || !*m, "SBV2_TEXT_GEMM must be f32 or bf16x3");
-        if (std::string(m) == "bf16x3") text_parts = 2;
-    }
-    w.set_cl_parts(text_parts);
+    // the exact-f32 kernels whatever SBV2_GEMM says.  (Round 2 measured their k = 3 convolutions on the split-bf16 matrix cores behind a knob: one flipped
+    // duration per 102 800 symbols, tests/flip_rate.py; the knob is gone, the text side is exact f32.)
+    w.set_cl_parts(0);
     // every tensor's shape is checked against the config before a kernel indexes it (a container / imported ONNX whose config and
     // weights disagree is refused here)
     const int Hc = cfg_.hidden, Gc = cfg_.gin, Ic = cfg_.inter, Fd = cfg_.dp_filter;
@@ -244,7 +240,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     // gemm_bfs.hip with pre-split operands.  SBV2_FLOW_1X1=f32 keeps them on
     // the exact-f32 kernel; SBV2_GEMM=f32 does as well.
     // Operand format: f16x3 (f16 hi + scaled f16 lo: 22 mantissa bits, common.h) costs the same three MFMAs per product as bf16x3 and is
-    // 20x closer to the f32 product on these shapes (tests/bfs_probe.py), so it is the default; SBV2_FLOW_1X1=bf16x3 keeps the two-bf16 split.
+    // 20x closer to the f32 product on these shapes (tools/bfs_probe.py), so it is the default; SBV2_FLOW_1X1=bf16x3 keeps the two-bf16 split.
     int flow_bfs = gemm_parts == 2 && (Hc & 15) == 0 ? kPartsF16x3 : 0;
     if (const char* m = getenv("SBV2_FLOW_1X1")) {
         const std::string v(m);
@@ -319,7 +315,6 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
         else SBV2_REQUIRE(v.empty(), "SBV2_DECODER must be f32, bf16x3, bf16 or f16");
         SBV2_REQUIRE(dec_mode_ == 0 || cl_ok, "SBV2_DECODER: the bf16 MFMA decoder needs channel counts that are multiples of 16");
     }
-    if (const char* f = getenv("SBV2_FUSE_PAIRS")) fuse_pairs_ = atoi(f) != 0;
     if (dec_mode_) load_decoder_cl(blob);
 }
 
@@ -384,7 +379,7 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     Plane Q = QKV.rows(0, H), K = QKV.rows(H, H), ctx = ar.plane(H, N), Y = ar.plane(H, N);
     SBV2_REQUIRE(Q.ld == x.ld, "plane pitch mismatch");
     Plane F = ar.plane(e.layers[0].ffn1.cout, N);
-    static const bool cl_ffn = !(getenv("SBV2_FFN") && std::string(getenv("SBV2_FFN")) == "km");   // A/B knob
+    constexpr bool cl_ffn = true;
     const PackedConv& f1 = e.layers[0].ffn1;
     const PackedConv& f2 = e.layers[0].ffn2;
     float* Fcl = (cl_ffn && f1.cl.parts && f2.cl.parts && f1.k >= 3 && f2.k >= 3 && (f1.cout & 15) == 0) ? ar.array<float>((size_t)N * f1.cout) : nullptr;
@@ -406,11 +401,10 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     // Which kernel (same bits, so the choice is free).  The software-pipelined kernel on pre-split tiles (k_vits_flash_x3q, attn_flash.hip) at every size when
     // the head dimension fits its DMA blocks: 4-wave workgroups while they leave at most one per CU (a single utterance: 58 us per launch at 897 frames
     // against 84 for k_vits_flash_x3p and ~80 for the converting kernel), 8-wave workgroups beyond (32 x 897 frames: 84 us against 113; the q | k | v product
-    // then writes q as f32 and k / v as parts only: the same bytes).  Otherwise the un-pipelined pre-split kernel from SBV2_FLASH_PARTS_MIN_T frames (4096: at 897
+    // then writes q as f32 and k / v as parts only: the same bytes).  Otherwise the un-pipelined pre-split kernel from 4096 frames (at 897
     // frames x 32 it is slower than converting, 138 against 124 us; at 14 001 it wins) and for launches of <= 64 workgroups; the converting kernel for the rest.
     // set_flash_parts: 2 = parts at every length, 3 = ... on the un-pipelined kernel, 0 = never (the tests).
-    static const int parts_min_t = getenv("SBV2_FLASH_PARTS_MIN_T") ? atoi(getenv("SBV2_FLASH_PARTS_MIN_T")) : 4096;
-    static const int parts_max_wgs = getenv("SBV2_FLASH_PARTS_MAX_WGS") ? atoi(getenv("SBV2_FLASH_PARTS_MAX_WGS")) : 64;
+    constexpr int parts_min_t = 4096, parts_max_wgs = 64;
     const int64_t attn_wgs = (int64_t)((pl.maxT + 127) / 128) * pl.ng;
     const bool kv_parts = SP && split_attn && flash_parts_enabled() &&
                           ((flash_parts_mode() != 3 && flash_pipelined_usable(dk)) || pl.maxT >= parts_min_t || attn_wgs <= parts_max_wgs || flash_parts_mode() >= 2);
@@ -921,7 +915,7 @@ int64_t VitsModel::stream_begin(int chunk_frames) {
     HIP_CHECK(hipSetDevice(device_));
     SBV2_REQUIRE(fl_.n == 1 && z_.p, "stream_begin needs a preceding forward of ONE utterance with skip_decoder");
     SBV2_REQUIRE(chunk_frames >= 16 && chunk_frames <= (1 << 20), "chunk_frames must be in [16, 2^20]");
-    static const int burst = getenv("SBV2_STREAM_BURST") ? std::max(1, std::min(16, atoi(getenv("SBV2_STREAM_BURST")))) : kStreamBurst;
+    constexpr int burst = kStreamBurst;   // (1 / 2 / 4 / 8 / 12 / 16 windows per replay measured in round 3: 2.62 / 1.88 / 1.64 / 1.41 / 1.39 / 1.47 ms per chunk)
     const int64_t Tf = fl_.len[0];
     ensure_plan(chunk_, chunk_frames, 1);
     const bool want_burst = burst > 1 && Tf > chunk_frames;   // an utterance of one chunk never needs it

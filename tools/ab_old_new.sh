@@ -1,11 +1,11 @@
 # Builder tool (GPU box): same-box A/B of the committed HEAD (a git worktree built under build/ab_old) against the working tree: the conv_clx timeline of a
-# few shapes and the bench, alternating.   bash tests/ab_old_new.sh
+# few shapes and the bench, alternating.   bash tools/ab_old_new.sh
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 for rep in 1 2; do
   for side in old new; do
     if [ $side = old ]; then D=$R/build/ab_old; else D=$R; fi
-    ( cd $D && CLX_TL_SHAPES=${AB_SHAPES:-1,2,5} python3 tests/clx_timeline.py 0 2>/dev/null | python3 -c "
+    ( cd $D && CLX_TL_SHAPES=${AB_SHAPES:-1,2,5} python3 tools/clx_timeline.py 0 2>/dev/null | python3 -c "
 import json, sys
 for l in sys.stdin:
     d = json.loads(l)

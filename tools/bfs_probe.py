@@ -1,6 +1,6 @@
 """Builder tool (GPU box): the split-bf16 1x1 GEMM of gemm_bfs.hip (pre-split operands, LDS-DMA ring, transposing LDS reads) at the
 DeBERTa-large / flow batch shapes: error against an f64 reference and time per launch next to the exact-f32 tiled GEMM.
-  python tests/bfs_probe.py [quick]"""
+  python tools/bfs_probe.py [quick]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

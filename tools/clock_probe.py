@@ -1,7 +1,7 @@
 """Builder tool (GPU box): the in-kernel clock check of MI355X_MICROARCH.md ("DVFS give-back", item 6) on the dominant decoder convolution
 (conv_cl, 128-row workgroups, split-bf16): the kernel, the kernel without its MFMAs, its MFMAs alone, its staging alone.  If the three
 variants hold the same clock, the kernel's MFMA and staging halves adding up instead of overlapping is a scheduling problem, not power.
-  python tests/clock_probe.py [seconds]"""
+  python tools/clock_probe.py [seconds]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sbv2_api_amd import _lib

@@ -1,8 +1,8 @@
-# Builder tool (GPU box): the conv_clx timeline of the product build and of the ablation builds under build/abl_*/ (tests/clx_ablate.sh), alternating.
+# Builder tool (GPU box): the conv_clx timeline of the product build and of the ablation builds under build/abl_*/ (tools/clx_ablate.sh), alternating.
 R=$GRAFT_REPO_ROOT
 for rep in 1 2; do
   for D in $R $R/build/abl_*; do
-    ( cd $D && CLX_TL_SHAPES=${AB_SHAPES:-1,2} CLX_TL_KINDS=${AB_KINDS:-1} python3 tests/clx_timeline.py 0 2>/dev/null | python3 -c "
+    ( cd $D && CLX_TL_SHAPES=${AB_SHAPES:-1,2} CLX_TL_KINDS=${AB_KINDS:-1} python3 tools/clx_timeline.py 0 2>/dev/null | python3 -c "
 import json, sys
 for l in sys.stdin:
     d = json.loads(l)

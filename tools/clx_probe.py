@@ -1,5 +1,5 @@
 """Builder tool (GPU box): conv_clx.hip (pre-split operands, LDS-DMA rings) against conv_cl.hip on the wide decoder stages' ResBlock shapes:
-time per launch and bit equality.   python tests/clx_probe.py"""
+time per launch and bit equality.   python tools/clx_probe.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

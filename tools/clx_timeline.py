@@ -1,7 +1,7 @@
 """Builder tool (GPU box): where a conv_clx workgroup's life goes (sbv2_debug_clx_timeline): per shape and launch form the un-stamped launch time and,
 from the stamps of one launch, the medians of a workgroup's prologue / step loop / epilogue / store drain, the gap between one workgroup leaving a CU and
 the next entering it, and the average number of workgroups per CU that are inside their step loop.
-  python tests/clx_timeline.py [variant ...]"""
+  python tools/clx_timeline.py [variant ...]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

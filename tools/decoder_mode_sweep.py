@@ -3,7 +3,7 @@ For each decoder arithmetic (SBV2_DECODER = bf16x3 (default) | f16 | bf16 | f32)
 conv_post is scaled so that the waveform peaks near 0.9 (the synthetic generator's output otherwise peaks at ~0.1: an error of 1e-4 there is 1e-3
 RELATIVE), and compared with the C / OpenMP f32 oracle on the same weights; the unscaled weights are measured beside it.  Each mode is also benched
 (batch 32 x 128 phonemes, pipelined steps).  One JSON object per line; the whole output is kept as profiles/r04_decoder_mode_sweep.json.
-  python tests/decoder_mode_sweep.py [gain]         each mode runs in a child process (SBV2_DECODER is read when the model is created)"""
+  python tools/decoder_mode_sweep.py [gain]         each mode runs in a child process (SBV2_DECODER is read when the model is created)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builder tool: registers / scratch / LDS / occupancy of every kernel in a .hip source (compiler's own report), e.g.
-#   bash tests/kernel_resources.sh conv_clx.hip [name filter]
+#   bash tools/kernel_resources.sh conv_clx.hip [name filter]
 cd "$(dirname "$0")/../sbv2-api_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Rpass-analysis=kernel-resource-usage -c "$1" -o /tmp/kres_$$.o 2>&1 |
   python3 -c "

@@ -2,7 +2,7 @@
 captured hipGraph; prints one JSON line (kept under profiles/ as r02_longform*.json).
 The DeBERTa input has the front end's own length (one token per character: n_phones // 2 tokens, 1000 for 2000 phonemes; the reference itself
 splits on newlines, tts.rs:290-321, and its TensorRT profile caps BERT at 100 tokens, model.rs:14-16: pass a third argument to cap the characters).
-usage: python tests/long_form_check.py [n_phones] [chunk_frames] [chars]         env SBV2_STREAM_GRAPH=0 -> eager chunk decode (A/B)"""
+usage: python tools/long_form_check.py [n_phones] [chunk_frames] [chars]         env SBV2_STREAM_GRAPH=0 -> eager chunk decode (A/B)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,5 @@
 # Builder tool (GPU box): board power / shader clock while a command runs, sampled from the amdgpu hwmon files every 50 ms.
-#   bash tests/power_trace.sh <out.csv> <command ...>
+#   bash tools/power_trace.sh <out.csv> <command ...>
 OUT=$1; shift
 H=$(ls -d /sys/class/drm/card*/device/hwmon/hwmon* 2>/dev/null | head -1)
 echo "hwmon: $H" >&2

@@ -4,7 +4,7 @@ conv_post is scaled so that the waveform peaks near 0.9, and compared with the C
 "w16" rows round every decoder weight to an f16-representable value first (oracle and GPU alike): a single-pass f16 stage then multiplies EXACT weights
 by f16-rounded activations, which is the arithmetic of a two-pass f16 scheme x_hi * (w_hi + w_lo) - its error without building its kernel.
 Each assignment is also benched (batch 32 x 128 phonemes).  One JSON object per line -> profiles/r05_precision_map.json.
-  python tests/precision_map.py [gain]"""
+  python tools/precision_map.py [gain]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,5 @@
-"""Turns the raw rocprofv3 outputs of tests/prof_final.sh (gpurun_out/final_*) into the tracked summaries under profiles/.
-usage: python tests/prof_summarise.py <tag>      (e.g. r01i)"""
+"""Turns the raw rocprofv3 outputs of tools/prof_final.sh (gpurun_out/final_*) into the tracked summaries under profiles/.
+usage: python tools/prof_summarise.py <tag>      (e.g. r01i)"""
 import collections
 import csv
 import glob
@@ -34,7 +34,7 @@ def per_kernel(path, counters):
 
 
 shutil.copy(os.path.join(G, "final_bench.json"), P("bench.json"))
-for extra in ("mixed256", "b1_latency", "longform_c256", "longform_c256_burst1", "longform_c1024"):
+for extra in ("mixed256", "b1_latency", "longform_c256", "longform_c1024"):
     src = os.path.join(G, f"final_{extra}.json")
     if os.path.exists(src) and os.path.getsize(src) > 2:
         shutil.copy(src, P(f"{extra}.json"))
@@ -46,12 +46,26 @@ if fe and wr:
     F, W = per_kernel(fe, ["FETCH_SIZE"]), per_kernel(wr, ["WRITE_SIZE"])
     rows = ["kernel,launches,avg_us,FETCH_SIZE_KB_per_launch(raw),fetch_bytes_per_launch(x2 gfx950 correction),WRITE_SIZE_KB_per_launch,"
             "write_bytes_per_launch,hbm_GBps"]
-    for k in sorted(F, key=lambda k: -F[k][0] * F[k][1])[:14]:
+    # every kernel that takes >= 0.5 % of the pass's kernel time (the PMC pass runs the steps un-pipelined: launches / steps = launches per step), then the
+    # HBM bytes per step of the decoder's kernels (the channels-last family) and of everything
+    total_us = sum(F[k][0] * F[k][1] for k in F)
+    dec = lambda k: any(t in k for t in ("conv_clx_kernel", "respair_clx_kernel", "respair_cl_kernel", "conv_cl_kernel", "conv_cl_small", "k_conv_post_tanh",
+                                         "k_split_cl(", "k_clx_zero_halo", "k_add_segvec_cl", "k_transpose_out"))
+    ffn = lambda k: "conv_clx_kernel<5," in k
+    steps = int(os.environ.get("PMC_STEPS", "2"))   # bench.py --steps 1 --warmup 1
+    sums = {"decoder": 0.0, "all": 0.0}
+    for k in sorted(F, key=lambda k: -F[k][0] * F[k][1]):
         n, us, c = F[k]
         fkb = c["FETCH_SIZE"]
         wkb = W.get(k, (0, 0, {"WRITE_SIZE": 0.0}))[2]["WRITE_SIZE"]
         fb, wb = fkb * 1024 * 2, wkb * 1024
-        rows.append(f"\"{k[:110]}\",{n},{us:.1f},{fkb:.1f},{fb:.3e},{wkb:.1f},{wb:.3e},{(fb + wb) / (us * 1e-6) / 1e9:.0f}")
+        sums["all"] += (fb + wb) * n / steps
+        if dec(k) and not ffn(k):
+            sums["decoder"] += (fb + wb) * n / steps
+        if n * us >= 0.005 * total_us:
+            rows.append(f"\"{k[:110]}\",{n},{us:.1f},{fkb:.1f},{fb:.3e},{wkb:.1f},{wb:.3e},{(fb + wb) / (us * 1e-6) / 1e9:.0f}")
+    rows.append(f"\"TOTAL HBM bytes per step: HiFi-GAN decoder kernels\",,,,{sums['decoder']:.4e},,,")
+    rows.append(f"\"TOTAL HBM bytes per step: all kernels\",,,,{sums['all']:.4e},,,")
     open(P("pmc_hbm_traffic.csv"), "w").write("\n".join(rows) + "\n")
 mf = one("final_pmc_mfma/*/*counter_collection.csv")
 if mf:
@@ -59,8 +73,11 @@ if mf:
     M = per_kernel(mf, names)
     rows = ["kernel,launches,avg_us,MFMA_busy_cycles_per_launch,GRBM_GUI_ACTIVE_per_launch,mfma_util(busy/(1024 SIMD * GUI_ACTIVE/8)),"
             "SQ_WAIT_ANY/SQ_WAVE_CYCLES,LDS_bank_conflict/LDS_idx_active"]
-    for k in sorted(M, key=lambda k: -M[k][0] * M[k][1])[:12]:
+    total_us = sum(M[k][0] * M[k][1] for k in M)
+    for k in sorted(M, key=lambda k: -M[k][0] * M[k][1]):
         n, us, c = M[k]
+        if n * us < 0.005 * total_us:
+            continue
         cyc = c["GRBM_GUI_ACTIVE"] / 8
         rows.append(f"\"{k[:110]}\",{n},{us:.1f},{c['SQ_VALU_MFMA_BUSY_CYCLES']:.3e},{c['GRBM_GUI_ACTIVE']:.3e},"
                     f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) if cyc else 0:.3f},{c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1):.3f},"

@@ -1,5 +1,5 @@
 """Builder tool (GPU box): phase timeline + in-kernel clock + ablations of the fused ResBlock step (respair_cl.hip) on random data.
-  python tests/respair_probe.py [seconds]"""
+  python tools/respair_probe.py [seconds]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sbv2_api_amd import _lib

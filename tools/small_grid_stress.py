@@ -1,6 +1,6 @@
 """Builder tool (GPU box): race screen for the LDS-DMA kernels (gemm_skinny, its k > 1 twin, conv_cl_small).  Random shapes, many repetitions:
 every result must be bit-identical to the tiled kernels' (sbv2_debug_set_skinny_max(0)); a DMA that is read before it has landed, or a
-ring slot that is refilled too early, shows up as a rare mismatch.   usage: python tests/small_grid_stress.py [seconds]"""
+ring slot that is refilled too early, shows up as a rare mismatch.   usage: python tools/small_grid_stress.py [seconds]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
