@@ -226,6 +226,10 @@ int sbv2_debug_set_skinny_max(int workgroups);
 /* 1 (default): the ResBlocks of the wide decoder stages run on conv_clx.hip when the launch is large enough to pay for it; 2: always;
    0: on conv_cl.hip (same bits in every case).  Returns the previous value. */
 int sbv2_debug_set_clx(int on);
+/* 1 (default): gemm_bfs products on small grids (a single utterance's DeBERTa Linear layers: 32 - 128 workgroups) split their K loop over 2 or 4 groups of
+   waves inside the workgroup and add the partial sums in group order: another summation order than the batch's tiles, so a single call and its batch row
+   agree to f32 rounding; 0: the unsplit dispatch (batch row == single call bit for bit; the bit-equality tests run on it).  Returns the previous value. */
+int sbv2_debug_set_ksplit(int on);
 /* the flow's attention on keys / values pre-split by the q | k | v product: 1 (default) for sequences of >= 4096 frames and launches of <= 64
    workgroups, 2 at every length, 3 at every length on the un-pipelined kernel (k_vits_flash_x3p, the fallback for head dimensions that are no multiple
    of 8), 4 at every length on the pipelined kernel's 8-wave shape (the batch shape, forced for the test), 0 never (converted per key tile inside the

@@ -95,6 +95,7 @@ SYMBOLS = {
     "sbv2_debug_time_conv1d": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, f32p]),
     "sbv2_debug_set_skinny_max": (C.c_int, [C.c_int]),
     "sbv2_debug_set_clx": (C.c_int, [C.c_int]),
+    "sbv2_debug_set_ksplit": (C.c_int, [C.c_int]),
     "sbv2_debug_set_flash_parts": (C.c_int, [C.c_int]),
     "sbv2_debug_conv1d_clx": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                         C.c_int64, f32p, f32p, f32p]),

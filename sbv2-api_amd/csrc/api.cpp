@@ -460,6 +460,7 @@ int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float
 
 int sbv2_debug_set_skinny_max(int workgroups) { return set_skinny_max(workgroups); }
 int sbv2_debug_set_clx(int on) { return set_clx(on); }
+int sbv2_debug_set_ksplit(int on) { return set_ksplit(on); }
 int sbv2_debug_set_flash_parts(int on) { return set_flash_parts(on); }
 
 int sbv2_debug_conv1d_clx(int device, const float* x, const float* w, const float* bias, const float* res, int64_t cin, int64_t cout, int64_t k,
@@ -965,7 +966,15 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     ys.ld = ld;
     ys.pstride = (int64_t)M * ld;
     // split_out: 0 = f32 result only; 2 / 3 = the result is ALSO written as that many bf16 parts, and y returns their sum (what a consumer sees)
-    auto run = [&]() { conv_bfs(pc, xs, &Y, split_out ? &ys : nullptr, nullptr, 1, nullptr, act, res ? &R : nullptr); };
+    // (scratch for the small-grid K split, as DeBERTa's forward provides it)
+    DevBuf dsk(((size_t)8 << 20) / sizeof(float) + 256);
+    HIP_CHECK(hipMemset(dsk.p, 0, ((size_t)8 << 20) + 256 * sizeof(float)));
+    BfsSplitK sk;
+    sk.ws = dsk.p;
+    sk.ws_bytes = (size_t)8 << 20;
+    sk.counters = reinterpret_cast<unsigned*>(dsk.p + (((size_t)8 << 20) / sizeof(float)));
+    sk.ncounters = 256;
+    auto run = [&]() { conv_bfs(pc, xs, &Y, split_out ? &ys : nullptr, nullptr, 1, nullptr, act, res ? &R : nullptr, 1.0f, 1.0f, -1, 0, &sk); };
     run();
     HIP_CHECK(hipDeviceSynchronize());
     if (iters > 0 && ms) {

@@ -47,6 +47,8 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     SBV2_REQUIRE(blob.kind == 1, "weight container is not a DeBERTa (kind 1) model");
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));  // never serialised against the NULL stream (e.g. RCCL launched by the caller)
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sk_counters_), sizeof(unsigned) * kSkCounters));
+    HIP_CHECK(hipMemset(sk_counters_, 0, sizeof(unsigned) * kSkCounters));
     f16x3_sat_prepare();
     const std::string& js = blob.config_json;
     cfg_.vocab = (int)json_number(js, "vocab_size");
@@ -196,6 +198,9 @@ BertModel* BertModel::clone() const {
     BertModel* c = new BertModel(*this);   // shares ws_ (device weights); Arena copies are empty
     c->stream_ = nullptr;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
+    c->sk_counters_ = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c->sk_counters_), sizeof(unsigned) * kSkCounters));
+    HIP_CHECK(hipMemset(c->sk_counters_, 0, sizeof(unsigned) * kSkCounters));
     c->out_ = Plane{};
     c->layout_ = SegLayout{};
     return c;
@@ -204,6 +209,7 @@ BertModel* BertModel::clone() const {
 BertModel::~BertModel() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (sk_counters_) (void)hipFree(sk_counters_);
 }
 
 void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const int64_t* lens) {
@@ -212,6 +218,7 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
     TraceRange tr("deberta");
     HIP_CHECK(hipStreamSynchronize(stream_));  // pinned staging of the previous call must be drained before reuse
     arena_.reset();
+    arena_.begin_uploads();   // every table of the pass is uploaded before the first kernel (deberta_embed_ln below): held back, neighbours merged
     const int H = cfg_.hidden, nh = cfg_.heads, d = H / nh;
     const int span = cfg_.buckets > 0 ? cfg_.buckets : cfg_.max_rel;
     std::vector<int> L(n);
@@ -386,6 +393,7 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
 
     const float inv_scale = 1.0f / std::sqrt((float)d * 3.0f);  // c2p + p2c => scale_factor 3 (:226-232)
 
+    arena_.end_uploads();
     deberta_embed_ln(d_ids, emb_, H, emb_g_, emb_b_, cfg_.eps, X, stream_);
     fill_zero(ctx.p, sizeof(float) * (size_t)H * ctx.ld, stream_);  // alignment-gap columns are never written by P.V
     if (mask) {
@@ -426,11 +434,19 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         fl_tw += 2.0 * (double)a.T * wlen * d;
     }
 
+    // scratch for the K split of small grids (gemm_bfs.hip: a single utterance's products; larger grids ignore it)
+    BfsSplitK sk;
+    if (SP) {
+        sk.ws = static_cast<float*>(arena_.alloc(kSkWsBytes));
+        sk.ws_bytes = kSkWsBytes;
+        sk.counters = sk_counters_;
+        sk.ncounters = kSkCounters;
+    }
     if (SP) split_planes(X, Xs, stream_);
     for (int li = 0; li < cfg_.layers; ++li) {
         const Layer& Ly = layers_[li];
         // q | k | v in one product (k-major planes)
-        if (SP) conv_bfs(Ly.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_);
+        if (SP) conv_bfs(Ly.qkv, Xs, &QKV, nullptr, nullptr, 1, stream_, ACT_NONE, nullptr, 1.0f, 1.0f, -1, 0, &sk);
         else conv_plain(Ly.qkv, X, QKV, 1, 0, nullptr, 1, stream_);
         if (ngS)
             deberta_attention(d_agS, ngS, Q.p, Kp.p, QKV.ld, Vp.p, Ly.pos_k.p, Ly.pos_q.p, ldp, win_lo_s, wlen_s, d_tab, maxT - 1, span, inv_scale,
@@ -451,10 +467,10 @@ void BertModel::forward(int n, const int64_t* ids, const int64_t* mask, const in
         }
         if (SP) {
             split_planes(ctx, Cs, stream_);
-            conv_bfs(Ly.o, Cs, &A, nullptr, nullptr, 1, stream_, ACT_NONE, &X);
+            conv_bfs(Ly.o, Cs, &A, nullptr, nullptr, 1, stream_, ACT_NONE, &X, 1.0f, 1.0f, -1, 0, &sk);
             layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_, &As);
-            conv_bfs(Ly.ffn1, As, nullptr, &Fs, nullptr, 1, stream_, ACT_GELU);
-            conv_bfs(Ly.ffn2, Fs, &X, nullptr, nullptr, 1, stream_, ACT_NONE, &A);
+            conv_bfs(Ly.ffn1, As, nullptr, &Fs, nullptr, 1, stream_, ACT_GELU, nullptr, 1.0f, 1.0f, -1, 0, &sk);
+            conv_bfs(Ly.ffn2, Fs, &X, nullptr, nullptr, 1, stream_, ACT_NONE, &A, 1.0f, 1.0f, -1, 0, &sk);
         } else {
             conv_plain(Ly.o, ctx, A, 1, 0, nullptr, 1, stream_, ACT_NONE, 1.0f, &X);
             layernorm_ch(A, A, Ly.ln1_g, Ly.ln1_b, cfg_.eps, ACT_NONE, nullptr, 0, d_valid, stream_);

@@ -63,7 +63,7 @@ void Arena::release() {
 }
 void Arena::upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     if (!bytes) return;
-    const size_t need = (bytes + 63) / 64 * 64;
+    const size_t need = (bytes + 255) / 256 * 256;   // the device allocator's rounding: neighbours in the arena are neighbours in the staging buffer
     for (; pcur_ < pinned_.size(); ++pcur_)
         if (pinned_[pcur_].off + need <= pinned_[pcur_].cap) break;
     if (pcur_ == pinned_.size()) {
@@ -73,8 +73,28 @@ void Arena::upload(void* dst, const void* src, size_t bytes, hipStream_t stream)
     }
     Chunk& c = pinned_[pcur_];
     std::memcpy(c.base + c.off, src, bytes);
-    HIP_CHECK(hipMemcpyAsync(dst, c.base + c.off, bytes, hipMemcpyHostToDevice, stream));
+    if (defer_ > 0) {
+        if (!pending_.empty()) {
+            Pending& l = pending_.back();
+            const size_t lr = (l.bytes + 255) / 256 * 256;
+            if (l.stream == stream && l.dst + lr == static_cast<char*>(dst) && l.src + lr == c.base + c.off) {
+                l.bytes = lr + bytes;   // (the rounded tail of the previous buffer is padding on both sides)
+                c.off += need;
+                return;
+            }
+        }
+        pending_.push_back(Pending{static_cast<char*>(dst), c.base + c.off, bytes, stream});
+    } else {
+        HIP_CHECK(hipMemcpyAsync(dst, c.base + c.off, bytes, hipMemcpyHostToDevice, stream));
+    }
     c.off += need;
+}
+void Arena::end_uploads() {
+    if (--defer_ > 0) return;
+    defer_ = 0;
+    std::vector<Pending> todo;
+    todo.swap(pending_);
+    for (const Pending& q : todo) HIP_CHECK(hipMemcpyAsync(q.dst, q.src, q.bytes, hipMemcpyHostToDevice, q.stream));
 }
 void Arena::reset() {
     // The chunk list is normally kept as it is: a pass with the same shapes replays the same allocation sequence and lands on the same
@@ -92,6 +112,8 @@ void Arena::reset() {
     cur_ = 0;
     for (auto& c : pinned_) c.off = 0;  // callers guarantee the previous pass's copies are complete
     pcur_ = 0;
+    pending_.clear();   // (a pass that threw inside an upload bracket)
+    defer_ = 0;
 }
 void Arena::rewind(const Mark& m) {
     if (chunks_.empty()) return;
@@ -233,6 +255,10 @@ std::vector<std::vector<int>> json_int_array2(const std::string& js, const std::
     return out;
 }
 
+
+static std::atomic<int> g_ksplit{1};
+bool ksplit_enabled() { return g_ksplit.load(std::memory_order_relaxed) != 0; }
+int set_ksplit(int on) { return g_ksplit.exchange(on); }
 
 // ---- f16x3 saturation counter (diagnostics; common.h) ----------------------------------------------------------------------------------
 static std::atomic<int> g_sat_on{getenv("SBV2_F16X3_SATCOUNT") ? atoi(getenv("SBV2_F16X3_SATCOUNT")) : 0};

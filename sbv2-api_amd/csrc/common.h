@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,12 @@ class Arena {
     // Host -> device copy that never blocks the host: the bytes are staged in pinned memory owned by the arena (valid until
     // the next reset()) and copied asynchronously on `stream`.
     void upload(void* dst, const void* src, size_t bytes, hipStream_t stream);
+    // Between begin_uploads() and end_uploads() the copies of upload() are held back and issued together, neighbours merged: buffers that were allocated
+    // one after the other from this arena and uploaded in the same order are ONE copy (staging and device placement both step by the 256-byte rounded
+    // size; the padding travels along).  A single-utterance call issued 67 copies of 4 - 1028 bytes, 5 us of GPU time each.  Nothing that reads the
+    // buffers may be launched inside the bracket.  (UploadBatch is the scope guard.)
+    void begin_uploads() { ++defer_; }
+    void end_uploads();
     // recycles the pinned staging only (callers guarantee that every copy issued so far has completed)
     void reset_pinned() {
         for (auto& c : pinned_) c.off = 0;
@@ -102,6 +109,30 @@ class Arena {
     size_t last_used_ = 0, recent_peak_ = 0;
     std::vector<Chunk> pinned_;
     size_t pcur_ = 0;
+    struct Pending {
+        char* dst;
+        const char* src;
+        size_t bytes;
+        hipStream_t stream;
+    };
+    std::vector<Pending> pending_;
+    int defer_ = 0;
+};
+struct UploadBatch {
+    Arena& a;
+    explicit UploadBatch(Arena& arena) : a(arena) { a.begin_uploads(); }
+    ~UploadBatch() noexcept(false) {
+        if (std::uncaught_exceptions() == 0) {
+            a.end_uploads();
+        } else {
+            try {
+                a.end_uploads();
+            } catch (...) {   // already unwinding: the first error is the one reported
+            }
+        }
+    }
+    UploadBatch(const UploadBatch&) = delete;
+    UploadBatch& operator=(const UploadBatch&) = delete;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -301,6 +332,14 @@ struct BfsWeights {         // W as MFMA A fragments: [K / 16][nmt][parts][64 la
     int nmt = 0, parts = 0, M = 0, K = 0;
     int f16 = 0;            // as SplitPlanes::f16
 };
+// Scratch of an execution context for gemm_bfs' small-grid K split: `ws` holds the partial accumulators of one launch (any contents), `counters` one arrival
+// counter per output tile, ZERO between launches (the kernel leaves them zero).  Launches that share them must be ordered (one stream).
+struct BfsSplitK {
+    float* ws = nullptr;
+    size_t ws_bytes = 0;
+    unsigned* counters = nullptr;
+    int ncounters = 0;
+};
 struct GemmBfsParams {
     BfsWeights W;
     SplitPlanes X;
@@ -317,6 +356,7 @@ struct GemmBfsParams {
     int ldr = 0;
     const unsigned char* mask = nullptr;   // output column c is kept iff mask[c / mask_div]
     int mask_div = 1;
+    BfsSplitK sk;                          // optional scratch for the small-grid K split (gemm_bfs.hip)
 };
 bool gemm_bfs_usable(const GemmBfsParams& p);
 void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream);
@@ -417,6 +457,9 @@ int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv
 bool conv_clx_usable(const ConvClxParams& p);
 bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
 int set_clx(int on);  // returns the previous setting
+// gemm_bfs: small grids split their K loop over groups of waves (another summation order than the batch's tiles; 0 = the unsplit, batch-order dispatch)
+bool ksplit_enabled();
+int set_ksplit(int on);  // returns the previous setting
 bool clx_wanted(int64_t tiles, int64_t min_tiles);   // mode 1: launches of >= min_tiles tiles; mode 2: always; mode 0: never
 void launch_conv_clx(const ConvClxParams& p, hipStream_t stream);
 

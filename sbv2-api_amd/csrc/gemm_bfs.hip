@@ -45,6 +45,7 @@ struct BfsKernelParams {
     GemmBfsParams p;
     int mask_shift;
     int gm, gn, total;
+    int ksplit;   // SK instances: workgroups per output tile (total = gm * gn * ksplit)
 };
 
 template <int I, int N, class F>
@@ -83,7 +84,13 @@ __device__ __forceinline__ int bfs_swz(int k) {
     return 0;
 }
 
-template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false>
+// SK (round 5, small grids): a single utterance's DeBERTa products are 32 - 128 tiles on 256 CUs and each workgroup streams its tile's whole K range through
+// ONE CU's L2 -> LDS path: 10.8 us at K = 1024, 29.9 at K = 4096 (4.4 us + 0.1 us per 16-deep chunk = 2 MB at 70 GB/s; splitting the chunks over more waves of
+// the SAME workgroup changed nothing, tools/ksplit_probe.py).  With SK, kp.ksplit workgroups share a tile: workgroup (tile, g) multiplies the g-th contiguous
+// K / ksplit range, leaves its accumulators in p.sk.ws and counts itself in; the one that arrives last adds the ksplit partial sums IN GROUP ORDER (its own
+// included, from memory: the result does not depend on who was last) and runs the epilogue.  Another summation order than the unsplit kernel: a batch row and
+// the single-utterance call agree to f32 rounding instead of bit for bit (sbv2_debug_set_ksplit(0): the unsplit dispatch, which the bit-equality tests run on).
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false, bool SK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM * TN >= 4 ? 2 : (TM * TN == 2 && NSLOT <= 4 ? 3 : 1)))) void gemm_bfs_kernel(const BfsKernelParams kp) {
     static_assert(!F16 || PARTS == 2, "f16x3 has two planes");
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -104,12 +111,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs; each XCD walks a contiguous range of tiles (m fastest), so the
     // tiles co-resident on one L2 share their weight rows / activation columns.  Speed only.
     const int per = gridDim.x >> 3;
-    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (t >= kp.total) return;
+    const int t_all = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t_all >= kp.total) return;
+    const int ntile = kp.gm * kp.gn;
+    const int t = SK ? t_all % ntile : t_all;        // output tile
+    const int kg = SK ? t_all / ntile : 0;           // ... and which part of K
     const int tmi = t % kp.gm, tni = t / kp.gm;
     const int m0 = tmi * MT, n0 = tni * NT;
     const int M = p.M, N = p.N;
-    const int nchunks = p.K >> 4;
+    const int nchunks = SK ? (p.K >> 4) / kp.ksplit : p.K >> 4;   // (the launch checks divisibility)
 
     // ---- DMA descriptors: DMA g of a chunk (g < GA: weight fragment blocks, else 1 KB pieces of the activation parts) belongs to wave g % 4
     const char* src[PERW];
@@ -139,7 +149,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     // LDS destinations are wave-uniform (M0): made provably so once, or hipcc re-derives them per DMA with v_readfirstlane
     int sdst[PERW];
 #pragma unroll
-    for (int q = 0; q < PERW; ++q) sdst[q] = __builtin_amdgcn_readfirstlane(dst[q]);
+    for (int q = 0; q < PERW; ++q) {
+        sdst[q] = __builtin_amdgcn_readfirstlane(dst[q]);
+        if (SK) src[q] += (int64_t)kg * nchunks * step[q];
+    }
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     auto dma = [&](int q, int off) {   // DMA q of the next chunk to stage (chunk image at LDS offset off); advances its source pointer
         __builtin_amdgcn_global_load_lds((bfs_gbl_t*)src[q], (bfs_lds_t*)(uintptr_t)(lds0 + off + sdst[q]), 16, 0, 0);
@@ -309,6 +322,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     }
     if (c < nchunks) step_chunk(c, fa, fb, std::false_type{}, BarEven{});
     __syncthreads();   // the epilogue re-uses the ring as its transpose tiles
+    if constexpr (SK) {
+        // accumulators -> p.sk.ws[tile][group][wave][quad][lane] (16-byte cells: every store / load is 1 KB per wave, coalesced).  The partial sums cross
+        // XCDs (one L2 each).  Agent-scope fences around the count cost 25 us per launch (a release writes the XCD's whole L2 back, an acquire invalidates
+        // it: 37.9 us against the unsplit kernel's 11.1); instead every access to the scratch is itself agent-coherent (sc1: stores write through, loads
+        // are not served from this XCD's L2), like the counter's atomic.
+        constexpr int NQ = TM * TN * (F16 ? 8 : 4);
+        const int ks = kp.ksplit;
+        f32x4v* wsp = reinterpret_cast<f32x4v*>(p.sk.ws) + ((size_t)t * ks * 4 + wave) * (NQ * 64) + lane;
+        auto st = [](f32x4v* dst, const f32x4v& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory"); };
+        {
+            f32x4v* mine = wsp + (size_t)kg * 4 * (NQ * 64);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        st(mine + ((i * TN + j) * (F16 ? 8 : 4) + q) * 64, f32x4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+                        if (F16) st(mine + ((i * TN + j) * 8 + 4 + q) * 64, f32x4v{accx[i][j][4 * q], accx[i][j][4 * q + 1], accx[i][j][4 * q + 2], accx[i][j][4 * q + 3]});
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial sums are in memory ...
+        __syncthreads();                                    // ... every thread's are ...
+        int* arrived = reinterpret_cast<int*>(smem);
+        if (tid == 0) *arrived = (int)__hip_atomic_fetch_add(p.sk.counters + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
+        __syncthreads();
+        const bool last = *arrived == ks - 1;
+        if (!last) return;
+        if (tid == 0) __hip_atomic_store(p.sk.counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.f;
+                    if (F16) accx[i][j][r] = 0.f;
+                }
+        static_assert(TM * TN == 1, "the K split serves the small-grid configuration (one 32 x 32 tile per wave)");
+        // four groups' partial sums are requested before the first of them is added (two memory round trips for ks = 8 instead of eight), added in group order
+        constexpr int kBatch = 4;
+#pragma unroll 1
+        for (int g0 = 0; g0 < ks; g0 += kBatch) {
+            f32x4v v[kBatch][NQ];
+#pragma unroll
+            for (int gi = 0; gi < kBatch; ++gi)
+                if (g0 + gi < ks) {
+                    const f32x4v* src_g = wsp + (size_t)(g0 + gi) * 4 * (NQ * 64);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[gi][q]) : "v"(src_g + q * 64) : "memory");
+                }
+#pragma unroll
+            for (int gi = 0; gi < kBatch; ++gi)
+                if (g0 + gi < ks) {
+                    // (waits for everything requested: the first wait of a batch is the only one that waits)
+                    if constexpr (NQ == 8)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[gi][0]), "+v"(v[gi][1]), "+v"(v[gi][2]), "+v"(v[gi][3]), "+v"(v[gi][4]), "+v"(v[gi][5]), "+v"(v[gi][6]), "+v"(v[gi][7]));
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[gi][0]), "+v"(v[gi][1]), "+v"(v[gi][2]), "+v"(v[gi][3]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[0][0][4 * q + e] += v[gi][q][e];
+                            if (F16) accx[0][0][4 * q + e] += v[gi][4 + q][e];
+                        }
+                }
+        }
+        __syncthreads();   // (wave 0's transpose tile starts at smem: `arrived` has been read by everybody)
+    }
 
     // ---- epilogue: each wave passes its 32 x 32 tiles through a private LDS tile and leaves with 16-byte stores (8 lanes = 128 bytes of a row)
     float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 36);
@@ -471,16 +554,22 @@ bool gemm_bfs_usable(const GemmBfsParams& p) {
            (p.X.ld & 7) == 0 && (!p.Y || (p.ldy & 3) == 0) && (!p.R || (p.ldr & 3) == 0) && (!p.Ys.parts || (p.Ys.ld & 3) == 0) && p.N >= 4;
 }
 
-template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false>
-static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream) {
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false, bool SK = false>
+static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream, int ksplit = 1) {
     constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN;
     constexpr int SLOT = KSUB * ((MT / 32) * PARTS * 1024 + PARTS * 16 * NT * 2);
     const GemmBfsParams& p = kp.p;
     kp.gm = (p.M + MT - 1) / MT;
     kp.gn = (p.N + NT - 1) / NT;
-    kp.total = kp.gm * kp.gn;
+    kp.ksplit = SK ? ksplit : 1;
+    kp.total = kp.gm * kp.gn * kp.ksplit;
+    if (SK) {
+        constexpr size_t kPerWg = (size_t)4 * TM * TN * (F16 ? 8 : 4) * 1024;   // bytes of partial sums per workgroup
+        SBV2_REQUIRE((p.K >> 4) % ksplit == 0 && p.sk.ws && p.sk.counters && kp.gm * kp.gn <= p.sk.ncounters && (size_t)kp.total * kPerWg <= p.sk.ws_bytes,
+                     "gemm_bfs: K split without room for it");
+    }
     const size_t lds = std::max<size_t>((size_t)NSLOT * SLOT, 4 * 32 * 36 * sizeof(float));
-    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT, F16>;
+    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT, F16, SK>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -522,8 +611,20 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
         // round 4.  Same per-element summation order on every tile.  (Rounds 3-4 measured the other tile / ring shapes behind knobs: 128 x 128 everywhere,
         // 64 x 128 on 3 / 6 slots, 128 x 64, two chunks per barrier, 64 x 64 for the 1024-row products, 4 / 12 / 16 slots for small grids: all slower
         // or equal; profiles/HISTORY.md.)
-        if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
-        else launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
+        if (big) {
+            launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
+        } else {
+            // Small grids with a long K loop and scratch from the caller (DeBERTa's FFN down projection in a single-utterance call, K = 4096: 30.1 -> 12-18 us):
+            // up to 8 workgroups per tile, as many as keep the grid within one workgroup per CU and every group at >= 32 chunks: handing over and adding the
+            // partial sums costs 3 - 6 us, what 30 - 60 chunks take (K = 1024 split 2 - 8 ways measured 13.3 - 17.4 us against 11.1 - 12.3 unsplit)
+            const int64_t tiles = blocks(64, 64);
+            const int nch = p.K >> 4;
+            int ks = 1;
+            if (ksplit_enabled() && p.sk.ws && p.sk.counters && tiles <= p.sk.ncounters && nch >= 128)
+                while (ks < 8 && tiles * (ks * 2) <= 256 && nch % (ks * 2) == 0 && nch / (ks * 2) >= 32 && (size_t)tiles * (ks * 2) * 32768 <= p.sk.ws_bytes) ks *= 2;
+            if (ks > 1) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true, true>(kp, stream, ks);
+            else launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
+        }
     } else if (p.W.parts == 2) {   // bf16x3 (opt-in)
         if (!big) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8>(kp, stream);
         else if (k32 && lone) launch_bfs_cfg<2, 2, 2, 2, 2, 2, 4>(kp, stream);

@@ -255,6 +255,7 @@ SegLayout make_layout(const std::vector<int>& lens, int gap, Arena& arena, hipSt
     l.d_mask = arena.array<unsigned char>(l.L);
     l.d_start = arena.array<int>(l.n);
     l.d_len = arena.array<int>(l.n);
+    UploadBatch ub(arena);   // four neighbours: one copy
     arena.upload(l.d_seg_of, seg.data(), sizeof(int) * l.L, stream);
     arena.upload(l.d_mask, mask.data(), l.L, stream);
     arena.upload(l.d_start, l.start.data(), sizeof(int) * l.n, stream);
@@ -333,7 +334,7 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
 
 // 1x1 product on the bf16 matrix cores with pre-split operands (gemm_bfs.hip); y and / or ys receive the result.
 void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
-              hipStream_t s, int act, const Plane* res, float alpha, float beta, int y_rows, int ys_row0) {
+              hipStream_t s, int act, const Plane* res, float alpha, float beta, int y_rows, int ys_row0, const BfsSplitK* sk) {
     SBV2_REQUIRE(w.bfs.parts && w.k == 1 && xs.C == w.cin && xs.parts == w.bfs.parts && xs.f16 == w.bfs.f16, "conv_bfs: operands were not prepared for the split-bf16 kernel");
     GemmBfsParams p;
     p.W = w.bfs;
@@ -362,6 +363,7 @@ void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const 
     p.mask_div = mask_div;
     if (y_rows >= 0) p.y_rows = y_rows;
     p.ys_row0 = ys_row0;
+    if (sk) p.sk = *sk;
     launch_gemm_bfs(p, s);
 }
 

@@ -101,7 +101,8 @@ void conv_plain(const PackedConv& w, Plane x, Plane y, int dil, int pad_l, const
                 int accumulate = 0);
 // 1x1 product with pre-split bf16 operands (gemm_bfs.hip): y (f32 plane) and / or ys (bf16 parts) receive act(W x + b) * alpha (+ res) * beta
 void conv_bfs(const PackedConv& w, const SplitPlanes& xs, const Plane* y, const SplitPlanes* ys, const unsigned char* mask, int mask_div,
-              hipStream_t s, int act = ACT_NONE, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f, int y_rows = -1, int ys_row0 = 0);
+              hipStream_t s, int act = ACT_NONE, const Plane* res = nullptr, float alpha = 1.0f, float beta = 1.0f, int y_rows = -1, int ys_row0 = 0,
+              const BfsSplitK* sk = nullptr);
 // (y_rows >= 0: only rows < y_rows go to y; ys_row0: only rows >= ys_row0 go to ys)
 // y[n][m] (token-major) = x^T W + b : the "weights as B operand" form used for V^T
 bool conv_km_to_cl(const PackedConv& w, Plane x, float* y, int ldy, int dil, int pad_l, const unsigned char* mask, int mask_div,
@@ -155,6 +156,9 @@ class BertModel {
     std::vector<Layer> layers_;
     Arena arena_;
     hipStream_t stream_ = nullptr;
+    unsigned* sk_counters_ = nullptr;   // this context's arrival counters for gemm_bfs' small-grid K split (kSkCounters, zero between launches)
+    static constexpr int kSkCounters = 256;
+    static constexpr size_t kSkWsBytes = (size_t)8 << 20;
     Plane out_;
     SegLayout layout_;
 };

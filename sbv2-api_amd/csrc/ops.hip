@@ -92,6 +92,20 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
             xv[k] = c < C ? val(c) : 0.f;
         }
     }
+    // gamma / beta / residual of every owned channel are requested with the values (the compiler keeps loads behind a barrier where they are written: behind
+    // the two reductions they were a second dependent memory round trip of the launch, 1 - 2 us of the 8 - 11 us a single-utterance LayerNorm takes) and
+    // before the first store: a load issued after a store is not usable until that store is acknowledged (in-order vmcnt)
+    constexpr bool PRE = CPT > 0 && CPT <= 32;
+    float gv[PRE ? NV : 1], bv[PRE ? NV : 1], rv[PRE ? NV : 1];
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = min(ty + G * k, C - 1);
+            gv[k] = gamma[c];
+            bv[k] = beta[c];
+            rv[k] = res ? res[(size_t)c * ldr + nc] : 0.f;
+        }
+    }
     float s = 0.f;
     if (CPT > 0) {
 #pragma unroll
@@ -140,17 +154,7 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
         if (res) v += res[(size_t)c * ldr + n];
         put(c, keep ? v : 0.f);
     };
-    if (CPT > 0 && CPT <= 32) {
-        // gamma / beta / residual of every owned channel are read before the first store: a load issued after a store is not usable
-        // until that store is acknowledged (in-order vmcnt), which made this loop one store round trip per channel
-        float gv[NV], bv[NV], rv[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int c = min(ty + G * k, C - 1);
-            gv[k] = gamma[c];
-            bv[k] = beta[c];
-            rv[k] = res ? res[(size_t)c * ldr + n] : 0.f;
-        }
+    if (PRE) {
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             if (ty + G * k < C) {

@@ -73,9 +73,12 @@ AttnPlan make_attn_plan(const SegLayout& lay, int H, int heads, int ld, int wind
     pl.d_ag = ar.array<AttnGroup>(pl.ng);
     pl.d_st = ar.array<GemmGroup>(pl.ng);
     pl.d_pv = ar.array<GemmGroup>(pl.ng);
-    ar.upload(pl.d_ag, ag.data(), sizeof(AttnGroup) * pl.ng, stream);
-    ar.upload(pl.d_st, st.data(), sizeof(GemmGroup) * pl.ng, stream);
-    ar.upload(pl.d_pv, pv.data(), sizeof(GemmGroup) * pl.ng, stream);
+    {
+        UploadBatch ub(ar);
+        ar.upload(pl.d_ag, ag.data(), sizeof(AttnGroup) * pl.ng, stream);
+        ar.upload(pl.d_st, st.data(), sizeof(GemmGroup) * pl.ng, stream);
+        ar.upload(pl.d_pv, pv.data(), sizeof(GemmGroup) * pl.ng, stream);
+    }
     return pl;
 }
 
@@ -644,17 +647,19 @@ void VitsModel::forward(const VitsBatch& b) {
     int* d_lg = ar.array<int>(Lt);
     int* d_sid = ar.array<int>(n);
     int* d_uid = ar.array<int>(n);
+    float* d_style = ar.array<float>((size_t)n * cfg_.style_dim);
     {
+        // six neighbours in the arena, uploaded in allocation order: one copy (Arena::begin_uploads)
+        UploadBatch ub(ar);
         std::vector<int> uid(n);
         for (int u = 0; u < n; ++u) uid[u] = b.utt_ids ? (int)b.utt_ids[u] : b.utt0 + u;
+        ar.upload(d_ph, ph.data(), sizeof(int) * Lt, stream_);
+        ar.upload(d_tn, tn.data(), sizeof(int) * Lt, stream_);
+        ar.upload(d_lg, lg.data(), sizeof(int) * Lt, stream_);
+        ar.upload(d_sid, sid.data(), sizeof(int) * n, stream_);
         ar.upload(d_uid, uid.data(), sizeof(int) * n, stream_);
+        ar.upload(d_style, b.styles, sizeof(float) * (size_t)n * cfg_.style_dim, stream_);
     }
-    float* d_style = ar.array<float>((size_t)n * cfg_.style_dim);
-    ar.upload(d_ph, ph.data(), sizeof(int) * Lt, stream_);
-    ar.upload(d_tn, tn.data(), sizeof(int) * Lt, stream_);
-    ar.upload(d_lg, lg.data(), sizeof(int) * Lt, stream_);
-    ar.upload(d_sid, sid.data(), sizeof(int) * n, stream_);
-    ar.upload(d_style, b.styles, sizeof(float) * (size_t)n * cfg_.style_dim, stream_);
 
     Plane bert = ar.plane(cfg_.bert_dim, Lt);
     if (b.bert_host) {
@@ -775,6 +780,7 @@ void VitsModel::forward(const VitsBatch& b) {
     }
     // (frame count rounded to 32: every plane of the decoder's wide stages - 8 and 64 positions per frame - is then a whole number of conv_clx's 256-position
     // tiles, and the kernel instance without the guarded last-tile epilogue applies)
+    ar.begin_uploads();   // the layout's four arrays and the token map: neighbours, one copy
     fl_ = make_layout(Tf, kFrameGap, ar, stream_, nullptr, 32);
     const SegLayout& fl = fl_;
     const int Lf = fl.L;
@@ -786,6 +792,7 @@ void VitsModel::forward(const VitsBatch& b) {
     }
     int* d_tok = ar.array<int>(Lf);
     ar.upload(d_tok, tok.data(), sizeof(int) * Lf, stream_);
+    ar.end_uploads();
 
     // ---- alignment expansion + prior sample ---------------------------------------------------------------
     tr.reset();

@@ -112,7 +112,7 @@ def test_respair_clx_kernel_same_bits_as_respair_cl(C, k, dil, N):
     assert not np.any(got[np.repeat(mask, 4)[:N] == 0])
 
 
-def _gemm_bfs(x, w, b, r, parts, act=0, split_out=0):
+def _gemm_bfs(x, w, b, r, parts, act=0, split_out=0, iters=0):
     m, k = w.shape
     n = x.shape[1]
     y = np.empty((m, n), np.float32)
@@ -120,7 +120,8 @@ def _gemm_bfs(x, w, b, r, parts, act=0, split_out=0):
     xs, ws = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(w, np.float32)
     bs = None if b is None else np.ascontiguousarray(b, np.float32)
     rs = None if r is None else np.ascontiguousarray(r, np.float32)
-    _lib.check(_lib.lib().sbv2_debug_gemm_bfs(0, P(xs), P(ws), P(bs), P(rs), m, n, k, parts, act, split_out, 0, y.ctypes.data_as(f32p), None))
+    ms = C.c_float()
+    _lib.check(_lib.lib().sbv2_debug_gemm_bfs(0, P(xs), P(ws), P(bs), P(rs), m, n, k, parts, act, split_out, iters, y.ctypes.data_as(f32p), C.byref(ms)))
     return y
 
 
@@ -155,6 +156,35 @@ def test_gemm_bfs_kernel(K, M, N):
         assert float(np.abs(y3s - g).max()) < 1e-4
         yhs = _gemm_bfs(x, w, None, None, 4, act=2, split_out=4)     # ... and as the f16 pair: 2^-22 relative
         assert float(np.abs(yhs - g).max()) < max(8 * err32, 2e-5)
+
+
+@pytest.mark.parametrize("K,M,N", [(1024, 1024, 68), (1024, 3072, 68), (1024, 4096, 68), (4096, 1024, 68), (4096, 1024, 132), (2048, 192, 260)])
+def test_gemm_bfs_small_grid_k_split(K, M, N):
+    """gemm_bfs' small-grid K split (SK: several workgroups per output tile, the last one to arrive adds the partial sums in group order): against the f64
+    product and the unsplit kernel (sbv2_debug_set_ksplit(0)), the same bits on every repetition (the order of the sum does not depend on which workgroup
+    arrives last) and arrival counters that are zero again after every launch (otherwise the second launch would add garbage or never finish its tiles)."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(K + M + N)
+    x = rng.standard_normal((K, N)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    ref = w.astype(np.float64) @ x.astype(np.float64) + b[:, None] + r
+    err32 = float(np.abs((w @ x + b[:, None] + r).astype(np.float32) - ref).max())
+    prev = lib.sbv2_debug_set_ksplit(1)
+    try:
+        first = _gemm_bfs(x, w, b, r, 4, iters=25)        # 26 launches on the same scratch, the last one's result
+        assert float(np.abs(first - ref).max()) < max(8 * err32, 2e-5)
+        for _ in range(3):
+            np.testing.assert_array_equal(_gemm_bfs(x, w, b, r, 4), first)
+        lib.sbv2_debug_set_ksplit(0)
+        unsplit = _gemm_bfs(x, w, b, r, 4)
+        assert float(np.abs(unsplit - ref).max()) < max(8 * err32, 2e-5)
+        d = float(np.abs(first - unsplit).max())
+        print(f"gemm_bfs K split vs unsplit ({K} x {M} x {N}): max-abs {d:.2e}")
+        assert d < 2e-5
+    finally:
+        lib.sbv2_debug_set_ksplit(prev)
 
 
 def test_gemm_bfs_f16x3_range():
@@ -325,10 +355,23 @@ def test_deberta_full_shape_mid_lengths_vs_oracle():
     rng = np.random.default_rng(7)
     seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], n), [2]]) for n in (98, 20, 126, 63, 150)]
     batch = model.predict_batch(s, seqs)
+    prev = _lib.lib().sbv2_debug_set_ksplit(0)      # the unsplit dispatch: one summation order whatever the grid
+    try:
+        batch0 = model.predict_batch(s, seqs)
+        single0 = {k: model.predict(s, seqs[k], np.ones_like(seqs[k])) for k in (0, 2, 4)}
+    finally:
+        _lib.lib().sbv2_debug_set_ksplit(prev)
     for k in (0, 2, 4):     # 100 and 128 tokens: the tiled fused attention; 152 tokens: the key-tile loop (attn_deberta.hip, > 128) at the full shape
         ref = O.deberta_forward(W, cfg, seqs[k])
         np.testing.assert_allclose(batch[k], ref, atol=2e-4, rtol=0)
-        np.testing.assert_array_equal(model.predict(s, seqs[k], np.ones_like(seqs[k])), batch[k])
+        np.testing.assert_array_equal(single0[k], batch0[k])
+        # default dispatch: small grids split K over several workgroups (gemm_bfs.hip SK, round 5; this 470-token batch is small enough to split two ways,
+        # the single call up to eight ways): f32-rounding agreement between the single call and its batch row
+        single = model.predict(s, seqs[k], np.ones_like(seqs[k]))
+        np.testing.assert_allclose(single, ref, atol=2e-4, rtol=0)
+        d = float(np.abs(single - batch[k]).max())
+        print(f"DeBERTa full shape, {len(seqs[k])} tokens: single call vs batch row under the default (K split) dispatch max-abs {d:.2e}")
+        assert d < 5e-5
     s.close()
 
 def test_deberta_long_attention_key_tile_loop(bert_tiny):
@@ -705,6 +748,7 @@ def test_config2_b32_u128_default_path():
     assert len(pcms) == 32
     lib = _lib.lib()
     prev = lib.sbv2_debug_set_clx(0)     # everything on conv_cl: batch row == single call, bit for bit
+    prev_ks = lib.sbv2_debug_set_ksplit(0)   # ... and the single call's DeBERTa products on the batch's summation order (no K split)
     try:
         b0 = pipe.prepare(utts, forced=True)
         pipe.run(b0)
@@ -715,6 +759,7 @@ def test_config2_b32_u128_default_path():
             np.testing.assert_array_equal(pipe.fetch(b1)[0], pcms_cl[i])
     finally:
         lib.sbv2_debug_set_clx(prev)
+        lib.sbv2_debug_set_ksplit(prev_ks)
     worst_row = 0.0
     for i, (u, got) in enumerate(zip(utts, pcms)):   # the default dispatch (a single call's 256-channel stage is too small for conv_clx, the batch's is not)
         assert got.shape == (512 * 897,) and np.isfinite(got).all() and np.abs(got).max() < 1.0
