@@ -349,7 +349,7 @@ def main():
                         "respair_cl<C=64>": ("respair_clx_kernel<64,", "respair_cl_kernel<1, false, 2"),
                         "gemm_bfs<bf16x3>": ("gemm_bfs_kernel<2,",),
                         "gemm_bfs<bf16x6>": ("gemm_bfs_kernel<3,",),
-                        "gemm_bfs<f16x3>": ("true>(sbv2::BfsKernelParams)",),
+                        "gemm_bfs<f16x3>": ("true, false>(sbv2::BfsKernelParams)", "true, true>(sbv2::BfsKernelParams)", "true>(sbv2::BfsKernelParams)"),
                         "gemm_skinny<16x16x4>": ("gemm_skinny",)}.get(dom["kernel"])
                 if want is None and dom["kernel"].startswith("conv_gemm<"):
                     want = ("conv_gemm_kernel<" + dom["kernel"][len("conv_gemm<"):-1].replace(",", ", "),)

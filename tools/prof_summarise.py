@@ -41,6 +41,9 @@ for extra in ("mixed256", "b1_latency", "longform_c256", "longform_c1024"):
 st = one("final_stats/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, P("bench_kernel_stats.csv"))
+b1 = one("final_b1_stats/*/*kernel_stats.csv")
+if b1:
+    shutil.copy(b1, P("b1_kernel_stats.csv"))   # 45 single-utterance calls (5 warm-up + 40 timed) under the tracer
 fe, wr = one("final_pmc_fetch/*/*counter_collection.csv"), one("final_pmc_write/*/*counter_collection.csv")
 if fe and wr:
     F, W = per_kernel(fe, ["FETCH_SIZE"]), per_kernel(wr, ["WRITE_SIZE"])
@@ -52,7 +55,7 @@ if fe and wr:
     dec = lambda k: any(t in k for t in ("conv_clx_kernel", "respair_clx_kernel", "respair_cl_kernel", "conv_cl_kernel", "conv_cl_small", "k_conv_post_tanh",
                                          "k_split_cl(", "k_clx_zero_halo", "k_add_segvec_cl", "k_transpose_out"))
     ffn = lambda k: "conv_clx_kernel<5," in k
-    steps = int(os.environ.get("PMC_STEPS", "2"))   # bench.py --steps 1 --warmup 1
+    steps = int(os.environ.get("PMC_STEPS", "3"))   # bench.py --steps 1 --warmup 1 + its instrumented roofline step
     sums = {"decoder": 0.0, "all": 0.0}
     for k in sorted(F, key=lambda k: -F[k][0] * F[k][1]):
         n, us, c = F[k]
