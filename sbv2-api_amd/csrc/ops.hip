@@ -61,6 +61,9 @@ void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamm
 // ------------------------------------------------------------------------------------------------
 // CPT > 0: every thread keeps its <= CPT channel values in registers, so the plane is read once (the value is needed three times: mean,
 // centred sum of squares, output); CPT == 0: generic fallback that re-reads it.  Same operations in the same order either way.
+#ifndef LN_EARLY_MAX
+#define LN_EARLY_MAX 24   // (-DLN_EARLY_MAX=32 / 0: the A/B builds of tools/, see the comment in the kernel)
+#endif
 template <bool DW, int CPT, int COLS>
 __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps,
                                                        int act, const float* res, int ldr, const unsigned char* mask,
@@ -95,17 +98,20 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     // gamma / beta / residual of every owned channel are requested with the values (the compiler keeps loads behind a barrier where they are written: behind
     // the two reductions they were a second dependent memory round trip of the launch, 1 - 2 us of the 8 - 11 us a single-utterance LayerNorm takes) and
     // before the first store: a load issued after a store is not usable until that store is acknowledged (in-order vmcnt)
-    constexpr bool PRE = CPT > 0 && CPT <= 32;
+    // (up to 24 channels per thread: with 32, i.e. 128 loads in flight against a 6-bit vmcnt, the single-utterance DeBERTa LayerNorm got SLOWER, 10.7 -> 12.4 us:
+    // it keeps requesting them behind the reductions)
+    constexpr bool PRE = CPT > 0 && CPT <= 32, EARLY = CPT > 0 && CPT <= LN_EARLY_MAX;
     float gv[PRE ? NV : 1], bv[PRE ? NV : 1], rv[PRE ? NV : 1];
-    if (PRE) {
+    auto load_params = [&]() {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
+        for (int k = 0; k < (PRE ? NV : 1); ++k) {
             const int c = min(ty + G * k, C - 1);
             gv[k] = gamma[c];
             bv[k] = beta[c];
             rv[k] = res ? res[(size_t)c * ldr + nc] : 0.f;
         }
-    }
+    };
+    if (EARLY) load_params();
     float s = 0.f;
     if (CPT > 0) {
 #pragma unroll
@@ -155,6 +161,7 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
         put(c, keep ? v : 0.f);
     };
     if (PRE) {
+        if (!EARLY) load_params();   // (still before the first store)
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             if (ty + G * k < C) {
