@@ -220,11 +220,12 @@ int sbv2_prof_end(char* json, int64_t cap);
 /* Times `iters` launches of one dilated conv (device buffers, random data) and returns the mean kernel time in ms. */
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters,
                            float* ms);
-/* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; the
- * default comes from SBV2_SKINNY_MAX).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
+/* Small-grid threshold of the f32 GEMM (workgroups of the 64 x 64 tiling below which the one-wave 16 x 16 kernel runs; 0 = never; default
+ * 128).  Returns the previous value; tests use it to compare both kernels bit for bit in one process. */
 int sbv2_debug_set_skinny_max(int workgroups);
-/* 1 (default): the ResBlocks of the wide decoder stages run on conv_clx.hip when the launch is large enough to pay for it; 2: always;
-   0: on conv_cl.hip (same bits in every case).  Returns the previous value. */
+/* 1 (default): the ResBlocks of the wide decoder stages run on conv_clx.hip when the launch has >= 128 tiles; 2: always; 0: on conv_cl.hip.
+   The two kernels sum in different orders (round 5: conv_clx on 16 x 16 x 32 MFMAs) and agree to f32 rounding; with 0 (and sbv2_debug_set_ksplit(0)) every
+   launch size takes the same kernels and a batch row equals its single-utterance call bit for bit.  Returns the previous value. */
 int sbv2_debug_set_clx(int on);
 /* 1 (default): gemm_bfs products on small grids (a single utterance's DeBERTa Linear layers: 32 - 128 workgroups) split their K loop over 2 or 4 groups of
    waves inside the workgroup and add the partial sums in group order: another summation order than the batch's tiles, so a single call and its batch row
@@ -233,7 +234,7 @@ int sbv2_debug_set_ksplit(int on);
 /* the flow's attention on keys / values pre-split by the q | k | v product: 1 (default) for sequences of >= 4096 frames and launches of <= 64
    workgroups, 2 at every length, 3 at every length on the un-pipelined kernel (k_vits_flash_x3p, the fallback for head dimensions that are no multiple
    of 8), 4 at every length on the pipelined kernel's 8-wave shape (the batch shape, forced for the test), 0 never (converted per key tile inside the
-   attention kernel); bit-identical; returns the previous setting (SBV2_FLASH_PARTS) */
+   attention kernel); bit-identical; returns the previous setting */
 int sbv2_debug_set_flash_parts(int on);
 /* Same contract as sbv2_debug_conv1d_cl (mode 1) through conv_clx.hip: x is split into bf16 parts of lrelu(x, pre_slope) first (split_cl), the
    convolution reads the parts; y = (conv + bias + res) * beta; ys_sum (optional) = hi + lo of the parts of lrelu(y, 0.1) the epilogue emits. */
@@ -256,7 +257,7 @@ int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, 
    allocated from then on (-1: leave as is; the SBV2_F16X3_SATCOUNT=1 environment variable switches it on from the start); *count (optional) receives the
    number of clamped values since the last call, on `device`.  A non-zero count on a real checkpoint means: run with SBV2_BERT_GEMM=bf16x6. */
 int sbv2_debug_f16x3_saturation(int device, int enable, uint64_t* count);
-/* 1 (default, SBV2_RESPAIR_CLX): the fused ResBlock steps of the <= 64-channel decoder stages run on respair_clx.hip (split-bf16, k in {3, 7, 11});
+/* 1 (default): the fused ResBlock steps of the <= 64-channel decoder stages run on respair_clx.hip (split-bf16, k in {3, 7, 11});
    0: on respair_cl.hip (same bits).  Returns the previous value. */
 int sbv2_debug_set_respair_clx(int on);
 /* One fused ResBlock1 step y' = beta (conv2(lrelu(conv1(lrelu(x), dilation) + b1)) + b2 + x) [+ y when accumulate], masked by mask[n / mask_div] (may be

@@ -876,7 +876,7 @@ __device__ __forceinline__ void fq_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// DG: builder's timeline variant (SBV2_FLASH_Q_STAMPS=<file>): s_memtime at every barrier / phase boundary of every wave of workgroup (0, 0), kept in LDS
+// DG: builder's timeline variant (a diagnostic instantiation, not launched by the product path): s_memtime at every barrier / phase boundary of every wave of workgroup (0, 0), kept in LDS
 template <int DT, int NW, bool DG = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vits_flash_x3q(const AttnGroup* groups, const float* Q, int ld, const __bf16* Kp, const __bf16* Vp,
                                                               int64_t pstride, int ldp, float* ctx, int ldc, int dk, const float* erk, const float* erv,

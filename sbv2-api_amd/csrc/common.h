@@ -482,7 +482,7 @@ struct ResPairParams {
     int alias_x2 = 1;      // set by launch_respair_cl: the intermediate window re-uses the conv1 window's LDS
     int abl = 0;           // diagnostics (wrong results): 1 = every global read hits the same few cache-hot rows, 2 = no global stores; diag kernel only: 4 = no MFMAs, 8 = no conv1 window conversion, 16 = no intermediate epilogue
     unsigned long long* stamps = nullptr;   // diag kernel only: 16 per workgroup
-    int rres_late = 0;     // respair_clx A/B knob (SBV2_RPX_RRES_LATE=1): request the residual rows before conv2 (rounds 1-3) instead of with the window
+    int rres_late = 0;     // respair_clx diagnostics only (sbv2_debug_respair_clock): request the residual rows before conv2 (rounds 1-3) instead of with the window
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);
 void launch_respair_cl_diag(const ResPairParams& p, hipStream_t stream);
@@ -491,6 +491,6 @@ void launch_respair_cl_diag(const ResPairParams& p, hipStream_t stream);
 bool respair_clx_usable(const ResPairParams& p);          // p.mask_shift set
 void launch_respair_clx(const ResPairParams& p, hipStream_t stream);
 void launch_respair_clx_diag(const ResPairParams& p, hipStream_t stream);
-int set_respair_clx(int on);   // returns the previous setting (default: SBV2_RESPAIR_CLX, 1)
+int set_respair_clx(int on);   // returns the previous setting (default 1)
 
 }  // namespace sbv2

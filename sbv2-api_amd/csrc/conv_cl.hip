@@ -19,7 +19,7 @@
 // contains no global memory operation and no barrier: B fragments are plain shifted rows of the window.  Global loads for chunk
 // c+1 are issued before the MFMA loop of chunk c and written to LDS after it (two barriers per chunk).
 // Channels-last to channels-last launches whose row tiles pair up (Cout >= 128) run 8 waves = 128 rows x 256 positions per workgroup
-// (template WM = 2): both 64-row wave groups read the one staged window (measured: -4.5 ms of a 112 ms step, SBV2_CL_WM=1 is the A/B).
+// (template WM = 2): both 64-row wave groups read the one staged window (measured in round 2: -4.5 ms of a 112 ms step).
 #include <type_traits>
 
 #include "common.h"

@@ -358,7 +358,7 @@ class VitsModel {
     float* dec_cond_vec_ = nullptr;  // cond(g) per utterance of the running forward
     int dec_post_k_ = 7;
     std::vector<Stage> stages_;
-    bool fuse_pairs_ = true;  // SBV2_FUSE_PAIRS=0 disables the fused ResBlock step of the 16/32-channel stages
+    bool fuse_pairs_ = true;  // the fused ResBlock step of the <= 64-channel stages (always on in the product; false only in kernel tests)
     int dec_mode_ = 0;  // 0 = exact f32 MFMA (k-major), 1 = split-bf16 (f32-grade), 2 = plain bf16, 3 = fp16 operands
     ClConv cl_pre_;
     std::vector<ClStage> cl_stages_;

@@ -46,7 +46,7 @@ void deberta_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, c
 void vits_softmax(const AttnGroup* groups, int ngroups, int maxT, float* S, const float* Q, int ldq, int dk,
                   const float* erk, int window, float qscale, float* pwin, hipStream_t s);
 // fused QK^T + relative-key term + online softmax + PV + relative-value term (attn_flash.hip); Q, K, V, ctx: k-major planes
-bool flash_pipelined_usable(int dk);   // attn_flash.hip: k_vits_flash_x3q takes this head dimension (and SBV2_FLASH_Q != 0)
+bool flash_pipelined_usable(int dk);   // attn_flash.hip: k_vits_flash_x3q takes this head dimension 
 void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, const float* Q, int ld, const SplitPlanes& kv, int k_row0,
                                 int v_row0, float* ctx, int ldc, int dk, const float* erk, const float* erv, int window, float qscale,
                                 hipStream_t s, int pipelined = 1);   // pipelined: 0 = k_vits_flash_x3p, 1 = k_vits_flash_x3q (shape by grid), 2 = ... 8-wave shape;   // keys / values pre-split into two bf16 parts (rows of kv); same bits as the split variant below
