@@ -62,7 +62,7 @@ void deberta_embed_ln(const int* ids, const float* emb, int H, const float* gamm
 // CPT > 0: every thread keeps its <= CPT channel values in registers, so the plane is read once (the value is needed three times: mean,
 // centred sum of squares, output); CPT == 0: generic fallback that re-reads it.  Same operations in the same order either way.
 #ifndef LN_EARLY_MAX
-#define LN_EARLY_MAX 24   // (-DLN_EARLY_MAX=32 / 0: the A/B builds of tools/, see the comment in the kernel)
+#define LN_EARLY_MAX 32   // (-DLN_EARLY_MAX=0: the loads behind the reductions as in rounds 1-4; tools/ln_ab.sh is the same-box A/B)
 #endif
 template <bool DW, int CPT, int COLS>
 __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const float* gamma, const float* beta, float eps,
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void k_layernorm_ch(Plane in, Plane out, const
     // gamma / beta / residual of every owned channel are requested with the values (the compiler keeps loads behind a barrier where they are written: behind
     // the two reductions they were a second dependent memory round trip of the launch, 1 - 2 us of the 8 - 11 us a single-utterance LayerNorm takes) and
     // before the first store: a load issued after a store is not usable until that store is acknowledged (in-order vmcnt)
-    // (up to 24 channels per thread: with 32, i.e. 128 loads in flight against a 6-bit vmcnt, the single-utterance DeBERTa LayerNorm got SLOWER, 10.7 -> 12.4 us:
-    // it keeps requesting them behind the reductions)
+    // (same-box A/B, profiles/r05n_ln_ab.txt: 8.04 -> 7.84 us per launch at 24 channels per thread, 12.48 -> 12.13 at 32 in a single-utterance call: within noise of
+    // nothing; kept because it is the order the comment above asks for)
     constexpr bool PRE = CPT > 0 && CPT <= 32, EARLY = CPT > 0 && CPT <= LN_EARLY_MAX;
     float gv[PRE ? NV : 1], bv[PRE ? NV : 1], rv[PRE ? NV : 1];
     auto load_params = [&]() {
