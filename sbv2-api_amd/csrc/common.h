@@ -482,6 +482,7 @@ struct ResPairParams {
     int alias_x2 = 1;      // set by launch_respair_cl: the intermediate window re-uses the conv1 window's LDS
     int abl = 0;           // diagnostics (wrong results): 1 = every global read hits the same few cache-hot rows, 2 = no global stores; diag kernel only: 4 = no MFMAs, 8 = no conv1 window conversion, 16 = no intermediate epilogue
     unsigned long long* stamps = nullptr;   // diag kernel only: 16 per workgroup
+    int nt_store = 0;      // set by launch_respair_clx: the plane does not fit the caches, its stores bypass them
     int rres_late = 0;     // respair_clx diagnostics only (sbv2_debug_respair_clock): request the residual rows before conv2 (rounds 1-3) instead of with the window
 };
 void launch_respair_cl(const ResPairParams& p, hipStream_t stream);

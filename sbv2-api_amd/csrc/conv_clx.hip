@@ -117,10 +117,11 @@ __device__ __forceinline__ void clx_halves(const bf16x8& a, const bf16x8& b, bf1
 // EDGE: the launch has a partial last position tile (N % 256 != 0): its guarded epilogue is compiled in.  (Compiled into every instance, that rarely taken
 // path set the register allocation of the whole kernel and the interior epilogue spilled in the middle of its load burst; the decoder's frame layout is
 // rounded so that the wide stages' planes are whole tiles.)
-// ... and the k-major epilogue (the flow's second FFN convolution) is an instance of its own (EPI 2; 1 = EDGE, 0 = whole tiles).
+// ... and the k-major epilogue (the flow's second FFN convolution) is an instance of its own (EPI 2; 1 = EDGE, 0 = whole tiles, 3 = whole tiles with non-temporal stores).
 template <int NTAPS, int kClxWR, int kClxXB, int XR, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
     constexpr bool EDGE = EPI == 1;
+    constexpr bool NT = EPI == 3;   // EPI 0 with non-temporal stores (result planes larger than the caches)
     constexpr int NPW = 64;                    // positions per wave
     constexpr int NTW = 256;                   // positions per workgroup
     constexpr int NW = 4;                      // waves
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     if (bx * NTW >= p.N) return;
     // EPI 0 with a ragged N (launched only when nothing accumulates): the last tile is moved left to end at N; the positions it shares with its neighbour are
     // computed twice from the same operands in the same order, and stored twice with the same bits
-    const int n0 = EPI == 0 ? min(bx * NTW, p.N - NTW) : bx * NTW;
+    const int n0 = (EPI == 0 || EPI == 3) ? min(bx * NTW, p.N - NTW) : bx * NTW;
     const int m0 = by * 64;                    // first output row of the workgroup (every wave: all 64 rows, its own 64 positions)
     const int M = p.M, N = p.N;
     const int nchunks = p.K >> 4;              // (even: K is a multiple of 32)
@@ -469,6 +470,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
         if (p.R) load_rows(0, p.R, p.ldr, m0 + c8);
         unsigned mbits = 0xFu;
         bool allkeep = true;
+        // NT (EPI 3): the stores of planes that do not fit the caches (a batch's 0.94 GB per stage; its consumer starts after the whole plane is written)
+        // bypass them (same-box A/B profiles/r05o_nt_store_ab.txt: C = 256 k = 3 conv1 238 -> 217 us, C = 128 k = 3 conv2 760 -> 737, step -0.3 ms; a single
+        // utterance's 29 MB planes are re-read from L2 / MALL and lose 0.1 ms per call with it: the launch decides by size).  An instance of its own: both
+        // store flavours behind a uniform branch in one kernel spilled 132 bytes.
         clx_static_for<0, 2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
@@ -512,8 +517,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                     if (!allkeep && !((mbits >> it) & 1u)) v[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
                 }
                 if (yp) {
-                    *reinterpret_cast<f32x4v*>(yp + it * ystep) = v[0];
-                    *reinterpret_cast<f32x4v*>(yp + it * ystep + 4) = v[1];
+                    if constexpr (NT) {
+                        __builtin_nontemporal_store(v[0], reinterpret_cast<f32x4v*>(yp + it * ystep));
+                        __builtin_nontemporal_store(v[1], reinterpret_cast<f32x4v*>(yp + it * ystep + 4));
+                    } else {
+                        *reinterpret_cast<f32x4v*>(yp + it * ystep) = v[0];
+                        *reinterpret_cast<f32x4v*>(yp + it * ystep + 4) = v[1];
+                    }
                 }
                 if (qs) {
                     bf16x8 h8, l8;
@@ -524,8 +534,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                         h8[e] = (__bf16)x;
                         l8[e] = (__bf16)(x - (float)h8[e]);
                     }
-                    *reinterpret_cast<bf16x8*>(qs + it * 512) = h8;
-                    *reinterpret_cast<bf16x8*>(qs + it * 512 + yplane) = l8;
+                    if constexpr (NT) {
+                        __builtin_nontemporal_store(h8, reinterpret_cast<bf16x8*>(qs + it * 512));
+                        __builtin_nontemporal_store(l8, reinterpret_cast<bf16x8*>(qs + it * 512 + yplane));
+                    } else {
+                        *reinterpret_cast<bf16x8*>(qs + it * 512) = h8;
+                        *reinterpret_cast<bf16x8*>(qs + it * 512 + yplane) = l8;
+                    }
                 }
             }
             if constexpr (i == 0) {
@@ -687,7 +702,12 @@ static void launch_clx_e(ClxKernelParams kp, hipStream_t stream);
 template <int NTAPS, int WR, int XB, int XR>
 static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
     if (kp.p.Ykm) launch_clx_e<NTAPS, WR, XB, XR, 2>(kp, stream);
-    else if (kp.p.N % kClxNT == 0 || (!kp.p.accumulate && kp.p.N >= kClxNT)) launch_clx_e<NTAPS, WR, XB, XR, 0>(kp, stream);
+    else if (kp.p.N % kClxNT == 0 || (!kp.p.accumulate && kp.p.N >= kClxNT)) {
+        // result planes of >= 128 MB (a batch's decoder stages; a long utterance) leave through non-temporal stores (EPI 3); smaller ones (a single utterance: 29 MB;
+        // the flow's 88 MB FFN intermediate, which its second conv reads straight back: 6.05 -> 6.2 ms with them) are re-read from the caches
+        if ((int64_t)kp.p.N * kp.p.M * 4 >= ((int64_t)128 << 20)) launch_clx_e<NTAPS, WR, XB, XR, 3>(kp, stream);
+        else launch_clx_e<NTAPS, WR, XB, XR, 0>(kp, stream);
+    }
     else launch_clx_e<NTAPS, WR, XB, XR, 1>(kp, stream);
 }
 

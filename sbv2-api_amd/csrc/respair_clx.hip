@@ -528,23 +528,31 @@ __global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdg
         }
     }
     const float beta = p.beta;
+    // the stores of planes that do not fit the caches bypass them (p.nt_store, set by the launch: conv_clx.hip has the measurement); two copies of the loop
+    // behind one uniform branch
+    auto store_rows = [&](auto ntc) {
+        constexpr bool NT = decltype(ntc)::value;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int row = it * RPI + rowi;
-        const int o = wn * 64 + row;                    // output index inside the workgroup's range
-        const int pos = n0 + o;                         // < 2^31 (checked by the caller)
-        const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * TP + (lane % LPR) * 4);
-        if (o >= nto || pos >= NB) continue;
-        f32x4v v;
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + rowi;
+            const int o = wn * 64 + row;                    // output index inside the workgroup's range
+            const int pos = n0 + o;                         // < 2^31 (checked by the caller)
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(ttile + row * TP + (lane % LPR) * 4);
+            if (o >= nto || pos >= NB) continue;
+            f32x4v v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (a[e] + b4[e] + rres[it][e]) * beta;
-        if (p.accumulate) {
+            for (int e = 0; e < 4; ++e) v[e] = (a[e] + b4[e] + rres[it][e]) * beta;
+            if (p.accumulate) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rold[it][e];
+                for (int e = 0; e < 4; ++e) v[e] += rold[it][e];
+            }
+            if (!mask_s[o + h2]) v = f32x4v{0.f, 0.f, 0.f, 0.f};   // position n0 + o = intermediate row o + h2
+            if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(p.Y + (int64_t)pos * C + c4));
+            else *reinterpret_cast<f32x4v*>(p.Y + (int64_t)pos * C + c4) = v;
         }
-        if (!mask_s[o + h2]) v = f32x4v{0.f, 0.f, 0.f, 0.f};   // position n0 + o = intermediate row o + h2
-        *reinterpret_cast<f32x4v*>(p.Y + (int64_t)pos * C + c4) = v;
-    }
+    };
+    if (p.nt_store) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
     RPX_STAMP(6);
     RPX_STAMP(15);
     if constexpr (DIAG) {
@@ -608,6 +616,7 @@ void launch_respair_clx(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(respair_clx_usable(p0), "respair_clx: operands do not fit the kernel");
     ResPairParams p = p0;
     p.rres_late = 0;
+    p.nt_store = (int64_t)p.N * p.C * 4 >= ((int64_t)128 << 20);
     launch_rpx_any<-1>(p, stream);
 }
 void launch_respair_clx_diag(const ResPairParams& p0, hipStream_t stream) {
