@@ -90,23 +90,32 @@ __device__ __forceinline__ int bfs_swz(int k) {
 // K / ksplit range, leaves its accumulators in p.sk.ws and counts itself in; the one that arrives last adds the ksplit partial sums IN GROUP ORDER (its own
 // included, from memory: the result does not depend on who was last) and runs the epilogue.  Another summation order than the unsplit kernel: a batch row and
 // the single-utterance call agree to f32 rounding instead of bit for bit (sbv2_debug_set_ksplit(0): the unsplit dispatch, which the bit-equality tests run on).
-template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false, bool SK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM * TN >= 4 ? 2 : (TM * TN == 2 && NSLOT <= 4 ? 3 : 1)))) void gemm_bfs_kernel(const BfsKernelParams kp) {
+// KG > 1 (round 5, the single utterance's K = 1024 products): the workgroup is KG groups of WM x WN waves (here: four groups of ONE wave, a 32 x 32 output tile);
+// group g owns the g-th contiguous K / KG range and its own ring, every group takes the same number of barriers, and behind the loop groups 1 .. KG - 1 hand
+// their accumulators to group 0 through their (now idle) rings, which adds them in group order and runs the epilogue.  What this buys is not the shorter loop per
+// wave (the same split on 64 x 64 tiles measured nothing) but HALF the bytes per CU: a 32 x 32 tile streams (32 + 32) rows of K where a 64 x 64 one streams
+// (64 + 64), on four times as many CUs.  Summation order: K / KG partial sums (sbv2_debug_set_ksplit(0) selects the unsplit kernel).
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false, bool SK = false, int KG = 1>
+__global__ __launch_bounds__(64 * WM * WN * KG) __attribute__((amdgpu_waves_per_eu(KG > 1 ? 1 : (F16 && TM * TN >= 4 ? 2 : (TM * TN == 2 && NSLOT <= 4 ? 3 : 1))))) void gemm_bfs_kernel(const BfsKernelParams kp) {
     static_assert(!F16 || PARTS == 2, "f16x3 has two planes");
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NW = WM * WN;   // waves of a group
+    static_assert(NW == 4 || NW == 1, "4 waves per group, or one");
+    static_assert(!(SK && KG > 1), "one kind of K split at a time");
     constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN, RB = NT * 2;
     constexpr int NMT = MT / 32;
     constexpr int A_BYTES = NMT * PARTS * 1024, B_PART = 16 * RB, B_BYTES = PARTS * B_PART;
     constexpr int CH = A_BYTES + B_BYTES;     // one 16-deep chunk
     constexpr int SLOT = KSUB * CH;           // a ring slot = KSUB chunks = the span between two barriers
     constexpr int GA = A_BYTES / 1024, GBP = B_PART / 1024, GB = GBP * PARTS;
-    static_assert((GA + GB) % 4 == 0 && GBP >= 1, "the DMAs of a chunk are dealt evenly over the four waves");
-    constexpr int PERW = (GA + GB) / 4;
+    static_assert((GA + GB) % NW == 0 && GBP >= 1, "the DMAs of a chunk are dealt evenly over the group's waves");
+    constexpr int PERW = (GA + GB) / NW;
     static_assert((NSLOT - 1) * KSUB * PERW <= 60, "vmcnt is a 6-bit counter");
     const GemmBfsParams& p = kp.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((tid >> 6) / NW) : 0;   // K group (KG > 1)
+    const int wave = KG > 1 ? __builtin_amdgcn_readfirstlane((tid >> 6) % NW) : tid >> 6;   // wave inside its group
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs; each XCD walks a contiguous range of tiles (m fastest), so the
     // tiles co-resident on one L2 share their weight rows / activation columns.  Speed only.
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     const int tmi = t % kp.gm, tni = t / kp.gm;
     const int m0 = tmi * MT, n0 = tni * NT;
     const int M = p.M, N = p.N;
-    const int nchunks = SK ? (p.K >> 4) / kp.ksplit : p.K >> 4;   // (the launch checks divisibility)
+    const int nchunks = SK ? (p.K >> 4) / kp.ksplit : (p.K >> 4) / KG;   // of this workgroup / group (the launch checks divisibility)
 
     // ---- DMA descriptors: DMA g of a chunk (g < GA: weight fragment blocks, else 1 KB pieces of the activation parts) belongs to wave g % 4
     const char* src[PERW];
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     int dst[PERW];
 #pragma unroll
     for (int q = 0; q < PERW; ++q) {
-        const int gi = wave + 4 * q;
+        const int gi = wave + NW * q;
         if (gi < GA) {
             const int mt = min(m0 / 32 + gi / PARTS, p.W.nmt - 1), part = gi % PARTS;   // row tiles outside the problem only feed outputs never stored
             src[q] = static_cast<const char*>(p.W.w) + ((int64_t)mt * PARTS + part) * 1024 + lane * 16;
@@ -152,8 +161,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     for (int q = 0; q < PERW; ++q) {
         sdst[q] = __builtin_amdgcn_readfirstlane(dst[q]);
         if (SK) src[q] += (int64_t)kg * nchunks * step[q];
+        if (KG > 1) src[q] += (int64_t)grp * nchunks * step[q];
     }
-    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (KG > 1 ? grp * (NSLOT * SLOT) : 0);
     auto dma = [&](int q, int off) {   // DMA q of the next chunk to stage (chunk image at LDS offset off); advances its source pointer
         __builtin_amdgcn_global_load_lds((bfs_gbl_t*)src[q], (bfs_lds_t*)(uintptr_t)(lds0 + off + sdst[q]), 16, 0, 0);
         src[q] += step[q];
@@ -322,6 +332,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
     }
     if (c < nchunks) step_chunk(c, fa, fb, std::false_type{}, BarEven{});
     __syncthreads();   // the epilogue re-uses the ring as its transpose tiles
+    if constexpr (KG > 1) {
+        // groups 1 .. KG - 1: accumulators -> their own ring, lane-linear 16-byte cells [wave][quad][lane]; group 0 adds them in group order
+        constexpr int NQ = TM * TN * (F16 ? 8 : 4);
+        static_assert(NW * NQ * 1024 <= NSLOT * SLOT, "a group's ring holds its waves' accumulators");
+        f32x4v* part = reinterpret_cast<f32x4v*>(smem + (size_t)grp * (NSLOT * SLOT)) + wave * (NQ * 64) + lane;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        part[((i * TN + j) * (F16 ? 8 : 4) + q) * 64] = f32x4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        if (F16) part[((i * TN + j) * 8 + 4 + q) * 64] = f32x4v{accx[i][j][4 * q], accx[i][j][4 * q + 1], accx[i][j][4 * q + 2], accx[i][j][4 * q + 3]};
+                    }
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll 1
+        for (int g = 1; g < KG; ++g) {
+            const f32x4v* src_g = part + (size_t)g * (NSLOT * SLOT / 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4v a = src_g[((i * TN + j) * (F16 ? 8 : 4) + q) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += a[e];
+                        if (F16) {
+                            const f32x4v x = src_g[((i * TN + j) * 8 + 4 + q) * 64];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accx[i][j][4 * q + e] += x[e];
+                        }
+                    }
+        }
+        // (group 0's waves write their transpose tiles into group 0's ring only: the other groups' partial sums are not overwritten while a sibling reads)
+    }
     if constexpr (SK) {
         // accumulators -> p.sk.ws[tile][group][wave][quad][lane] (16-byte cells: every store / load is 1 KB per wave, coalesced).  The partial sums cross
         // XCDs (one L2 each).  Agent-scope fences around the count cost 25 us per launch (a release writes the XCD's whole L2 back, an acquire invalidates
@@ -329,10 +378,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
         // are not served from this XCD's L2), like the counter's atomic.
         constexpr int NQ = TM * TN * (F16 ? 8 : 4);
         const int ks = kp.ksplit;
-        f32x4v* wsp = reinterpret_cast<f32x4v*>(p.sk.ws) + ((size_t)t * ks * 4 + wave) * (NQ * 64) + lane;
+        f32x4v* wsp = reinterpret_cast<f32x4v*>(p.sk.ws) + ((size_t)t * ks * NW + wave) * (NQ * 64) + lane;
         auto st = [](f32x4v* dst, const f32x4v& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory"); };
         {
-            f32x4v* mine = wsp + (size_t)kg * 4 * (NQ * 64);
+            f32x4v* mine = wsp + (size_t)kg * NW * (NQ * 64);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -369,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 && TM *
 #pragma unroll
             for (int gi = 0; gi < kBatch; ++gi)
                 if (g0 + gi < ks) {
-                    const f32x4v* src_g = wsp + (size_t)(g0 + gi) * 4 * (NQ * 64);
+                    const f32x4v* src_g = wsp + (size_t)(g0 + gi) * NW * (NQ * 64);
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[gi][q]) : "v"(src_g + q * 64) : "memory");
                 }
@@ -554,7 +603,7 @@ bool gemm_bfs_usable(const GemmBfsParams& p) {
            (p.X.ld & 7) == 0 && (!p.Y || (p.ldy & 3) == 0) && (!p.R || (p.ldr & 3) == 0) && (!p.Ys.parts || (p.Ys.ld & 3) == 0) && p.N >= 4;
 }
 
-template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false, bool SK = false>
+template <int PARTS, int TM, int TN, int WM, int WN, int KSUB, int NSLOT, bool F16 = false, bool SK = false, int KG = 1>
 static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream, int ksplit = 1) {
     constexpr int MT = 32 * TM * WM, NT = 32 * TN * WN;
     constexpr int SLOT = KSUB * ((MT / 32) * PARTS * 1024 + PARTS * 16 * NT * 2);
@@ -564,12 +613,13 @@ static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream, int ksplit = 
     kp.ksplit = SK ? ksplit : 1;
     kp.total = kp.gm * kp.gn * kp.ksplit;
     if (SK) {
-        constexpr size_t kPerWg = (size_t)4 * TM * TN * (F16 ? 8 : 4) * 1024;   // bytes of partial sums per workgroup
+        constexpr size_t kPerWg = (size_t)WM * WN * TM * TN * (F16 ? 8 : 4) * 1024;   // bytes of partial sums per workgroup
         SBV2_REQUIRE((p.K >> 4) % ksplit == 0 && p.sk.ws && p.sk.counters && kp.gm * kp.gn <= p.sk.ncounters && (size_t)kp.total * kPerWg <= p.sk.ws_bytes,
                      "gemm_bfs: K split without room for it");
     }
-    const size_t lds = std::max<size_t>((size_t)NSLOT * SLOT, 4 * 32 * 36 * sizeof(float));
-    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT, F16, SK>;
+    const size_t lds = std::max<size_t>((size_t)KG * NSLOT * SLOT, (size_t)WM * WN * 32 * 36 * sizeof(float));
+    SBV2_REQUIRE(KG == 1 || (p.K >> 4) % KG == 0, "gemm_bfs: K does not split into equal groups");
+    auto kern = gemm_bfs_kernel<PARTS, TM, TN, WM, WN, KSUB, NSLOT, F16, SK, KG>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -579,7 +629,7 @@ static void launch_bfs_cfg(BfsKernelParams kp, hipStream_t stream, int ksplit = 
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(kern, dim3(round_up(kp.total, 8)), dim3(256), lds, stream, kp);
+    hipLaunchKernelGGL(kern, dim3(round_up(kp.total, 8)), dim3(64 * WM * WN * KG), lds, stream, kp);
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -622,7 +672,12 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
             int ks = 1;
             if (ksplit_enabled() && p.sk.ws && p.sk.counters && tiles <= p.sk.ncounters && nch >= 128)
                 while (ks < 8 && tiles * (ks * 2) <= 256 && nch % (ks * 2) == 0 && nch / (ks * 2) >= 32 && (size_t)tiles * (ks * 2) * 32768 <= p.sk.ws_bytes) ks *= 2;
+            // ... and the shorter K loops on 32 x 32 tiles whose four waves each take a quarter of K (the kernel's KG): half the bytes per CU on four times the
+            // CUs, as long as that is still one workgroup per CU (DeBERTa's 1024 x 1024 product at 68 columns: 96 workgroups, 11.0 -> 8.1 us; the 3072- and
+            // 4096-row products would be 288 / 384 workgroups and measured 16.3 us against 11.6 - 12.1)
+            const bool kg4 = ksplit_enabled() && ks == 1 && nch % 4 == 0 && nch >= 32 && blocks(32, 32) <= 256;
             if (ks > 1) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true, true>(kp, stream, ks);
+            else if (kg4) launch_bfs_cfg<2, 1, 1, 1, 1, 1, 4, true, false, 4>(kp, stream);
             else launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);
         }
     } else if (p.W.parts == 2) {   // bf16x3 (opt-in)
