@@ -183,6 +183,17 @@ static void launch_layernorm(Plane in, Plane out, const float* gamma, const floa
                              const unsigned char* mask, const float* w, const float* b, int dil, hipStream_t s, SplitPlanes sp = SplitPlanes{}) {
     SBV2_REQUIRE(!sp.parts || (sp.C == out.C && sp.ld >= out.L), "layernorm: split output shape");
     const dim3 block(256);
+    // A single utterance (66 tokens x 1024 channels, 897 frames or 257 symbols x 192): few columns per workgroup and few channels per thread, i.e. more
+    // workgroups and a shorter chain of dependent loads per thread (12.4 -> ~7 us and 7.8 -> ~5 us per launch, 129 launches per call).  Another grouping of the
+    // per-column sums than the batch's launch shape: f32-rounding apart from it, so it belongs to the small-grid dispatch that sbv2_debug_set_ksplit(0) turns off.
+    if (ksplit_enabled() && in.C >= 512 && in.C <= 8 * 128 && in.L <= 256) {
+        hipLaunchKernelGGL((k_layernorm_ch<DW, 8, 2>), dim3((in.L + 1) / 2), block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
+        return;
+    }
+    if (ksplit_enabled() && in.C < 512 && in.C <= 6 * 32 && in.L <= 1024) {
+        hipLaunchKernelGGL((k_layernorm_ch<DW, 6, 8>), dim3((in.L + 7) / 8), block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
+        return;
+    }
     // few, wide columns (DeBERTa: 1024 channels x ~2k tokens): 8 columns x 32 channel groups per workgroup, or the grid is 64 workgroups
     if (!DW && in.C >= 512 && in.L <= 8192 && in.C <= 32 * 32) {
         hipLaunchKernelGGL((k_layernorm_ch<DW, 32, 8>), dim3((in.L + 7) / 8), block, 0, s, in, out, gamma, beta, eps, act, res, ldr, mask, w, b, dil, sp);
