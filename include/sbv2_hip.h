@@ -227,9 +227,10 @@ int sbv2_debug_set_skinny_max(int workgroups);
    The two kernels sum in different orders (round 5: conv_clx on 16 x 16 x 32 MFMAs) and agree to f32 rounding; with 0 (and sbv2_debug_set_ksplit(0)) every
    launch size takes the same kernels and a batch row equals its single-utterance call bit for bit.  Returns the previous value. */
 int sbv2_debug_set_clx(int on);
-/* 1 (default): gemm_bfs products on small grids (a single utterance's DeBERTa Linear layers: 32 - 128 workgroups) split their K loop over 2 or 4 groups of
-   waves inside the workgroup and add the partial sums in group order: another summation order than the batch's tiles, so a single call and its batch row
-   agree to f32 rounding; 0: the unsplit dispatch (batch row == single call bit for bit; the bit-equality tests run on it).  Returns the previous value. */
+/* 1 (default): the small-grid dispatch of a single utterance's launches: gemm_bfs products with a long K loop split it over workgroups (K >= 2048) or over the
+   four waves of a 32 x 32 tile (the 1024 x 1024 products) and add the partial sums in group order, and LayerNorm runs few columns per workgroup; other
+   summation orders than the batch's launch shapes, so a single call and its batch row agree to f32 rounding; 0: the batch's launch shapes at every size (batch
+   row == single call bit for bit; the bit-equality tests run on it).  Returns the previous value. */
 int sbv2_debug_set_ksplit(int on);
 /* the flow's attention on keys / values pre-split by the q | k | v product: 1 (default) for sequences of >= 4096 frames and launches of <= 64
    workgroups, 2 at every length, 3 at every length on the un-pipelined kernel (k_vits_flash_x3p, the fallback for head dimensions that are no multiple
