@@ -250,7 +250,8 @@ int sbv2_debug_conv_cl_clock(int device, int64_t C, int64_t k, int64_t dilation,
    exports them; no reference counterpart).  kind 1 = conv1 (parts in, parts out), 2 = conv2 (+ residual in, f32 + parts out), 3 = a branch's last conv2
    (accumulating).  `seconds` of back-to-back launches, then the stamps of one more: 12 words per workgroup {loop start / end in shader cycles and in
    100 MHz ticks, kernel entry, last store issued, stores acknowledged (100 MHz), HW_ID | XCC_ID << 32, epilogue: behind the post-loop barrier, its
-   global reads arrived, the first half's stores issued (100 MHz), 0}; *ms_per_launch is of the un-stamped kernel. */
+   global reads arrived, the first half's stores issued (100 MHz), 0}; *ms_per_launch is of the un-stamped kernel.  `variant` selects a kernel variant under
+   test in builder experiments; the library holds only variant 0 (the product kernel), other values run the same kernel. */
 int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int kind, int variant, double seconds, uint64_t* stamps,
                             int64_t capacity_words, int64_t* workgroups, double* ms_per_launch);
 /* Diagnostics for the f16x3 operand format (DeBERTa's and the flow's 1x1 products): the split of an activation into the f16 hi / scaled-lo pair clamps

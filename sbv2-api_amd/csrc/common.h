@@ -451,7 +451,7 @@ struct ConvClxParams {
     const unsigned char* mask = nullptr;   // position n is kept iff mask[n >> mask_shift]
     int mask_shift = -1;
     unsigned long long* stamps = nullptr;  // diagnostics: kClxStampWords per workgroup (sbv2_debug_clx_timeline)
-    int variant = 0;            // diagnostics: kernel variant under test (0 = the product configuration)
+    int variant = 0;            // diagnostics (sbv2_debug_clx_timeline): kernel variant under test in a builder experiment; the library holds variant 0 only
 };
 int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv_clx starts for p
 bool conv_clx_usable(const ConvClxParams& p);
