@@ -266,6 +266,18 @@ int sbv2_debug_set_respair_clx(int on);
    null), channels-last x / y [N][C], w [C][C][k], split-bf16, through respair_cl.hip (variant 0) or respair_clx.hip (variant 1).  Test hook. */
 int sbv2_debug_respair(int device, const float* x, const float* w1, const float* w2, const float* b1, const float* b2, int64_t C, int64_t N, int64_t k,
                        int64_t dilation, const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, float* y);
+/* 1 (default; SBV2_RESBRANCH=0): the k = 3 branches of the <= 64-channel decoder stages run their three steps in ONE launch (resbranch_clx.hip: y_1, y_2 stay
+   on the chip, 2 plane passes through HBM per branch instead of 6); 0: three respair_clx launches (same bits).  Returns the previous value. */
+int sbv2_debug_set_resbranch(int on);
+/* A whole ResBlock1 branch (HifiGanResidualBlock.forward, modeling_vits.py:455-463; the graph of scripts/convert/convert_model.py:97-110): three steps
+   y_q = conv2_q(lrelu(conv1_q(lrelu(y_{q-1}), dilations[q]) + b1_q)) + b2_q + y_{q-1}, result beta * y_3 [+ y when accumulate], masked by mask[n / mask_div]
+   (a power of two; mask may be null) at every layer; channels-last x / y [N][C], w [6][C][C][k] and bias [6][C] in the order conv1_0, conv2_0, conv1_1, ...,
+   split-bf16; variant 0 = three launches of the fused step (respair_clx.hip), 1 = one launch (resbranch_clx.hip).  iters > 0: *ms = average duration of
+   `iters` further runs; stamps (variant 1, may be null): 16 words per workgroup of one more, stamped launch (s_memtime at entry [0], window converted [1], end
+   of step 1 / 2 / 3 [2 .. 4], stores issued [6]; s_memrealtime at entry / exit [14, 15]).  Test / measurement hook. */
+int sbv2_debug_resbranch(int device, const float* x, const float* w, const float* bias, int64_t C, int64_t N, int64_t k, const int64_t* dilations,
+                         const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, int64_t iters, float* y, float* ms,
+                         uint64_t* stamps, int64_t stamps_cap);
 /* Diagnostics: one fused ResBlock step (respair_cl.hip, split-bf16, C = 16 / 32 / 64) on random data, `seconds` of back-to-back launches,
    then out[0] = in-kernel clock (MHz, median over workgroups), out[1] = ms per launch, out[2] = workgroups stamped, out[2 + i] = median shader
    cycles from a workgroup's entry to phase stamp i (1 = conv1 window staged, 7 / 8 / 9 / 10 = first chunk's MFMAs / barrier / next chunk staged /

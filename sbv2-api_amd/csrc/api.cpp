@@ -826,6 +826,131 @@ int sbv2_debug_respair(int device, const float* x, const float* w1, const float*
     API_END
 }
 
+int sbv2_debug_resbranch(int device, const float* x, const float* w, const float* bias, int64_t C, int64_t N, int64_t k, const int64_t* dilations,
+                         const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, int64_t iters, float* y, float* ms,
+                         uint64_t* stamps, int64_t stamps_cap) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(x && w && bias && y && dilations && (C == 16 || C == 32 || C == 64) && N >= 1 && k >= 1 && k <= kMaxTaps && (k & 1) && mask_div >= 1 &&
+                     (mask_div & (mask_div - 1)) == 0, "bad arguments");
+    const size_t wsz = (size_t)C * C * k;
+    Blob b = one_conv_blob(w, bias, {C, C, k}, C);
+    WeightStore ws(b);
+    ClConv cv[2 * kResBranchSteps];
+    const void* wp[2 * kResBranchSteps] = {};
+    for (int i = 0; i < 2 * kResBranchSteps; ++i) {
+        cv[i] = pack_cl(ws, w + i * wsz, (int)C, (int)C, (int)k, 2, bias + (size_t)i * C);
+        if (C == 16) wp[i] = pack_cl_pairs(ws, w + i * wsz, (int)k);
+    }
+    DevBuf dx((size_t)N * C), dy((size_t)N * C), da((size_t)N * C), db((size_t)N * C);
+    HIP_CHECK(hipMemcpy(dx.p, x, sizeof(float) * N * C, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dy.p, y, sizeof(float) * N * C, hipMemcpyHostToDevice));   // (the previous contents matter when accumulate is set)
+    DevBuf dy0((size_t)N * C);
+    HIP_CHECK(hipMemcpy(dy0.p, y, sizeof(float) * N * C, hipMemcpyHostToDevice));
+    unsigned char* dm = nullptr;
+    const size_t nm = (size_t)((N + mask_div - 1) / mask_div);
+    if (mask) {
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dm), nm));
+        HIP_CHECK(hipMemcpy(dm, mask, nm, hipMemcpyHostToDevice));
+    }
+    int shift = 0;
+    while ((1 << shift) < mask_div) ++shift;
+    auto run = [&]() {
+        if (variant) {     // 1 = the fused branch (resbranch_clx.hip)
+            ResBranchParams rb;
+            rb.X = dx.p;
+            rb.Y = dy.p;
+            for (int i = 0; i < 2 * kResBranchSteps; ++i) {
+                rb.W[i] = C == 16 ? wp[i] : cv[i].w;
+                rb.b[i] = cv[i].bias;
+            }
+            rb.C = (int)C;
+            rb.N = (int)N;
+            rb.k = (int)k;
+            for (int q = 0; q < kResBranchSteps; ++q) rb.dil[q] = (int)dilations[q];
+            rb.beta = beta;
+            rb.accumulate = accumulate;
+            rb.mask = dm;
+            rb.mask_shift = shift;
+            launch_resbranch(rb, nullptr);
+        } else {           // 0 = three launches of the fused step (respair_clx.hip)
+            const float* cur = dx.p;
+            for (int q = 0; q < kResBranchSteps; ++q) {
+                const bool last = q + 1 == kResBranchSteps;
+                ResPairParams rp;
+                rp.X = cur;
+                rp.Y = last ? dy.p : (q & 1 ? db.p : da.p);
+                rp.W1 = cv[2 * q].w;
+                rp.W2 = cv[2 * q + 1].w;
+                rp.W1p = wp[2 * q];
+                rp.W2p = wp[2 * q + 1];
+                rp.b1 = cv[2 * q].bias;
+                rp.b2 = cv[2 * q + 1].bias;
+                rp.C = (int)C;
+                rp.N = (int)N;
+                rp.k = (int)k;
+                rp.dil = (int)dilations[q];
+                rp.split = 1;
+                rp.beta = last ? beta : 1.0f;
+                rp.accumulate = last ? accumulate : 0;
+                rp.mask = dm;
+                rp.mask_div = (int)mask_div;
+                launch_respair_cl(rp, nullptr);
+                cur = rp.Y;
+            }
+        }
+    };
+    try {
+        run();
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, dy.p, sizeof(float) * N * C, hipMemcpyDeviceToHost));
+        if (iters > 0 && ms) {
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) run();
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            *ms = t / (float)iters;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        if (stamps && stamps_cap >= 16 && variant) {   // one more launch of the stamped instantiation: 16 words per workgroup (resbranch_clx.hip)
+            unsigned long long* ds = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ds), sizeof(unsigned long long) * (size_t)stamps_cap));
+            HIP_CHECK(hipMemset(ds, 0, sizeof(unsigned long long) * (size_t)stamps_cap));
+            ResBranchParams rb;
+            rb.X = dx.p;
+            rb.Y = dy0.p;
+            for (int i = 0; i < 2 * kResBranchSteps; ++i) {
+                rb.W[i] = C == 16 ? wp[i] : cv[i].w;
+                rb.b[i] = cv[i].bias;
+            }
+            rb.C = (int)C;
+            rb.N = (int)std::min<int64_t>(N, (stamps_cap / 16 - 8) * 100);   // (at least 104 outputs per workgroup: the stamps of every workgroup fit)
+            rb.k = (int)k;
+            for (int q = 0; q < kResBranchSteps; ++q) rb.dil[q] = (int)dilations[q];
+            rb.beta = beta;
+            rb.mask = dm;
+            rb.mask_shift = shift;
+            rb.stamps = ds;
+            launch_resbranch(rb, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(stamps, ds, sizeof(unsigned long long) * (size_t)stamps_cap, hipMemcpyDeviceToHost));
+            (void)hipFree(ds);
+        }
+    } catch (...) {
+        if (dm) (void)hipFree(dm);
+        throw;
+    }
+    if (dm) (void)hipFree(dm);
+    API_END
+}
+int sbv2_debug_set_resbranch(int on) { return set_resbranch(on); }
+
 int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int variant, int abl, double seconds, double* out, int nout) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));

@@ -1448,7 +1448,7 @@ void vits_flash_attention_parts(const AttnGroup* groups, int ngroups, int maxT, 
     if (ngroups <= 0 || maxT <= 0) return;
     if (pipelined && flash_pipelined_usable(dk)) {
         // 128-query workgroups (4 waves, one per SIMD) while they leave at most one workgroup per CU; beyond, 256-query workgroups of 8 waves (two per SIMD)
-        const bool wide = pipelined == 2 || (int64_t)((maxT + 127) / 128) * ngroups > 256;   // (2: the test forces the 8-wave shape on small batches)
+        const bool wide = pipelined == 2 || (int64_t)((maxT + 127) / 128) * ngroups > device_cu_count();   // (2: the test forces the 8-wave shape on small batches)
         if (wide) {
             if (dk <= 32) launch_flash_x3q<1, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);
             else if (dk <= 64) launch_flash_x3q<2, 8>(groups, ngroups, maxT, Q, ld, kv, k_row0, v_row0, ctx, ldc, dk, erk, erv, window, qscale, s);

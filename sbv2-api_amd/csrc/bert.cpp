@@ -50,6 +50,7 @@ BertModel::BertModel(const Blob& blob, int device) : device_(device) {
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sk_counters_), sizeof(unsigned) * kSkCounters));
     HIP_CHECK(hipMemset(sk_counters_, 0, sizeof(unsigned) * kSkCounters));
     f16x3_sat_prepare();
+    sat_watch_.baseline();
     const std::string& js = blob.config_json;
     cfg_.vocab = (int)json_number(js, "vocab_size");
     cfg_.hidden = (int)json_number(js, "hidden");
@@ -502,7 +503,9 @@ void BertModel::copy_out(float* host) {
         off += layout_.len[i];
     }
     HIP_CHECK(hipMemcpyAsync(host, d_out, sizeof(float) * (size_t)total * H, hipMemcpyDeviceToHost, stream_));
+    sat_watch_.enqueue(stream_);
     HIP_CHECK(hipStreamSynchronize(stream_));
+    sat_watch_.check("DeBERTa, sbv2_bert_predict");
 }
 
 }  // namespace sbv2

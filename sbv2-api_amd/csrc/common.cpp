@@ -73,6 +73,7 @@ void Arena::upload(void* dst, const void* src, size_t bytes, hipStream_t stream)
     }
     Chunk& c = pinned_[pcur_];
     std::memcpy(c.base + c.off, src, bytes);
+    if (need > bytes) std::memset(c.base + c.off + bytes, 0, need - bytes);   // a merged copy (below) carries this padding to the device: zeros, not stale bytes
     if (defer_ > 0) {
         if (!pending_.empty()) {
             Pending& l = pending_.back();
@@ -256,12 +257,26 @@ std::vector<std::vector<int>> json_int_array2(const std::string& js, const std::
 }
 
 
+int device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t pr;
+    v = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    cached[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 static std::atomic<int> g_ksplit{1};
 bool ksplit_enabled() { return g_ksplit.load(std::memory_order_relaxed) != 0; }
 int set_ksplit(int on) { return g_ksplit.exchange(on); }
 
 // ---- f16x3 saturation counter (diagnostics; common.h) ----------------------------------------------------------------------------------
-static std::atomic<int> g_sat_on{getenv("SBV2_F16X3_SATCOUNT") ? atoi(getenv("SBV2_F16X3_SATCOUNT")) : 0};
+// Counting is ON by default since round 6 (the atomic only fires on a clamp; SBV2_F16X3_SATCOUNT=0 turns it off): a real DeBERTa-large checkpoint with an
+// outlier activation beyond +-65504 must not be clamped silently (SatWatch below prints the warning).
+static std::atomic<int> g_sat_on{getenv("SBV2_F16X3_SATCOUNT") ? atoi(getenv("SBV2_F16X3_SATCOUNT")) : 1};
 static std::mutex g_sat_mu;
 static std::map<int, unsigned long long*> g_sat_ctr;   // per device
 static unsigned long long* sat_ptr(bool create) {
@@ -288,6 +303,42 @@ int f16x3_sat_enable(int on) {
     if (on) (void)sat_ptr(true);
     return prev;
 }
+// ---- SatWatch: one stderr warning per model handle the first time the device's clamp count is non-zero (independent of SBV2_LOG) ---------------
+SatWatch::~SatWatch() {
+    if (host_) (void)hipHostFree(host_);
+}
+void SatWatch::enqueue(hipStream_t stream) {
+    if (warned_) return;
+    unsigned long long* ctr = f16x3_sat_counter();
+    if (!ctr) return;
+    if (!host_) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&host_), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+            host_ = nullptr;
+            return;
+        }
+        *host_ = 0;
+    }
+    armed_ = hipMemcpyAsync(host_, ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream) == hipSuccess;
+}
+unsigned long long SatWatch::check(const char* who) {
+    if (!armed_ || !host_) return 0;
+    armed_ = false;
+    const unsigned long long n = *host_;
+    if (n < base_) base_ = 0;   // (the device's count was reset in between: sbv2_debug_f16x3_saturation)
+    if (n > base_ && !warned_) {
+        warned_ = true;
+        fprintf(stderr,
+                "sbv2_hip WARNING (%s): %llu activation value(s) beyond +-65504 were clamped by the f16x3 operand split (f16 exponent range). "
+                "The result is NOT f32-grade for this input. Re-run with SBV2_BERT_GEMM=bf16x6 (bf16 exponent range, twice the matrix work) "
+                "and, for the flow, SBV2_FLOW_1X1=bf16x3; sbv2_debug_f16x3_saturation() reads / resets the count.\n",
+                who, n - base_);
+    }
+    return n;
+}
+void SatWatch::baseline() {
+    if (f16x3_sat_counter()) base_ = f16x3_sat_read(false);   // clamps counted on this device before the handle existed are not its own
+}
+
 unsigned long long f16x3_sat_read(bool reset) {
     unsigned long long* p = sat_ptr(false);
     if (!p) return 0;

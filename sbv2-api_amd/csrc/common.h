@@ -86,7 +86,9 @@ class Arena {
     void upload(void* dst, const void* src, size_t bytes, hipStream_t stream);
     // Between begin_uploads() and end_uploads() the copies of upload() are held back and issued together, neighbours merged: buffers that were allocated
     // one after the other from this arena and uploaded in the same order are ONE copy (staging and device placement both step by the 256-byte rounded
-    // size; the padding travels along).  A single-utterance call issued 67 copies of 4 - 1028 bytes, 5 us of GPU time each.  Nothing that reads the
+    // size; the padding travels along as ZEROS).  PRECONDITION of the deferred mode: an upload covers its whole allocation (up to the 256-byte rounding);
+    // an upload of a prefix of a larger buffer followed by an adjacent allocation would have the merged copy zero the buffer's tail inside the rounding
+    // gap.  Every deferred upload of the library is `array<T>(n)` + `upload(.., n * sizeof(T))`.  A single-utterance call issued 67 copies of 4 - 1028 bytes, 5 us of GPU time each.  Nothing that reads the
     // buffers may be launched inside the bracket.  (UploadBatch is the scope guard.)
     void begin_uploads() { ++defer_; }
     void end_uploads();
@@ -222,6 +224,7 @@ struct ConvParams {
 
 // hipFuncSetAttribute applies to the CURRENT device's copy of a kernel; a process that drives several GPUs (sbv2_node_*, one host thread per
 // device) must raise the dynamic-LDS limit once per (kernel, device), not once per kernel.  `done` is the caller's static per-kernel mask.
+int device_cu_count();   // compute units of the current device (hipDeviceProp, cached per device): the small-grid thresholds are in units of it
 inline void allow_full_lds(const void* kernel, std::atomic<uint64_t>& done) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
@@ -296,7 +299,7 @@ struct SplitPlanes {        // [part][C][ld] 16-bit, the column axis contiguous;
     int parts = 0, C = 0, L = 0, ld = 0;   // parts = number of planes
     int f16 = 0;            // 0: bf16 parts (each the rounding of what the previous ones left), 1: the f16 hi / scaled-lo pair
     int64_t pstride = 0;    // elements from one part to the next
-    unsigned long long* sat = nullptr;   // f16 pair only, diagnostics (SBV2_F16X3_SATCOUNT=1 / sbv2_debug_f16x3_saturation): counts values the split clamped
+    unsigned long long* sat = nullptr;   // f16 pair only (f16x3_sat_counter(): on unless SBV2_F16X3_SATCOUNT=0): counts values the split clamped
     int code() const { return f16 ? kPartsF16x3 : parts; }
     SplitPlanes rows(int c0, int n) const {
         SplitPlanes s = *this;
@@ -305,10 +308,28 @@ struct SplitPlanes {        // [part][C][ld] 16-bit, the column axis contiguous;
         return s;
     }
 };
-// Device counter of f16x3 saturations for the current device, or null when counting is off (the default).  The f16 pair has f16's exponent range:
-// a finite value beyond +-65504 is clamped by the split (NaN / Inf propagate as on the f32 path); with synthetic O(1) weights it never happens, a real
-// DeBERTa checkpoint with outlier channels should be run once with SBV2_F16X3_SATCOUNT=1 (fallback: SBV2_BERT_GEMM=bf16x6, bf16's range).
+// Device counter of f16x3 saturations for the current device, or null when counting is off (SBV2_F16X3_SATCOUNT=0; ON by default since round 6: the
+// atomic only fires on a clamp).  The f16 pair has f16's exponent range: a finite value beyond +-65504 is clamped by the split (NaN / Inf propagate as on
+// the f32 path); with synthetic O(1) weights it never happens, a real DeBERTa checkpoint with outlier channels would be clamped silently without it
+// (fallback: SBV2_BERT_GEMM=bf16x6, bf16's range).
 unsigned long long* f16x3_sat_counter();
+// Per model handle: copies the device's count to a pinned word behind the work queued on `stream` (enqueue), and once the caller has synchronised that
+// stream prints ONE stderr warning per handle the first time the count is non-zero (check; independent of SBV2_LOG).  Returns the count it saw.
+class SatWatch {
+public:
+    SatWatch() = default;
+    SatWatch(const SatWatch&) {}                           // a cloned execution context watches (and warns) on its own
+    SatWatch& operator=(const SatWatch&) { return *this; }
+    ~SatWatch();
+    void baseline();                      // at handle creation: what the device has counted so far belongs to other handles
+    void enqueue(hipStream_t stream);
+    unsigned long long check(const char* who);
+    bool warned() const { return warned_; }
+private:
+    unsigned long long* host_ = nullptr;
+    unsigned long long base_ = 0;
+    bool armed_ = false, warned_ = false;
+};
 int f16x3_sat_enable(int on);                        // returns the previous setting
 void f16x3_sat_prepare();   // creates the current device's counter if counting is on (call at model creation, outside any stream capture)
 unsigned long long f16x3_sat_read(bool reset);       // current device
@@ -375,7 +396,7 @@ __device__ __forceinline__ void split_store4(const SplitPlanes& sp, int64_t off,
             h[e] = (_Float16)c;
             l[e] = (_Float16)((c - (float)h[e]) * kF16LoScale);
         }
-        if (sp.sat) {   // (uniform branch; diagnostics only)
+        if (sp.sat) {   // (uniform branch; the atomic fires only on a clamp)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (fabsf(v[e]) > 65504.f && fabsf(v[e]) != __builtin_inff()) atomicAdd(sp.sat, 1ull);
@@ -493,5 +514,29 @@ bool respair_clx_usable(const ResPairParams& p);          // p.mask_shift set
 void launch_respair_clx(const ResPairParams& p, hipStream_t stream);
 void launch_respair_clx_diag(const ResPairParams& p, hipStream_t stream);
 int set_respair_clx(int on);   // returns the previous setting (default 1)
+
+// resbranch_clx.hip (round 6): the THREE steps of a ResBlock1 branch in one launch (k = 3, C in {16, 32, 64}): y_1 and y_2 never leave the chip, 2 plane passes
+// through HBM per branch instead of 6; bit-identical to three respair_clx launches
+constexpr int kResBranchSteps = 3;
+constexpr int kResBranchMargin = 6;   // window rows a tap may reach beyond the window's ends (>= dilation * (k - 1) / 2)
+struct ResBranchParams {
+    const float* X = nullptr;   // y_0 [N][C]
+    float* Y = nullptr;         // beta * y_3 [N][C] (+= when accumulate)
+    const void* W[2 * kResBranchSteps] = {};   // conv1, conv2 of step 0, conv1, conv2 of step 1, ...: pack_cl fragment blocks (C >= 32) / pack_cl_pairs (C = 16)
+    const float* b[2 * kResBranchSteps] = {};
+    int C = 0, N = 0, k = 3;
+    int dil[kResBranchSteps] = {1, 1, 1};      // dilation of each step's conv1 (conv2: 1)
+    float slope = 0.1f, beta = 1.0f;
+    int accumulate = 0;
+    const unsigned char* mask = nullptr;       // position n is kept iff mask[n >> mask_shift]
+    int mask_shift = -1;
+    int halo = 0;               // set by launch_resbranch: sum over the steps of (dil + 1) * (k - 1) / 2
+    int nt_store = 0;           // set by launch_resbranch
+    unsigned long long* stamps = nullptr;      // diagnostics: 16 per workgroup (sbv2_debug_resbranch_clock)
+};
+bool resbranch_usable(const ResBranchParams& p);
+bool resbranch_enabled();
+int set_resbranch(int on);      // returns the previous setting (default 1; SBV2_RESBRANCH=0)
+void launch_resbranch(const ResBranchParams& p, hipStream_t stream);
 
 }  // namespace sbv2

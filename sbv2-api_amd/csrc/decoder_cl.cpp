@@ -345,6 +345,32 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             const float* y = XU;
             const SplitClPlanes* ys = &XUs;   // bf16 parts of lrelu(y)
             const int nd = (int)rb.dil.size();
+            // k = 3 branches of the <= 64-channel stages: all three steps in ONE launch (resbranch_clx.hip: the residual stream stays in registers, the
+            // operands in LDS; 2 plane passes through HBM instead of 6; same bits as the three fused steps below)
+            if (!clx && fuse_pairs_ && resbranch_enabled() && C <= 64 && st.mode == 1 && nd == kResBranchSteps && (U & (U - 1)) == 0) {
+                ResBranchParams bp;
+                bp.X = XU;
+                bp.Y = XS;
+                for (int q = 0; q < nd; ++q) {
+                    bp.W[2 * q] = C == 16 ? rb.c1[q].wp : rb.c1[q].w;
+                    bp.W[2 * q + 1] = C == 16 ? rb.c2[q].wp : rb.c2[q].w;
+                    bp.b[2 * q] = rb.c1[q].bias;
+                    bp.b[2 * q + 1] = rb.c2[q].bias;
+                    bp.dil[q] = rb.dil[q];
+                }
+                bp.C = C;
+                bp.N = (int)Lo;
+                bp.k = rb.k;
+                bp.slope = 0.1f;
+                bp.beta = 1.0f / nk;
+                bp.accumulate = j > 0;
+                bp.mask = fl.d_mask;
+                bp.mask_shift = ushift;
+                if (resbranch_usable(bp)) {
+                    launch_resbranch(bp, stream_);
+                    continue;
+                }
+            }
             for (int q = 0; q < nd; ++q) {
                 const int d = rb.dil[q];
                 const bool last = q + 1 == nd;

@@ -450,9 +450,11 @@ __global__ __launch_bounds__(64 * WM * WN * KG) __attribute__((amdgpu_waves_per_
     // s + 1 requested before the first store of sub-tile s.  In the generic path below hipcc cannot count the stores of split_store4's loop over the parts,
     // so every use of a loaded value behind them waits s_waitcnt vmcnt(0): three exposed store acknowledgements per 32 x 32 sub-tile, on top of the loads
     // queued behind the previous sub-tile's stores.  Same arithmetic in the same order: same bits.
-    const bool ys_own = !p.Ys.parts || (p.Ys.parts == PARTS && (p.Ys.f16 != 0) == F16 && !p.Ys.sat);
-    if (m0 + MT <= M && n0 + NT <= N && ys_own && (p.y_rows & 31) == 0 && (p.ys_row0 & 31) == 0 && (!p.mask || kp.mask_shift == 0)) {
+    const bool ys_own = !p.Ys.parts || (p.Ys.parts == PARTS && (p.Ys.f16 != 0) == F16);
+    // (y_rows: the default 0x7fffffff = every row; a bound inside the matrix must fall on a 32-row sub-tile for the uniform toY test below)
+    if (m0 + MT <= M && n0 + NT <= N && ys_own && (p.y_rows >= M || (p.y_rows & 31) == 0) && (p.ys_row0 & 31) == 0 && (!p.mask || kp.mask_shift == 0)) {
         constexpr int NS = TM * TN;
+        unsigned nclamp = 0;   // f16 pair: values this lane's split clamped to +-65504 (counted into p.Ys.sat once, behind the last store)
         f32x4v rr[2][4];
         float brow[2][4];
         unsigned mk[2];
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) __attribute__((amdgpu_waves_per_
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {   // split_store4's f16 pair: finite values beyond f16's range saturate, NaN / infinity pass through
                             const float c = (v[e] != v[e] || fabsf(v[e]) == __builtin_inff()) ? v[e] : fminf(fmaxf(v[e], -65504.f), 65504.f);
+                            nclamp += (c != v[e] && v[e] == v[e]) ? 1u : 0u;
                             h[e] = (_Float16)c;
                             l[e] = (_Float16)((c - (float)h[e]) * kF16LoScale);
                         }
@@ -523,6 +526,9 @@ __global__ __launch_bounds__(64 * WM * WN * KG) __attribute__((amdgpu_waves_per_
                 }
             }
         });
+        if constexpr (F16) {
+            if (p.Ys.parts && p.Ys.sat && nclamp) atomicAdd(p.Ys.sat, (unsigned long long)nclamp);
+        }
         return;
     }
 #pragma unroll
@@ -653,7 +659,8 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
     const bool big = blocks(128, 128) >= 128;
     // Ring depth = bytes in flight per CU: a chunk's DMAs take ~1 us to land under load, a chunk's MFMAs 0.2 - 0.4 us.  Grids that leave one
     // workgroup per CU take the whole LDS (144 KB); larger grids run two workgroups per CU with 80 / 72 KB each.
-    const bool lone = blocks(128, 128) <= 256;
+    const int ncu = device_cu_count();   // (256 on MI355X)
+    const bool lone = blocks(128, 128) <= ncu;
     const bool k32 = (p.K & 31) == 0;
     if (p.W.f16) {
         // f16x3 (the default format): small grids (a single utterance) on 64 x 64 tiles with an 8-slot ring; everything else on 64 x 128 tiles with a 4-slot
@@ -671,11 +678,11 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
             const int nch = p.K >> 4;
             int ks = 1;
             if (ksplit_enabled() && p.sk.ws && p.sk.counters && tiles <= p.sk.ncounters && nch >= 128)
-                while (ks < 8 && tiles * (ks * 2) <= 256 && nch % (ks * 2) == 0 && nch / (ks * 2) >= 32 && (size_t)tiles * (ks * 2) * 32768 <= p.sk.ws_bytes) ks *= 2;
+                while (ks < 8 && tiles * (ks * 2) <= ncu && nch % (ks * 2) == 0 && nch / (ks * 2) >= 32 && (size_t)tiles * (ks * 2) * 32768 <= p.sk.ws_bytes) ks *= 2;
             // ... and the shorter K loops on 32 x 32 tiles whose four waves each take a quarter of K (the kernel's KG): half the bytes per CU on four times the
             // CUs, as long as that is still one workgroup per CU (DeBERTa's 1024 x 1024 product at 68 columns: 96 workgroups, 11.0 -> 8.1 us; the 3072- and
             // 4096-row products would be 288 / 384 workgroups and measured 16.3 us against 11.6 - 12.1)
-            const bool kg4 = ksplit_enabled() && ks == 1 && nch % 4 == 0 && nch >= 32 && blocks(32, 32) <= 256;
+            const bool kg4 = ksplit_enabled() && ks == 1 && nch % 4 == 0 && nch >= 32 && blocks(32, 32) <= ncu;
             if (ks > 1) launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true, true>(kp, stream, ks);
             else if (kg4) launch_bfs_cfg<2, 1, 1, 1, 1, 1, 4, true, false, 4>(kp, stream);
             else launch_bfs_cfg<2, 1, 1, 2, 2, 1, 8, true>(kp, stream);

@@ -159,6 +159,7 @@ class BertModel {
     unsigned* sk_counters_ = nullptr;   // this context's arrival counters for gemm_bfs' small-grid K split (kSkCounters, zero between launches)
     static constexpr int kSkCounters = 256;
     static constexpr size_t kSkWsBytes = (size_t)8 << 20;
+    SatWatch sat_watch_;                // f16x3 clamp warning of this handle (common.h)
     Plane out_;
     SegLayout layout_;
 };
@@ -340,6 +341,7 @@ class VitsModel {
     VitsConfig cfg_;
     std::shared_ptr<WeightStore> ws_;
     hipStream_t stream_ = nullptr;
+    SatWatch sat_watch_;                // f16x3 clamp warning of this handle (common.h)
     hipEvent_t after_ev_ = nullptr;   // orders this context after the producer stream of its DeBERTa features (created on first use)
     Arena arena_, keep_;
     // weights

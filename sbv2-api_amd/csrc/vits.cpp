@@ -154,6 +154,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));  // never serialised against the NULL stream (e.g. RCCL launched by the caller)
     f16x3_sat_prepare();
+    sat_watch_.baseline();
     const std::string& js = blob.config_json;
     auto I = [&](const char* k) { return (int)json_number(js, k); };
     cfg_.n_vocab = I("n_vocab"); cfg_.n_tones = I("n_tones"); cfg_.n_langs = I("n_langs"); cfg_.n_speakers = I("n_speakers");
@@ -190,7 +191,7 @@ VitsModel::VitsModel(const Blob& blob, int device) : device_(device) {
     WeightStore& w = *ws_;
     // The text side decides the INTEGER durations (ceil(exp(logw) * length_scale)): text encoder and both duration predictors run on
     // the exact-f32 kernels whatever SBV2_GEMM says.  (Round 2 measured their k = 3 convolutions on the split-bf16 matrix cores behind a knob: one flipped
-    // duration per 102 800 symbols, tests/flip_rate.py; the knob is gone, the text side is exact f32.)
+    // duration per 102 800 symbols, profiles/r02_flip_rate.json; the knob and its script are gone, the text side is exact f32.)
     w.set_cl_parts(0);
     // every tensor's shape is checked against the config before a kernel indexes it (a container / imported ONNX whose config and
     // weights disagree is refused here)
@@ -414,7 +415,8 @@ void VitsModel::run_encoder(const Encoder& e, Plane x, const SegLayout& lay, con
     if (kv_parts) QKVs = alloc_split(ar, 2, 3 * H, N);
     // Large batches: the FFN pair on conv_clx.hip (pre-split chunk-major operands by LDS-DMA instead of conv_cl's transposing register staging):
     // x is split once per layer from its k-major plane (split_cl_km), conv_1's epilogue writes relu(.) as conv_2's operand parts, conv_2 writes
-    // the k-major result + residual.  Same MFMA order as the conv_cl path: same bits, so small launches (a single utterance) may stay there.
+    // the k-major result + residual.  Small launches (a single utterance) stay on conv_cl: since round 5 conv_clx multiplies on 16 x 16 x 32 MFMAs in another
+    // summation order, so the two agree to f32 rounding (1e-5 kernel against kernel), not bit for bit.
     const bool clx_ffn = Fcl && f1.cl.parts == 2 && f2.cl.parts == 2 && f1.k == 5 && f2.k == 5 && (H & 63) == 0 && (f1.cout & 63) == 0 &&
                          clx_wanted((int64_t)(N / 256) * (H / 64), 192);
     SplitClPlanes XsC, FsC;
@@ -756,7 +758,11 @@ void VitsModel::forward(const VitsBatch& b) {
     std::vector<float> logw_p(Lt);
     HIP_CHECK(hipMemcpyAsync(dur_p.data(), d_dur, sizeof(int) * Lt, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipMemcpyAsync(logw_p.data(), d_logw, sizeof(float) * Lt, hipMemcpyDeviceToHost, stream_));
+    // (the f16x3 clamp count of everything queued so far: DeBERTa's products when a pipeline run feeds this call on the same device, the previous call's
+    // flow; the one host sync of the batch is here anyway)
+    sat_watch_.enqueue(stream_);
     HIP_CHECK(hipStreamSynchronize(stream_));
+    sat_watch_.check("DeBERTa / flow products seen by the VITS call");
     dur_host_.assign((size_t)total_t, 0);
     logw_host_.assign((size_t)total_t, 0.f);
     std::vector<int> Tf(n);

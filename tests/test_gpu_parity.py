@@ -112,6 +112,50 @@ def test_respair_clx_kernel_same_bits_as_respair_cl(C, k, dil, N):
     assert not np.any(got[np.repeat(mask, 4)[:N] == 0])
 
 
+def _resbranch(x, w, b, k, dils, mask, mask_div, beta, prev, variant):
+    N, C = x.shape
+    y = np.ascontiguousarray(prev, np.float32).copy() if prev is not None else np.zeros((N, C), np.float32)
+    P = lambda a: a.ctypes.data_as(f32p)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    d = np.asarray(dils, np.int64)
+    _lib.check(_lib.lib().sbv2_debug_resbranch(0, P(x), P(w), P(b), C, N, k, d.ctypes.data_as(_lib.i64p), None if m is None else m.ctypes.data, mask_div,
+                                               float(beta), 1 if prev is not None else 0, variant, 0, P(y), None, None, 0))
+    return y
+
+
+@pytest.mark.parametrize("C,N", [(16, 700), (16, 233), (16, 232 * 9 + 5), (32, 257), (32, 2000), (32, 232), (32, 31), (64, 130), (64, 1111), (64, 104 * 17 + 3), (64, 105)])
+def test_resbranch_kernel_same_bits_as_three_respair_steps(C, N):
+    """resbranch_clx.hip (round 6): the three steps of a k = 3 ResBlock1 branch (dilations 1, 3, 5) in ONE launch, the residual stream in registers and the
+    operand windows in LDS, gives the SAME bits as three launches of the fused step (respair_clx.hip): plain, with a column mask (edges of packed utterances:
+    mask_div 4) and with beta + accumulate (the branch's last step), at lengths around the tile sizes (232 / 104 outputs per workgroup); and both agree with
+    the numpy oracle's three resblock steps (O.conv1d_same: the checker)."""
+    k, dils = 3, (1, 3, 5)
+    rng = np.random.default_rng(C * 1000 + N)
+    x = rng.standard_normal((N, C)).astype(np.float32)
+    w = (rng.standard_normal((6, C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b = rng.standard_normal((6, C)).astype(np.float32)
+    ref = _resbranch(x, w, b, k, dils, None, 1, 1.0, None, 0)
+    got = _resbranch(x, w, b, k, dils, None, 1, 1.0, None, 1)
+    np.testing.assert_array_equal(got, ref)
+    y = x.T.copy()
+    for q in range(3):
+        t = O.conv1d_same(O.leaky_relu(y, 0.1), w[2 * q], b[2 * q], dils[q])
+        y = O.conv1d_same(O.leaky_relu(t, 0.1), w[2 * q + 1], b[2 * q + 1], 1) + y
+    np.testing.assert_allclose(got.T, y, atol=3e-4, rtol=1e-5)
+    mask = (rng.random((N + 3) // 4) > 0.15).astype(np.uint8)
+    xm = x * np.repeat(mask, 4)[:N, None]                      # (a masked column holds zeros in the real planes)
+    prev = rng.standard_normal((N, C)).astype(np.float32) * np.repeat(mask, 4)[:N, None]
+    ref = _resbranch(xm, w, b, k, dils, mask, 4, 1.0 / 3, prev, 0)
+    got = _resbranch(xm, w, b, k, dils, mask, 4, 1.0 / 3, prev, 1)
+    np.testing.assert_array_equal(got, ref)
+    ref = _resbranch(xm, w, b, k, dils, mask, 4, 1.0, None, 0)
+    got = _resbranch(xm, w, b, k, dils, mask, 4, 1.0, None, 1)
+    np.testing.assert_array_equal(got, ref)
+    assert not np.any(got[np.repeat(mask, 4)[:N] == 0])
+    got = _resbranch(x, w, b, k, (5, 1, 3), None, 1, 1.0, None, 1)      # (another order of the dilations: same halo, other per-step reach)
+    np.testing.assert_array_equal(got, _resbranch(x, w, b, k, (5, 1, 3), None, 1, 1.0, None, 0))
+
+
 import contextlib
 
 
@@ -236,7 +280,44 @@ def test_gemm_bfs_f16x3_range():
         assert np.isnan(yn[:, 4]).all() and not np.isfinite(yn[:, 6]).any()
         assert np.isfinite(yn[:, [c for c in range(N) if c not in (4, 6)]]).all()
     finally:
-        _lib.check(lib.sbv2_debug_f16x3_saturation(0, 0, None))
+        _lib.check(lib.sbv2_debug_f16x3_saturation(0, 1, None))   # (counting is on by default since round 6; the call also resets the count)
+
+
+def test_f16x3_clamp_warns_once_per_handle(capfd):
+    """Real-checkpoint safety (round 6): counting the f16x3 split's clamps is ON by default, and a model handle prints ONE stderr warning, independent of
+    SBV2_LOG, the first time the count is non-zero, naming the bf16x6 fallback.  A tiny DeBERTa whose FFN up-projection is scaled by 1e6 produces GELU
+    outputs far beyond f16's +-65504 (the FFN intermediate exists only as f16x3 parts); the unscaled model stays silent."""
+    lib, cnt = _lib.lib(), C.c_uint64(0)
+    bc, bw = weights("bert", "tiny")
+    ids = np.array([1, 5, 9, 13, 17, 21, 2], np.int64)
+    msk = np.ones_like(ids)
+    _lib.check(lib.sbv2_debug_f16x3_saturation(0, 1, C.byref(cnt)))    # reset
+    quiet = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, bw), True)
+    if lib.sbv2_bert_gemm_parts(quiet.handle) != 4:
+        quiet.close()
+        pytest.skip("DeBERTa products are not on the f16x3 format in this environment (SBV2_BERT_GEMM)")
+    model.predict(quiet, ids, msk)
+    model.predict(quiet, ids, msk)
+    quiet.close()
+    assert "WARNING" not in capfd.readouterr().err
+    W = dict(bw)
+    W["deberta.encoder.layer.0.intermediate.dense.weight"] = (bw["deberta.encoder.layer.0.intermediate.dense.weight"] * np.float32(1e6)).astype(np.float32)
+    loud = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, W), True)
+    out = model.predict(loud, ids, msk)
+    err1 = capfd.readouterr().err
+    assert err1.count("sbv2_hip WARNING") == 1 and "SBV2_BERT_GEMM=bf16x6" in err1 and "65504" in err1
+    model.predict(loud, ids, msk)
+    assert "WARNING" not in capfd.readouterr().err          # once per handle
+    loud.close()
+    assert np.isfinite(out).all()                            # clamped, not overflowed
+    _lib.check(lib.sbv2_debug_f16x3_saturation(0, -1, C.byref(cnt)))
+    assert cnt.value > 0
+    # a second handle on the same (still dirty after the reset above? no: reset) device warns again when ITS input clamps
+    loud2 = model.load_model(synth.pack_blob(synth.KIND_BERT, bc, W), True)
+    model.predict(loud2, ids, msk)
+    assert capfd.readouterr().err.count("sbv2_hip WARNING") == 1
+    loud2.close()
+    _lib.check(lib.sbv2_debug_f16x3_saturation(0, 1, C.byref(cnt)))    # leave the count at zero for the tests that follow
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,L", [(1024, 1024, 1, 1, 66), (1024, 3072, 1, 1, 130), (4096, 1024, 1, 1, 66), (1024, 4096, 1, 1, 35),
@@ -816,6 +897,55 @@ def test_config2_b32_u128_default_path():
     print(f"configs[2]: worst waveform max-abs error of the 32 utterances vs the C oracle {worst:.3e}")
     assert worst < 5e-5
     pipe.close(); bs.close(); vs.close()
+
+
+def test_batch_row_vs_single_call_predicted_durations():
+    """Under the DEFAULT dispatch a single call and its batch row run different summation orders in DeBERTa (small-grid K splits, LayerNorm launch shapes),
+    and DeBERTa's features feed ceil(exp(logw) * length_scale): with PREDICTED durations (every other single-vs-batch test forces them) an utterance may get
+    another integer frame count when it is co-batched only where exp(logw) sits on a ceil edge.  32 full-shape utterances (8 224 symbols): features agree to
+    f32 rounding, log-durations to 1e-5 in the median (1e-3 at worst), and every symbol whose integer duration differs is within 1e-4 relative of an integer (at most 2 of them: the
+    f32-vs-f32 control of tools/flip_rate_bert.py is 2 per 205 600); on the size-independent dispatch the integers are equal.  INTEGRATION.md states it."""
+    bc, bw = weights("bert", "full")
+    vc, vw = weights("vits", "full")
+    bs, vs = model.load_model(blob("bert", "full"), True), model.load_model(blob("vits", "full"), False)
+    utts = [synth.make_utterance(128, bc, vc, seed=7300 + i) for i in range(32)]
+    ones = [np.ones_like(u["forced_durations"]) for u in utts]      # forced 1-frame durations keep the decoder cheap; the PREDICTIONS are compared
+
+    def run(batched):
+        if batched:
+            hs = model.predict_batch(bs, [u["input_ids"] for u in utts])
+        else:
+            hs = [model.predict(bs, u["input_ids"], u["attention_mask"]) for u in utts]
+        feats = [np.repeat(h, np.asarray(u["word2ph"], np.int64), axis=0).T.copy() for h, u in zip(hs, utts)]
+        part = [dict(u, bert=f, forced_durations=o) for u, f, o in zip(utts, feats, ones)]
+        d, lw = [], []
+        if batched:
+            model.synthesize_batch(vs, part, sdp_ratio=0.5, forced=True, fetch=False)
+            return feats, *model.fetch_durations(vs, sum(u["T_text"] for u in utts))
+        for q in part:
+            model.synthesize_batch(vs, [q], sdp_ratio=0.5, forced=True, fetch=False)
+            a, b = model.fetch_durations(vs, q["T_text"])
+            d.append(a); lw.append(b)
+        return feats, np.concatenate(d), np.concatenate(lw)
+
+    fb, db, lb = run(True)
+    f1, d1, l1 = run(False)
+    dfeat = max(float(np.abs(a - b).max()) for a, b in zip(fb, f1))
+    flips = np.nonzero(db != d1)[0]
+    print(f"single call vs batch row, predicted durations: features max-abs {dfeat:.2e}, logw max-abs {float(np.abs(lb - l1).max()):.2e}, "
+          f"{flips.size} of {db.size} integer durations differ")
+    # (the spline of the stochastic predictor amplifies locally: tools/flip_rate_bert.py's f32-vs-f32 control has median 1e-6 / max 7e-4 on log-durations)
+    assert dfeat < 2e-5 and float(np.median(np.abs(lb - l1))) < 1e-5 and float(np.abs(lb - l1).max()) < 1e-3
+    w = np.exp(lb.astype(np.float64))
+    for i in flips:
+        assert abs(w[i] - np.round(w[i])) < 1e-4 * w[i], f"symbol {i}: duration {db[i]} vs {d1[i]} away from a ceil edge (w = {w[i]})"
+    assert flips.size <= 2
+    with _size_independent_dispatch():
+        _, db0, lb0 = run(True)
+        _, d10, l10 = run(False)
+    np.testing.assert_array_equal(db0, d10)
+    np.testing.assert_array_equal(lb0, l10)
+    bs.close(); vs.close()
 
 
 def test_small_grid_dispatch_reaches_the_small_grid_kernels():

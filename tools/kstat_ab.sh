@@ -1,7 +1,7 @@
 # Builder tool: isolated kernel durations of bench steps (pipeline depth 1: one execution context, no overlap; bench.py's collect then fails on its first
 # ticket, AFTER the traced launches: the ms-per-step line stays empty, the kernel statistics are those of the steps that ran) for a list of
 # "NAME=VALUE" environment settings ("-" = defaults); prints the kernels whose name contains $PAT.
-#   bash tools/kstat_ab.sh flash - SBV2_FLASH_PARTS_MIN_T=0
+#   bash tools/kstat_ab.sh flash - SBV2_FLASH_Q=0
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
 PAT=$1; shift

@@ -1,4 +1,4 @@
-# Builder tool (GPU box): same-box A/B of when k_layernorm_ch requests gamma / beta / residual (LN_EARLY_MAX = 24: the build; 32: with the values for every
+# Builder tool (GPU box): same-box A/B of when k_layernorm_ch requests gamma / beta / residual (LN_EARLY_MAX = 32: the build, ops.hip's default; 24: round 5's first setting; with the values for every
 # instance; 0: behind the reductions as in rounds 1-4): single-utterance latency and the LayerNorm rows of its kernel stats.  The variants are whole libraries
 # built beforehand into build/libsbv2_hip_ln{32,0}.so (see the round-5 notes in DESIGN.md); the product library is restored at the end.
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
