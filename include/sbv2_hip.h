@@ -269,6 +269,16 @@ int sbv2_debug_respair(int device, const float* x, const float* w1, const float*
 /* 1 (default; SBV2_RESBRANCH=0): the k = 3 branches of the <= 64-channel decoder stages run their three steps in ONE launch (resbranch_clx.hip: y_1, y_2 stay
    on the chip, 2 plane passes through HBM per branch instead of 6); 0: three respair_clx launches (same bits).  Returns the previous value. */
 int sbv2_debug_set_resbranch(int on);
+/* 1 (default; SBV2_UPX=0): the ConvTranspose1d of the wide decoder stages (large launches) runs as ONE phased conv_clx.hip launch on pre-split operands
+   (rows = (phase, cout), taps = the union of the phases' input taps padded to an odd count); 0: conv_cl.hip's phase groups.  f32 rounding apart (another
+   summation order).  Returns the previous value. */
+int sbv2_debug_set_upx(int on);
+/* ConvTranspose1d(lrelu(x, pre_slope)) [cin][L] -> y [cout][L * stride] (weight [cin][cout][k], padding (k - stride) / 2) through the phased conv_clx launch;
+   mask (may be null): input position n and its `stride` outputs are kept iff mask[n / mask_div]; ys_sum (may be null): hi + lo of the bf16 parts of
+   lrelu(y, 0.1) the launch writes for the ResBlocks.  iters > 0: *ms = average duration.  Test / measurement hook (scripts/convert/convert_model.py:97-110's
+   `ups` layers). */
+int sbv2_debug_conv_transpose1d_clx(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k, int64_t L,
+                                    int64_t stride, float pre_slope, const uint8_t* mask, int64_t mask_div, int64_t iters, float* y, float* ys_sum, float* ms);
 /* A whole ResBlock1 branch (HifiGanResidualBlock.forward, modeling_vits.py:455-463; the graph of scripts/convert/convert_model.py:97-110): three steps
    y_q = conv2_q(lrelu(conv1_q(lrelu(y_{q-1}), dilations[q]) + b1_q)) + b2_q + y_{q-1}, result beta * y_3 [+ y when accumulate], masked by mask[n / mask_div]
    (a power of two; mask may be null) at every layer; channels-last x / y [N][C], w [6][C][C][k] and bias [6][C] in the order conv1_0, conv2_0, conv1_1, ...,
@@ -289,6 +299,11 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
    the result is also emitted as that many bf16 parts and y returns their sum.  iters > 0: average launch time in *ms.  Test hook. */
 int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
                         int parts, int act, int split_out, int64_t iters, float* y, float* ms);
+/* The same product for TWO inputs xa, xb [K][N] launched alternately (iters + 2 launches) on ONE K-split scratch buffer that is never cleared in between;
+   ya / yb = the last result of each.  A workgroup that summed a stale partial sum (the other input's, left in its XCD's L2 by the previous launch) shows up as a
+   wrong result: the race screen of gemm_bfs.hip's cross-workgroup K split.  parts as above. */
+int sbv2_debug_gemm_bfs_alt(int device, const float* xa, const float* xb, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
+                            int parts, int64_t iters, float* ya, float* yb);
 
 #ifdef __cplusplus
 }

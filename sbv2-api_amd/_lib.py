@@ -107,9 +107,13 @@ SYMBOLS = {
     "sbv2_debug_respair": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_int,
                                      C.c_int, f32p]),
     "sbv2_debug_set_resbranch": (C.c_int, [C.c_int]),
+    "sbv2_debug_set_upx": (C.c_int, [C.c_int]),
+    "sbv2_debug_conv_transpose1d_clx": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_void_p,
+                                                  C.c_int64, C.c_int64, f32p, f32p, f32p]),
     "sbv2_debug_resbranch": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, i64p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int,
                                        C.c_int64, f32p, f32p, C.c_void_p, C.c_int64]),
     "sbv2_debug_respair_clock": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.c_int]),
+    "sbv2_debug_gemm_bfs_alt": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, f32p, f32p]),
     "sbv2_debug_gemm_bfs": (C.c_int, [C.c_int, f32p, f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
                                       f32p, f32p]),
 }

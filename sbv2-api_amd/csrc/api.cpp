@@ -405,6 +405,101 @@ int sbv2_debug_conv_transpose1d(int device, const float* x, const float* w, cons
     API_END
 }
 
+int sbv2_debug_set_upx(int on) { return set_upx(on); }
+int sbv2_debug_conv_transpose1d_clx(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k, int64_t L,
+                                    int64_t stride, float pre_slope, const uint8_t* mask, int64_t mask_div, int64_t iters, float* y, float* ys_sum, float* ms) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    SBV2_REQUIRE(x && w && bias && y && mask_div >= 1 && (mask_div & (mask_div - 1)) == 0, "bad arguments");
+    Blob b = one_conv_blob(w, bias, {cin, cout, k}, cout);
+    WeightStore ws(b);
+    ClUpX u = build_upx(ws, w, bias, (int)cin, (int)cout, (int)k, (int)stride);
+    SBV2_REQUIRE(u.wx, "shape not supported by the phased conv_clx transposed convolution");
+    const int64_t Lo = L * stride;
+    std::vector<float> xt((size_t)L * cin), yt((size_t)Lo * cout);
+    for (int64_t ci = 0; ci < cin; ++ci)
+        for (int64_t n = 0; n < L; ++n) xt[(size_t)n * cin + ci] = x[(size_t)ci * L + n];
+    DevBuf dx(xt.size()), dy(yt.size());
+    HIP_CHECK(hipMemcpy(dx.p, xt.data(), sizeof(float) * xt.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dy.p, 0xFF, sizeof(float) * yt.size()));   // (NaN: every output row must be written)
+    DevBuf dxs(split_cl_bytes((int)cin, L) / 4 + 4), dys(split_cl_bytes((int)cout, Lo) / 4 + 4);
+    SplitClPlanes xs = make_split_cl(dxs.p, (int)cin, L, nullptr), ysp = make_split_cl(dys.p, (int)cout, Lo, nullptr);
+    split_cl(dx.p, (int)cin, L, (int)cin, pre_slope, xs, nullptr);
+    unsigned char* dm = nullptr;
+    int shift = 0;
+    while ((1 << shift) < mask_div) ++shift;
+    if (mask) {
+        const size_t nm = (size_t)((L + mask_div - 1) / mask_div);
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dm), nm));
+        HIP_CHECK(hipMemcpy(dm, mask, nm, hipMemcpyHostToDevice));
+    }
+    ConvClxParams p;
+    p.X = xs;
+    p.W = u.wx;
+    p.nmt = u.M / 32;
+    p.M = u.M;
+    p.N = (int)L;
+    p.K = (int)cin;
+    p.ntaps = u.ntaps;
+    p.shift0 = u.shift0;
+    p.shift_step = -1;
+    p.Y = dy.p;
+    p.ldy = (int)cout;
+    if (ys_sum) {
+        p.Ys = ysp;
+        p.ys_slope = 0.1f;
+    }
+    p.bias = u.bias;
+    p.mask = dm;                 // indexed by the INPUT position >> shift
+    p.mask_shift = shift;
+    p.out_stride = (int)stride;
+    p.phase_rows = (int)cout;
+    for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = u.phase_off[q];
+    try {
+        SBV2_REQUIRE(conv_clx_usable(p), "shape not supported by conv_clx");
+        launch_conv_clx(p, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        if (iters > 0 && ms) {
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) launch_conv_clx(p, nullptr);
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            *ms = t / (float)iters;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+    } catch (...) {
+        if (dm) (void)hipFree(dm);
+        throw;
+    }
+    if (dm) (void)hipFree(dm);
+    HIP_CHECK(hipMemcpy(yt.data(), dy.p, sizeof(float) * yt.size(), hipMemcpyDeviceToHost));
+    for (int64_t co = 0; co < cout; ++co)
+        for (int64_t n = 0; n < Lo; ++n) y[(size_t)co * Lo + n] = yt[(size_t)n * cout + co];
+    if (ys_sum) {
+        const int64_t rows = kClxFront + Lo + kClxBack;
+        std::vector<uint16_t> hs(split_cl_bytes((int)cout, Lo) / 2);
+        HIP_CHECK(hipMemcpy(hs.data(), ysp.p, hs.size() * 2, hipMemcpyDeviceToHost));
+        auto f = [](uint16_t h) {
+            const uint32_t v = (uint32_t)h << 16;
+            float o;
+            std::memcpy(&o, &v, 4);
+            return o;
+        };
+        for (int64_t co = 0; co < cout; ++co)
+            for (int64_t n = 0; n < Lo; ++n) {
+                const size_t base = ((size_t)(co >> 4) * 2 * rows + kClxFront + n) * 16 + (co & 15);
+                ys_sum[(size_t)co * Lo + n] = f(hs[base]) + f(hs[base + (size_t)rows * 16]);
+            }
+    }
+    API_END
+}
+
 int sbv2_debug_conv1d_cl(int device, const float* x, const float* w, const float* bias, int64_t cin, int64_t cout, int64_t k, int64_t L,
                          int64_t dilation, float pre_slope, int mode, int64_t iters, float* y, float* ms) {
     API_BEGIN
@@ -1054,8 +1149,10 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
     API_END
 }
 
-int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
-                        int parts, int act, int split_out, int64_t iters, float* y, float* ms) {
+// x2 / y2 (sbv2_debug_gemm_bfs_alt): a second input; the launches alternate between the two on ONE scratch buffer that is never cleared in between, so a
+// workgroup that read a stale partial sum (the other input's, left in its XCD's L2 by the previous launch) would show up in the result
+static int debug_gemm_bfs_impl(int device, const float* x, const float* x2, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
+                               int parts, int act, int split_out, int64_t iters, float* y, float* y2, float* ms) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
     SBV2_REQUIRE((parts == 2 || parts == 3 || parts == kPartsF16x3) && x && w && y && M >= 1 && N >= 4 && (N & 3) == 0 && (K & 15) == 0, "bad arguments");
@@ -1082,6 +1179,15 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     xs.ld = ld;
     xs.pstride = (int64_t)K * ld;
     split_planes(X, xs, nullptr);
+    DevBuf dx2(x2 ? (size_t)K * ld : 4), dxs2(x2 ? (size_t)split_nplanes(parts) * K * ld / 2 + 16 : 4);
+    SplitPlanes xs2 = xs;
+    if (x2) {
+        Plane X2{dx2.p, (int)K, (int)N, ld};
+        HIP_CHECK(hipMemset(X2.p, 0, sizeof(float) * (size_t)K * ld));
+        HIP_CHECK(hipMemcpy2D(X2.p, sizeof(float) * ld, x2, sizeof(float) * N, sizeof(float) * N, K, hipMemcpyHostToDevice));
+        xs2.p = dxs2.p;
+        split_planes(X2, xs2, nullptr);
+    }
     SplitPlanes ys;
     ys.p = dys.p;
     ys.parts = split_nplanes(split_out);
@@ -1092,14 +1198,18 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
     ys.pstride = (int64_t)M * ld;
     // split_out: 0 = f32 result only; 2 / 3 = the result is ALSO written as that many bf16 parts, and y returns their sum (what a consumer sees)
     // (scratch for the small-grid K split, as DeBERTa's forward provides it)
-    DevBuf dsk(((size_t)8 << 20) / sizeof(float) + 256);
-    HIP_CHECK(hipMemset(dsk.p, 0, ((size_t)8 << 20) + 256 * sizeof(float)));
+    constexpr size_t kWs = (size_t)48 << 20;   // (as BertModel::kSkWsBytes / kSkCounters)
+    DevBuf dsk(kWs / sizeof(float) + 1024);
+    HIP_CHECK(hipMemset(dsk.p, 0, kWs + 1024 * sizeof(float)));
     BfsSplitK sk;
     sk.ws = dsk.p;
-    sk.ws_bytes = (size_t)8 << 20;
-    sk.counters = reinterpret_cast<unsigned*>(dsk.p + (((size_t)8 << 20) / sizeof(float)));
-    sk.ncounters = 256;
-    auto run = [&]() { conv_bfs(pc, xs, &Y, split_out ? &ys : nullptr, nullptr, 1, nullptr, act, res ? &R : nullptr, 1.0f, 1.0f, -1, 0, &sk); };
+    sk.ws_bytes = kWs;
+    sk.counters = reinterpret_cast<unsigned*>(dsk.p + (kWs / sizeof(float)));
+    sk.ncounters = 1024;
+    int turn = 0;
+    auto run = [&]() {
+        conv_bfs(pc, (x2 && (turn++ & 1)) ? xs2 : xs, &Y, split_out ? &ys : nullptr, nullptr, 1, nullptr, act, res ? &R : nullptr, 1.0f, 1.0f, -1, 0, &sk);
+    };
     run();
     HIP_CHECK(hipDeviceSynchronize());
     if (iters > 0 && ms) {
@@ -1115,6 +1225,15 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
         *ms = t / (float)iters;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
+    }
+    if (x2) {   // the last launch of each input, back to back on the used scratch
+        turn = 1;
+        run();
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy2D(y2, sizeof(float) * N, Y.p, sizeof(float) * ld, sizeof(float) * N, M, hipMemcpyDeviceToHost));
+        turn = 0;
+        run();
+        HIP_CHECK(hipDeviceSynchronize());
     }
     HIP_CHECK(hipMemcpy2D(y, sizeof(float) * N, Y.p, sizeof(float) * ld, sizeof(float) * N, M, hipMemcpyDeviceToHost));
     if (split_out) {
@@ -1141,6 +1260,20 @@ int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float*
             }
     }
     API_END
+}
+
+int sbv2_debug_gemm_bfs(int device, const float* x, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
+                        int parts, int act, int split_out, int64_t iters, float* y, float* ms) {
+    return debug_gemm_bfs_impl(device, x, nullptr, w, bias, res, M, N, K, parts, act, split_out, iters, y, nullptr, ms);
+}
+int sbv2_debug_gemm_bfs_alt(int device, const float* xa, const float* xb, const float* w, const float* bias, const float* res, int64_t M, int64_t N, int64_t K,
+                            int parts, int64_t iters, float* ya, float* yb) {
+    if (!xb || !yb) {
+        set_last_error("bad arguments");
+        return 1;
+    }
+    float ms = 0.f;
+    return debug_gemm_bfs_impl(device, xa, xb, w, bias, res, M, N, K, parts, 0, 0, iters, ya, yb, &ms);
 }
 
 int sbv2_debug_time_conv1d(int device, int64_t cin, int64_t cout, int64_t k, int64_t L, int64_t dilation, int64_t iters, float* ms) {

@@ -473,11 +473,19 @@ struct ConvClxParams {
     int mask_shift = -1;
     unsigned long long* stamps = nullptr;  // diagnostics: kClxStampWords per workgroup (sbv2_debug_clx_timeline)
     int variant = 0;            // diagnostics (sbv2_debug_clx_timeline): kernel variant under test in a builder experiment; the library holds variant 0 only
+    // Phased output (round 6: the polyphase ConvTranspose1d of the wide decoder stages): row m of the product is output channel m % phase_rows of phase
+    // m / phase_rows, and position n of that phase is OUTPUT row n * out_stride + phase_off[phase] of Y / Ys (Ys.C == phase_rows, Ys.N == N * out_stride;
+    // phase_rows a multiple of 64).  N, X and the mask stay indexed by the INPUT position: pass mask_shift = (output positions per mask entry) / out_stride.
+    // No residual, no accumulate, whole-tile launches (N >= 256).
+    int out_stride = 1, phase_rows = 0;    // phase_rows 0: not phased
+    int phase_off[kMaxPhases] = {0};
+    double prof_flops = 0.0;               // > 0: the launch's algorithmic FLOP for sbv2_prof_* (a phased launch multiplies zero padding taps too)
 };
 int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv_clx starts for p
 bool conv_clx_usable(const ConvClxParams& p);
 bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
 int set_clx(int on);  // returns the previous setting
+int set_upx(int on);  // the wide stages' transposed convolutions as phased conv_clx launches (default 1); returns the previous setting
 // gemm_bfs: small grids split their K loop over groups of waves (another summation order than the batch's tiles; 0 = the unsplit, batch-order dispatch)
 bool ksplit_enabled();
 int set_ksplit(int on);  // returns the previous setting
@@ -536,6 +544,7 @@ struct ResBranchParams {
 };
 bool resbranch_usable(const ResBranchParams& p);
 bool resbranch_enabled();
+bool resbranch_wanted(int C);   // the default fuses C <= 32 (mode 2: C = 64 too)
 int set_resbranch(int on);      // returns the previous setting (default 1; SBV2_RESBRANCH=0)
 void launch_resbranch(const ResBranchParams& p, hipStream_t stream);
 

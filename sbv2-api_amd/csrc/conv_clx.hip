@@ -118,9 +118,11 @@ __device__ __forceinline__ void clx_halves(const bf16x8& a, const bf16x8& b, bf1
 // path set the register allocation of the whole kernel and the interior epilogue spilled in the middle of its load burst; the decoder's frame layout is
 // rounded so that the wide stages' planes are whole tiles.)
 // ... and the k-major epilogue (the flow's second FFN convolution) is an instance of its own (EPI 2; 1 = EDGE, 0 = whole tiles, 3 = whole tiles with non-temporal stores).
-template <int NTAPS, int kClxWR, int kClxXB, int XR, int EPI>
+// PH: phased output rows (ConvClxParams::phase_rows: the polyphase transposed convolutions, round 6); whole-tile epilogues only.
+template <int NTAPS, int kClxWR, int kClxXB, int XR, int EPI, bool PH = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 4096 + kClxXB * 2 * XR * 32 <= 53 * 1024 ? 3 : 2))) void conv_clx_kernel(const ClxKernelParams kp) {
     constexpr bool EDGE = EPI == 1;
+    static_assert(!PH || EPI == 0 || EPI == 3, "phased output: whole-tile channels-last epilogues only");
     constexpr bool NT = EPI == 3;   // EPI 0 with non-temporal stores (result planes larger than the caches)
     constexpr int NPW = 64;                    // positions per wave
     constexpr int NTW = 256;                   // positions per workgroup
@@ -500,10 +502,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                     load_rows(1, p.Y, p.ldy, m);
                 }
             }
-            float* yp = p.Y ? p.Y + (int64_t)nf16 * p.ldy + m : nullptr;
-            const int64_t ystep = (int64_t)16 * p.ldy;
+            // PH: this workgroup's 64 rows are channels mo .. mo + 63 of ONE phase; its position n is output row n * out_stride + phase_off[phase]
+            int ostride = 1, mch = m;
+            int64_t orow = nf16;
+            if constexpr (PH) {
+                const int ph = m0 / p.phase_rows;
+                ostride = p.out_stride;
+                mch = m - ph * p.phase_rows;
+                orow = (int64_t)nf16 * ostride + p.phase_off[ph];
+            }
+            float* yp = p.Y ? p.Y + orow * p.ldy + mch : nullptr;
+            const int64_t ystep = (int64_t)16 * ostride * p.ldy;
+            const int64_t qstep = (int64_t)512 * ostride;
             // bf16 parts of lrelu(result), chunk-major: 8 channels = 16 bytes of a 32-byte row; the lo plane follows the hi plane
-            char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(m >> 4) * 2) * yplane + ((int64_t)p.Ys.front + nf16) * 32 + (m & 15) * 2 : nullptr;
+            char* qs = p.Ys.p ? static_cast<char*>(p.Ys.p) + ((int64_t)(mch >> 4) * 2) * yplane + ((int64_t)p.Ys.front + orow) * 32 + (mch & 15) * 2 : nullptr;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 f32x4v v[2];
@@ -535,11 +547,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                         l8[e] = (__bf16)(x - (float)h8[e]);
                     }
                     if constexpr (NT) {
-                        __builtin_nontemporal_store(h8, reinterpret_cast<bf16x8*>(qs + it * 512));
-                        __builtin_nontemporal_store(l8, reinterpret_cast<bf16x8*>(qs + it * 512 + yplane));
+                        __builtin_nontemporal_store(h8, reinterpret_cast<bf16x8*>(qs + it * qstep));
+                        __builtin_nontemporal_store(l8, reinterpret_cast<bf16x8*>(qs + it * qstep + yplane));
                     } else {
-                        *reinterpret_cast<bf16x8*>(qs + it * 512) = h8;
-                        *reinterpret_cast<bf16x8*>(qs + it * 512 + yplane) = l8;
+                        *reinterpret_cast<bf16x8*>(qs + it * qstep) = h8;
+                        *reinterpret_cast<bf16x8*>(qs + it * qstep + yplane) = l8;
                     }
                 }
             }
@@ -690,17 +702,31 @@ bool conv_clx_usable(const ConvClxParams& p) {
     if (p.mask && p.mask_shift < 0) return false;
     if (p.Y && (p.ldy & 3)) return false;
     if (p.R && (p.ldr & 3)) return false;
-    if (p.Ys.p && (p.Ys.C != p.M || p.Ys.N != p.N)) return false;
+    if (p.phase_rows) {   // phased output (a polyphase transposed convolution)
+        if ((p.phase_rows & 63) || p.M % p.phase_rows || p.M / p.phase_rows > kMaxPhases || p.out_stride < 1 || p.R || p.accumulate || p.Ykm || p.N < kClxNT ||
+            !(p.ntaps == 3 || p.ntaps == 5)) return false;
+        if (p.Y && p.ldy < p.phase_rows) return false;
+        if (p.Ys.p && (p.Ys.C != p.phase_rows || p.Ys.N != (int64_t)p.N * p.out_stride)) return false;
+        for (int q = 0; q < p.M / p.phase_rows; ++q)
+            if (p.phase_off[q] < 0 || p.phase_off[q] >= p.out_stride) return false;
+    } else if (p.Ys.p && (p.Ys.C != p.M || p.Ys.N != p.N)) return false;
     return p.N >= 1 && p.X.N == p.N;
 }
 
 static thread_local int64_t* g_clx_grid_only = nullptr;   // clx_grid_workgroups: report the grid instead of launching
 
-template <int NTAPS, int WR, int XB, int XR, int EPI>
+template <int NTAPS, int WR, int XB, int XR, int EPI, bool PH = false>
 static void launch_clx_e(ClxKernelParams kp, hipStream_t stream);
 
 template <int NTAPS, int WR, int XB, int XR>
 static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
+    if constexpr ((NTAPS == 3 || NTAPS == 5) && XR == 288) {
+        if (kp.p.phase_rows) {   // (conv_clx_usable: whole tiles, nothing accumulates)
+            if ((int64_t)kp.p.N * kp.p.M * 4 >= ((int64_t)128 << 20)) return launch_clx_e<NTAPS, WR, XB, XR, 3, true>(kp, stream);
+            return launch_clx_e<NTAPS, WR, XB, XR, 0, true>(kp, stream);
+        }
+    }
+    SBV2_REQUIRE(!kp.p.phase_rows, "conv_clx: phased output is instantiated for 3 / 5 taps on 288-row windows");
     if (kp.p.Ykm) launch_clx_e<NTAPS, WR, XB, XR, 2>(kp, stream);
     else if (kp.p.N % kClxNT == 0 || (!kp.p.accumulate && kp.p.N >= kClxNT)) {
         // result planes of >= 128 MB (a batch's decoder stages; a long utterance) leave through non-temporal stores (EPI 3); smaller ones (a single utterance: 29 MB;
@@ -711,7 +737,7 @@ static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
     else launch_clx_e<NTAPS, WR, XB, XR, 1>(kp, stream);
 }
 
-template <int NTAPS, int WR, int XB, int XR, int EPI>
+template <int NTAPS, int WR, int XB, int XR, int EPI, bool PH>
 static void launch_clx_e(ClxKernelParams kp, hipStream_t stream) {
     const ConvClxParams& p = kp.p;
     SBV2_REQUIRE(kp.xrows <= XR, "conv_clx: tap span exceeds the window buffer of this configuration");
@@ -722,7 +748,7 @@ static void launch_clx_e(ClxKernelParams kp, hipStream_t stream) {
         return;
     }
     const size_t lds = std::max<size_t>((size_t)WR * 4096 + (size_t)XB * 2 * XR * 32, (size_t)4 * 64 * 36 * sizeof(float));
-    auto kern = conv_clx_kernel<NTAPS, WR, XB, XR, EPI>;
+    auto kern = conv_clx_kernel<NTAPS, WR, XB, XR, EPI, PH>;
     static std::atomic<uint64_t> lds_allowed{0};
     allow_full_lds(reinterpret_cast<const void*>(kern), lds_allowed);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -736,7 +762,8 @@ static void launch_clx_e(ClxKernelParams kp, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(p.Ykm || p.ntaps == 5 ? 28 : 26, 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);   // 28: the flow's FFN convs
+        // 28: the flow's FFN convs; 8: a phased launch = a transposed convolution, counted with conv_cl<2,split-bf16> where the upsamplers always were
+        conv_prof_add(PH ? 8 : (p.Ykm || p.ntaps == 5 ? 28 : 26), p.prof_flops > 0.0 ? p.prof_flops : 2.0 * p.M * (double)p.N * p.K * p.ntaps, e0, e1);
     }
 }
 

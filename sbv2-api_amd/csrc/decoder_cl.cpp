@@ -121,6 +121,48 @@ void* pack_cl_pairs(WeightStore& ws, const float* w, int k) {
     return ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
 }
 
+ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s) {
+    ClUpX u;
+    const int pad = (k - s) / 2;
+    if (k - 2 * pad != s || s < 1 || s > kMaxPhases || (cout & 63) || (cin & 31)) return u;
+    int tmin = 1 << 30, tmax = -(1 << 30);
+    for (int r = 0; r < s; ++r)
+        for (int tt = -k; tt <= k; ++tt) {
+            const int j = s * tt + r + pad;
+            if (j >= 0 && j < k) {
+                tmin = std::min(tmin, tt);
+                tmax = std::max(tmax, tt);
+            }
+        }
+    int U = tmax - tmin + 1;
+    if ((U & 1) == 0) ++U;                       // a zero tap behind the last one
+    if (!(U == 3 || U == 5)) return u;
+    const int M = s * cout;
+    std::vector<float> w((size_t)M * cin * U, 0.f), bias((size_t)M);
+    double macs = 0;
+    for (int r = 0; r < s; ++r)
+        for (int co = 0; co < cout; ++co) {
+            bias[(size_t)r * cout + co] = ub ? ub[co] : 0.f;
+            for (int ti = 0; ti < U; ++ti) {
+                const int j = s * (tmin + ti) + r + pad;
+                if (j < 0 || j >= k) continue;
+                if (co == 0) macs += (double)cin * cout;
+                for (int ci = 0; ci < cin; ++ci) w[((size_t)(r * cout + co) * cin + ci) * U + ti] = wt[((size_t)ci * cout + co) * k + j];
+            }
+        }
+    u.wx = pack_clx16(ws, w.data(), M, cin, U);
+    u.bias = ws.upload(bias.data(), bias.size());
+    u.M = M;
+    u.K = cin;
+    u.ntaps = U;
+    u.shift0 = -tmin;                            // tap ti reads input position n - (tmin + ti)
+    u.nph = s;
+    u.cout = cout;
+    u.alg_macs_per_pos = macs;
+    for (int r = 0; r < s; ++r) u.phase_off[r] = r;
+    return u;
+}
+
 // pack_cl's precision code of a decoder arithmetic (dec_mode_ / ClStage::mode)
 static int cl_parts_of(int mode) { return mode == 1 ? 2 : (mode == 2 ? 1 : 3); }
 
@@ -197,6 +239,7 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
             g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, cl_parts_of(st.mode), bias.data());
             st.up.push_back(g);
         }
+        if (st.mode == 1 && st.ch >= 64) st.upx = build_upx(*ws_, t.data, ub, cin, cout, k, s);
         for (int j = 0; j < nk; ++j) {
             ClBranch rb;
             rb.k = cfg_.res_kernels[j];
@@ -225,6 +268,9 @@ bool clx_wanted(int64_t tiles, int64_t min_tiles) {
     return m == 2 || (m == 1 && tiles >= min_tiles);
 }
 int set_clx(int on) { return g_clx.exchange(on); }
+// the transposed convolutions of the wide stages as phased conv_clx launches (round 6; SBV2_UPX=0 / sbv2_debug_set_upx(0): conv_cl's phase groups, for A/B runs)
+static std::atomic<int> g_upx{getenv("SBV2_UPX") ? atoi(getenv("SBV2_UPX")) : 1};
+int set_upx(int on) { return g_upx.exchange(on); }
 
 void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l,
                         const unsigned char* mask, int mask_div, float pre_slope, const float* R, int ldr, float beta, int accumulate) {
@@ -268,21 +314,24 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
     int U = 1;
     int64_t Lcur = Lf;
     const int nk = (int)cfg_.res_kernels.size();
+    SplitClPlanes cur_s;         // bf16 parts of lrelu(cur, 0.1) when the previous stage's last launch wrote them (the operand of a conv_clx transposed convolution)
+    bool cur_s_ok = false;
+    // whether stage si's transposed convolution runs as ONE phased conv_clx launch (round 6; conv_cl's phase groups ran one 8-wave workgroup per CU at 233
+    // registers: 1.0 ms per launch at the 128-channel stage for 0.24 ms of bytes and 0.33 ms of MFMA work, profiles/r06d_decoder_kernel_list.txt)
+    auto upx_wanted = [&](size_t si, int64_t Lin, int Uin) {
+        if (si >= cl_stages_.size()) return false;
+        const ClStage& s2 = cl_stages_[si];
+        return clx_enabled() && g_upx.load(std::memory_order_relaxed) != 0 && s2.mode == 1 && s2.upx.wx != nullptr && Lin >= 256 && (Uin & (Uin - 1)) == 0 &&
+               clx_wanted((Lin / 256) * (s2.upx.M / 64), clx_min_tiles());
+    };
     for (size_t si = 0; si < cl_stages_.size(); ++si) {
         const ClStage& st = cl_stages_[si];
+        const int Uin = U;
         U *= st.rate;
         const int64_t Lo = (int64_t)Lf * U;
         SBV2_REQUIRE(Lo < (1ll << 31), "batch too long for 32-bit positions");
         C = st.ch;
         float* XS = ar.array<float>((size_t)Lo * C);
-        const Arena::Mark mk = ar.mark();
-        float* XU = ar.array<float>((size_t)Lo * C);
-        float* T1 = ar.array<float>((size_t)Lo * C);
-        float* YA = ar.array<float>((size_t)Lo * C);
-        float* YB = ar.array<float>((size_t)Lo * C);
-        // Wide stages (>= 128 channels, split-bf16): the ResBlock convolutions read PRE-SPLIT operands (conv_clx.hip: LDS-DMA only, one barrier
-        // per tap).  The stage input is split once (split_cl); every other operand is written by the producing convolution's epilogue as the
-        // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
         int ushift = 0;
         while ((1 << ushift) < U) ++ushift;
         // (launches of at least clx_min_tiles() tiles: smaller ones do not pay for the extra halo launches.  The two paths agree to f32 rounding,
@@ -295,6 +344,18 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             for (int d : rb.dil)
                 if (d * (rb.k - 1) > 64 || d * (rb.k - 1) / 2 > kClxFront) clx = false;
         }
+        // the NEXT stage's transposed convolution on conv_clx reads lrelu(XS) as bf16 parts: this stage's last launch writes them next to XS
+        const bool next_upx = clx && upx_wanted(si + 1, Lo, U);
+        SplitClPlanes XSs;
+        if (next_upx) XSs = make_split_cl(ar.alloc(split_cl_bytes(C, Lo)), C, Lo, stream_);
+        const Arena::Mark mk = ar.mark();
+        float* XU = ar.array<float>((size_t)Lo * C);
+        float* T1 = ar.array<float>((size_t)Lo * C);
+        float* YA = ar.array<float>((size_t)Lo * C);
+        float* YB = ar.array<float>((size_t)Lo * C);
+        // Wide stages (>= 128 channels, split-bf16): the ResBlock convolutions read PRE-SPLIT operands (conv_clx.hip: LDS-DMA only, one barrier
+        // per tap).  The stage input is split once (split_cl); every other operand is written by the producing convolution's epilogue as the
+        // bf16 parts of lrelu(result), next to (conv2) or instead of (conv1) the f32 plane.  Same bits as the conv_cl path.
         SplitClPlanes XUs, T1s, YsA, YsB;
         if (clx) {
             const size_t sb = split_cl_bytes(C, Lo);
@@ -305,41 +366,76 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         }
         // (the stage input's parts are written by the transposed convolution's own epilogue below: no separate split pass over XU)
         bool parts_done = clx;   // every phase group's launch wrote its share of XUs
-        for (const auto& g : st.up) {
-            ConvClParams p;
-            p.X = cur;
-            p.ldx = st.cin;
-            p.NB = (int)Lcur;
-            p.W = g.c.w;
-            p.nmt = g.c.nmt;
-            p.tm = g.c.tm;
-            p.split = st.mode == 1;
-            p.f16 = st.mode == 3;
-            p.M = g.c.M;
-            p.N = (int)Lcur;
-            p.K = st.cin;
-            p.ntaps = g.ntaps;
-            for (int t = 0; t < g.ntaps; ++t) p.shift[t] = g.shift[t];
-            p.Y = XU;
-            p.ldy = C;
-            p.bias = g.c.bias;
-            p.pre_slope = 0.1f;
-            p.mask = fl.d_mask;
-            p.mask_div = U;
-            p.out_stride = st.rate;
-            p.phase_rows = C;
-            for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
-            if (clx && conv_cl_parts_ok(p)) {
-                p.ys_p = XUs.p;
-                p.ys_rows = (int64_t)XUs.front + XUs.N + XUs.back;
-                p.ys_front = XUs.front;
-                p.ys_slope = 0.1f;
-            } else {
-                parts_done = false;
+        if (upx_wanted(si, Lcur, Uin)) {
+            // ONE phased conv_clx launch: rows (phase, cout), the union of the phases' taps; its operand = bf16 parts of lrelu(cur, 0.1)
+            if (!cur_s_ok) {
+                cur_s = make_split_cl(ar.alloc(split_cl_bytes(st.cin, Lcur)), st.cin, Lcur, stream_);
+                split_cl(cur, st.cin, Lcur, st.cin, 0.1f, cur_s, stream_);
             }
-            launch_conv_cl(p, stream_);
+            int ushift_in = 0;
+            while ((1 << ushift_in) < Uin) ++ushift_in;
+            ConvClxParams pu;
+            pu.X = cur_s;
+            pu.W = st.upx.wx;
+            pu.nmt = st.upx.M / 32;
+            pu.M = st.upx.M;
+            pu.N = (int)Lcur;
+            pu.K = st.cin;
+            pu.ntaps = st.upx.ntaps;
+            pu.shift0 = st.upx.shift0;
+            pu.shift_step = -1;
+            pu.Y = XU;
+            pu.ldy = C;
+            if (clx) {
+                pu.Ys = XUs;
+                pu.ys_slope = 0.1f;
+            }
+            pu.bias = st.upx.bias;
+            pu.mask = fl.d_mask;
+            pu.mask_shift = ushift_in;      // (the mask is per frame: output row >> ushift == input position >> ushift_in)
+            pu.out_stride = st.rate;
+            pu.phase_rows = C;
+            for (int q = 0; q < kMaxPhases; ++q) pu.phase_off[q] = st.upx.phase_off[q];
+            pu.prof_flops = 2.0 * st.upx.alg_macs_per_pos * (double)Lcur;
+            SBV2_REQUIRE(conv_clx_usable(pu), "decoder: the phased transposed convolution does not fit conv_clx");
+            launch_conv_clx(pu, stream_);
+        } else {
+            for (const auto& g : st.up) {
+                ConvClParams p;
+                p.X = cur;
+                p.ldx = st.cin;
+                p.NB = (int)Lcur;
+                p.W = g.c.w;
+                p.nmt = g.c.nmt;
+                p.tm = g.c.tm;
+                p.split = st.mode == 1;
+                p.f16 = st.mode == 3;
+                p.M = g.c.M;
+                p.N = (int)Lcur;
+                p.K = st.cin;
+                p.ntaps = g.ntaps;
+                for (int t = 0; t < g.ntaps; ++t) p.shift[t] = g.shift[t];
+                p.Y = XU;
+                p.ldy = C;
+                p.bias = g.c.bias;
+                p.pre_slope = 0.1f;
+                p.mask = fl.d_mask;
+                p.mask_div = U;
+                p.out_stride = st.rate;
+                p.phase_rows = C;
+                for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = g.phase_off[q];
+                if (clx && conv_cl_parts_ok(p)) {
+                    p.ys_p = XUs.p;
+                    p.ys_rows = (int64_t)XUs.front + XUs.N + XUs.back;
+                    p.ys_front = XUs.front;
+                    p.ys_slope = 0.1f;
+                } else {
+                    parts_done = false;
+                }
+                launch_conv_cl(p, stream_);
+            }
+            if (clx && !parts_done) split_cl(XU, C, Lo, C, 0.1f, XUs, stream_);   // (small launches: one pass over the finished plane, same bits)
         }
-        if (clx && !parts_done) split_cl(XU, C, Lo, C, 0.1f, XUs, stream_);   // (small launches: one pass over the finished plane, same bits)
         for (int j = 0; j < nk; ++j) {
             const ClBranch& rb = st.branches[j];
             const float* y = XU;
@@ -347,7 +443,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             const int nd = (int)rb.dil.size();
             // k = 3 branches of the <= 64-channel stages: all three steps in ONE launch (resbranch_clx.hip: the residual stream stays in registers, the
             // operands in LDS; 2 plane passes through HBM instead of 6; same bits as the three fused steps below)
-            if (!clx && fuse_pairs_ && resbranch_enabled() && C <= 64 && st.mode == 1 && nd == kResBranchSteps && (U & (U - 1)) == 0) {
+            if (!clx && fuse_pairs_ && resbranch_wanted(C) && C <= 64 && st.mode == 1 && nd == kResBranchSteps && (U & (U - 1)) == 0) {
                 ResBranchParams bp;
                 bp.X = XU;
                 bp.Y = XS;
@@ -408,6 +504,9 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
                     if (!last) {
                         p2.Ys = *yns;
                         p2.ys_slope = 0.1f;
+                    } else if (next_upx && j + 1 == nk) {   // the stage's finished sum: lrelu(XS, 0.1) as the next transposed convolution's operand
+                        p2.Ys = XSs;
+                        p2.ys_slope = 0.1f;
                     }
                     p2.bias = rb.c2[q].bias;
                     p2.R = y;
@@ -455,6 +554,8 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
         ar.rewind(mk);
         cur = XS;
         Lcur = Lo;
+        cur_s = XSs;
+        cur_s_ok = next_upx;
     }
     pcm_lens_.assign(n, 0);
     pcm_offs_.assign(n, 0);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) __attribute__((amdgpu_waves_per_
                     acc[i][j][r] = 0.f;
                     if (F16) accx[i][j][r] = 0.f;
                 }
-        static_assert(TM * TN == 1, "the K split serves the small-grid configuration (one 32 x 32 tile per wave)");
+        if constexpr (TM * TN == 1) {
         // four groups' partial sums are requested before the first of them is added (two memory round trips for ks = 8 instead of eight), added in group order
         constexpr int kBatch = 4;
 #pragma unroll 1
@@ -438,6 +438,9 @@ __global__ __launch_bounds__(64 * WM * WN * KG) __attribute__((amdgpu_waves_per_
                             if (F16) accx[0][0][4 * q + e] += v[gi][4 + q][e];
                         }
                 }
+        }
+        } else {
+            static_assert(TM * TN == 1, "the K split serves the small-grid configuration (one 32 x 32 tile per wave)");
         }
         __syncthreads();   // (wave 0's transpose tile starts at smem: `arrived` has been read by everybody)
     }
@@ -669,6 +672,10 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
         // 64 x 128 on 3 / 6 slots, 128 x 64, two chunks per barrier, 64 x 64 for the 1024-row products, 4 / 12 / 16 slots for small grids: all slower
         // or equal; profiles/HISTORY.md.)
         if (big) {
+            // (Round 6 measured the cross-workgroup K split at this shape too, two workgroups per 64 x 128 tile of DeBERTa's K = 4096 product, 272 -> 544
+            // workgroups on 768 slots: 90.2 -> 86.9-88.0 us per launch, profiles/r06g_bfs_batch_ksplit_probe.txt; at K = 1024 26.8 -> 35.9.  These launches
+            // are not waiting for empty slots: 272 tiles x 256 chunks x 12 KB of operand tiles = 835 MB through the L2 -> LDS path in 88 us = 9.5 TB/s,
+            // i.e. 21.8 algorithmic FLOP per staged byte x 9.5 TB/s = the 207 TFLOP/s they reach whatever the number of workgroups.  Not kept.)
             launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
         } else {
             // Small grids with a long K loop and scratch from the caller (DeBERTa's FFN down projection in a single-utterance call, K = 4096: 30.1 -> 12-18 us):

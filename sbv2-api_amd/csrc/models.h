@@ -61,6 +61,17 @@ class WeightStore;
 // w is [M][K][k] (Conv1d layout); K is zero-padded to a multiple of 16
 ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
 void* pack_clx16(WeightStore& ws, const float* w, int M, int K, int k);
+// A ConvTranspose1d (weight [cin][cout][k], stride s, padding (k - s) / 2) as ONE phased product for conv_clx.hip (round 6): rows (phase, cout), taps = the
+// union of the phases' input taps (zero weights where a phase has none), padded to an odd count (conv_clx pairs its steps across chunks: 3 or 5 taps); tap t
+// reads input position n + shift0 - t.  wx == nullptr: the shape does not fit (decoder_cl.cpp falls back to conv_cl.hip's phase groups).
+struct ClUpX {
+    void* wx = nullptr;
+    float* bias = nullptr;      // per row (phase, cout)
+    int M = 0, K = 0, ntaps = 0, shift0 = 0, nph = 0, cout = 0;
+    double alg_macs_per_pos = 0;   // multiply-adds per input position that are not padding (the launch's algorithmic FLOP for the profile)
+    int phase_off[kMaxPhases] = {0};
+};
+ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s);
 void* pack_cl_pairs(WeightStore& ws, const float* w, int k);   // w [16][16][k] -> tap-pair fragments (split-bf16) for respair_clx's 16-channel kernel
 // w is [M][K] (Linear / 1x1 conv): bf16 parts (2 = hi + lo, 3 = hi + mid + lo) as MFMA A fragments; K must be a multiple of 16
 BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts);
@@ -157,8 +168,8 @@ class BertModel {
     Arena arena_;
     hipStream_t stream_ = nullptr;
     unsigned* sk_counters_ = nullptr;   // this context's arrival counters for gemm_bfs' small-grid K split (kSkCounters, zero between launches)
-    static constexpr int kSkCounters = 256;
-    static constexpr size_t kSkWsBytes = (size_t)8 << 20;
+    static constexpr int kSkCounters = 1024;
+    static constexpr size_t kSkWsBytes = (size_t)48 << 20;   // (round 6: the batch's K = 4096 product: 272 tiles x 2 groups x 64 KB)
     SatWatch sat_watch_;                // f16x3 clamp warning of this handle (common.h)
     Plane out_;
     SegLayout layout_;
@@ -297,6 +308,7 @@ class VitsModel {
     };
     struct ClStage {
         std::vector<ClUpGroup> up;
+        ClUpX upx;              // the same transposed convolution as one phased conv_clx launch (large batches of the wide stages; else conv_cl's groups)
         std::vector<ClBranch> branches;
         int cin, ch, rate;
         int mode = 1;   // the stage's arithmetic (dec_mode_ codes 1 .. 3; SBV2_DECODER_STAGES)

@@ -627,9 +627,16 @@ static void launch_rb(const ResBranchParams& p, hipStream_t stream) {
     }
 }
 
+// 0: three launches of the fused step; 1 (default): C <= 32; 2: C = 64 too.  (Measured, profiles/r06b_bench_resbranch_ab.json + r06d_decoder_kernel_list.txt:
+// at C = 64 the fused branch takes as long as its three steps in isolation (1.19 ms per half plane either way: both are bound by the L2 -> LDS weight stream
+// and LDS reads of a 32 x 64 wave tile, not by HBM) and 0.25 ms MORE inside the step; at C = 32 / 16 it is 21-29 % faster.)
 static std::atomic<int> g_rb{getenv("SBV2_RESBRANCH") ? atoi(getenv("SBV2_RESBRANCH")) : 1};   // sbv2_debug_set_resbranch
 int set_resbranch(int on) { return g_rb.exchange(on); }
 bool resbranch_enabled() { return g_rb.load(std::memory_order_relaxed) != 0; }
+bool resbranch_wanted(int C) {
+    const int m = g_rb.load(std::memory_order_relaxed);
+    return m >= 2 || (m == 1 && C <= 32);
+}
 
 bool resbranch_usable(const ResBranchParams& p) {
     if (!(p.C == 16 || p.C == 32 || p.C == 64) || p.k != 3 || p.N < 1 || !(p.slope >= 0.f && p.slope <= 1.f) || (p.mask && p.mask_shift < 0)) return false;

@@ -219,7 +219,7 @@ def test_gemm_bfs_kernel(K, M, N):
         assert float(np.abs(yhs - g).max()) < max(8 * err32, 2e-5)
 
 
-@pytest.mark.parametrize("K,M,N", [(1024, 1024, 68), (1024, 3072, 68), (1024, 4096, 68), (4096, 1024, 68), (4096, 1024, 132), (2048, 192, 260)])
+@pytest.mark.parametrize("K,M,N", [(1024, 1024, 68), (1024, 3072, 68), (1024, 4096, 68), (4096, 1024, 68), (4096, 1024, 132), (2048, 192, 260), (2048, 512, 1100)])
 def test_gemm_bfs_small_grid_k_split(K, M, N):
     """gemm_bfs' small-grid K split (SK: several workgroups per output tile, the last one to arrive adds the partial sums in group order): against the f64
     product and the unsplit kernel (sbv2_debug_set_ksplit(0)), the same bits on every repetition (the order of the sum does not depend on which workgroup
@@ -244,6 +244,15 @@ def test_gemm_bfs_small_grid_k_split(K, M, N):
         d = float(np.abs(first - unsplit).max())
         print(f"gemm_bfs K split vs unsplit ({K} x {M} x {N}): max-abs {d:.2e}")
         assert d < 2e-5
+        # stale partial sums: two DIFFERENT inputs alternate on one scratch buffer that is never cleared (a stale L2 line of the previous launch would hold the
+        # other input's sums); each must give the bits of its own single launch
+        lib.sbv2_debug_set_ksplit(1)
+        x2 = rng.standard_normal((K, N)).astype(np.float32)
+        ya, yb = np.empty((M, N), np.float32), np.empty((M, N), np.float32)
+        P = lambda a: a.ctypes.data_as(f32p)
+        _lib.check(lib.sbv2_debug_gemm_bfs_alt(0, P(x), P(x2), P(w), P(b), P(r), M, N, K, 4, 24, P(ya), P(yb)))
+        np.testing.assert_array_equal(ya, first)
+        np.testing.assert_array_equal(yb, _gemm_bfs(x2, w, b, r, 4))
     finally:
         lib.sbv2_debug_set_ksplit(prev)
 
@@ -356,6 +365,33 @@ def test_conv_transpose_kernel(cin, cout, k, s, p, L):
     P = lambda a: a.ctypes.data_as(f32p)
     _lib.check(_lib.lib().sbv2_debug_conv_transpose1d(0, P(x), P(w), P(b), cin, cout, k, L, s, p, 0.1, P(y)))
     np.testing.assert_allclose(y, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,L", [(64, 64, 16, 8, 300), (128, 64, 8, 2, 1000), (64, 128, 16, 8, 256), (256, 128, 16, 8, 515), (128, 64, 8, 2, 4097)])
+def test_conv_transpose_clx_kernel(cin, cout, k, s, L):
+    """The wide stages' ConvTranspose1d as ONE phased conv_clx launch (round 6): rows = (phase, cout), taps = the union of the phases' input taps padded to an
+    odd count with zero weights, output row n * stride + phase, on pre-split bf16 hi / lo operands: against the oracle's conv_transpose1d (the checker), with a
+    column mask on the input positions, every output row written (the buffer starts as NaN), and the bf16 parts of lrelu(result) it leaves for the ResBlocks."""
+    rng = np.random.default_rng(k * 100 + s + L)
+    x = rng.standard_normal((cin, L)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout, k)) / np.sqrt(cin * k / s)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    P = lambda a: a.ctypes.data_as(f32p)
+    p = (k - s) // 2
+    ref = O.conv_transpose1d(O.leaky_relu(x, 0.1), w, b, s, p)
+    y, ys = np.empty((cout, L * s), np.float32), np.empty((cout, L * s), np.float32)
+    _lib.check(_lib.lib().sbv2_debug_conv_transpose1d_clx(0, P(x), P(w), P(b), cin, cout, k, L, s, 0.1, None, 1, 0, P(y), P(ys), None))
+    assert np.isfinite(y).all()
+    np.testing.assert_allclose(y, ref, atol=3e-5, rtol=1e-5)
+    lr = np.where(y >= 0, y, y * np.float32(0.1)).astype(np.float32)
+    assert float(np.abs(ys - lr).max()) <= 2.0 ** -16 * float(np.abs(lr).max())
+    mask = (rng.random((L + 3) // 4) > 0.2).astype(np.uint8)
+    keep = np.repeat(mask, 4)[:L]
+    xm = x * keep[None, :]
+    refm = O.conv_transpose1d(O.leaky_relu(xm, 0.1), w, b, s, p) * np.repeat(keep, s)[None, :]
+    _lib.check(_lib.lib().sbv2_debug_conv_transpose1d_clx(0, P(xm), P(w), P(b), cin, cout, k, L, s, 0.1, mask.ctypes.data, 4, 0, P(y), None, None))
+    np.testing.assert_allclose(y, refm, atol=3e-5, rtol=1e-5)
+    assert not np.any(y[:, np.repeat(keep, s) == 0])
 
 
 def _conv_cl_dev(x, w, b, dil, slope, mode):
