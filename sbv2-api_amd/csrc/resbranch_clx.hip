@@ -649,24 +649,14 @@ bool resbranch_usable(const ResBranchParams& p) {
     return halo * 2 <= 64;   // (leaves >= half of the smallest window as output)
 }
 
-static std::atomic<int> g_rb_cfg{getenv("SBV2_RESBRANCH_CFG") ? atoi(getenv("SBV2_RESBRANCH_CFG")) : 0};   // builder knob: alternative shapes (A/B runs)
 template <int DG>
 static void launch_rb_any(const ResBranchParams& p, hipStream_t stream) {
-    // window sizes / weight rings.  C = 64: 128 rows on 4 waves; C = 32 / 16: 256 rows on 4 waves; weight groups = all taps of a chunk, three ring slots
-    // (C = 64: one tap per group, four slots: the LDS that three workgroups per CU leave)
-    const int cfg = g_rb_cfg.load(std::memory_order_relaxed);
-    if (p.C == 64) {
-        if (cfg == 1) return launch_rb<64, 3, 2, 2, 2, DG>(p, stream);
-        return launch_rb<64, 3, 2, 1, 4, DG>(p, stream);
-    }
-    if (p.C == 32) {
-        if (cfg == 1) return launch_rb<32, 3, 4, 4, 2, DG>(p, stream);
-        return launch_rb<32, 3, 4, 4, 3, DG>(p, stream);
-    }
-    if (p.C == 16) {
-        if (cfg == 1) return launch_rb<16, 3, 4, 4, 2, DG>(p, stream);
-        return launch_rb<16, 3, 4, 4, 3, DG>(p, stream);
-    }
+    // window sizes / weight rings.  C = 64: 128 rows on 4 waves, one tap per weight group, four ring slots (54 KB: three workgroups per CU); C = 32 / 16: 256
+    // rows on 4 waves, weight groups = all taps of a chunk, three slots.  (The double buffer of respair_clx.hip, two slots, measured the same on all three:
+    // profiles/r06c_resbranch_probe_double_buffer.jsonl; what these launches wait for is not their weights.)
+    if (p.C == 64) return launch_rb<64, 3, 2, 1, 4, DG>(p, stream);
+    if (p.C == 32) return launch_rb<32, 3, 4, 4, 3, DG>(p, stream);
+    if (p.C == 16) return launch_rb<16, 3, 4, 4, 3, DG>(p, stream);
     SBV2_REQUIRE(false, "resbranch: shape not instantiated");
 }
 

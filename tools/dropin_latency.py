@@ -9,7 +9,7 @@ with PREDICTED durations and noise on, at the sentence lengths the reference's T
 64, next to the same sentences through sbv2_pipeline_run (device resident between the stages) with the same settings.  Prints one JSON line.
 `--fp32` selects BASELINE configs[1]'s stated arithmetic (exact-f32 MFMA everywhere) and times the 128-phoneme utterance in it.
 
-    python3 tools/dropin_latency.py [calls] [--fp32]
+    python3 tools/dropin_latency.py [calls] [--fp32] [--tokens=25]
 """
 import ctypes as C
 import json
@@ -27,6 +27,7 @@ import numpy as np
 from sbv2_api_amd import _lib, configs, model, synth
 from sbv2_api_amd._lib import check, f32p, i64p
 
+TOKENS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--tokens=")]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 CALLS = int(args[0]) if args else 60
 bc, vc = configs.DEBERTA_FULL, configs.VITS_FULL
@@ -88,7 +89,7 @@ rows = []
 if FP32:
     rows.append(one(64, 128))          # BASELINE configs[1]: batch 1, 128 phonemes, fp32
 else:
-    for tok in (16, 25, 64, 100):
+    for tok in (TOKENS or (16, 25, 64, 100)):
         rows.append(one(tok, 2 * tok))
 out = {"what": "sbv2_bert_predict -> host repeat / transpose -> sbv2_vits_synthesize (the calls of the Rust shim, INTEGRATION.md §1) vs sbv2_pipeline_run, "
                "one sentence per call, predicted durations, sdp_ratio 0.0, noise_scale 0.677, noise_scale_w 0.8, full model shapes, synthetic weights",

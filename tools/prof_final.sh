@@ -11,6 +11,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_
 python3 bench.py --config mixed256 --steps 3 --warmup 1 --no-cpu-baseline > $O/final_mixed256.json 2> $O/final_mixed256.err
 python3 tools/b1_latency.py 40 2> $O/final_b1.err | tail -1 > $O/final_b1_latency.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_b1_stats -- python3 tools/b1_latency.py 40 > $O/final_b1_stats.log 2>&1
+python3 tools/dropin_latency.py 60 2> $O/final_dropin.err | tail -1 > $O/final_dropin_latency.json
+python3 tools/dropin_latency.py 60 --fp32 2>> $O/final_dropin.err | tail -1 > $O/final_dropin_latency_fp32.json
+rm -rf /tmp/kt25; rocprofv3 --kernel-trace --output-format csv -d /tmp/kt25 -- python3 tools/dropin_latency.py 40 --tokens=25 > /dev/null 2>&1
+python3 tools/trace_gaps.py /tmp/kt25 300 > $O/final_dropin25_gaps.json
 python3 tools/long_form_check.py 2000 256 2> $O/final_longform.err | tail -1 > $O/final_longform_c256.json
 
 python3 tools/long_form_check.py 2000 1024 2>> $O/final_longform.err | tail -1 > $O/final_longform_c1024.json

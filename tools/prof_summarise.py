@@ -34,7 +34,7 @@ def per_kernel(path, counters):
 
 
 shutil.copy(os.path.join(G, "final_bench.json"), P("bench.json"))
-for extra in ("mixed256", "b1_latency", "longform_c256", "longform_c1024"):
+for extra in ("mixed256", "b1_latency", "longform_c256", "longform_c1024", "dropin_latency", "dropin_latency_fp32", "dropin25_gaps"):
     src = os.path.join(G, f"final_{extra}.json")
     if os.path.exists(src) and os.path.getsize(src) > 2:
         shutil.copy(src, P(f"{extra}.json"))
@@ -52,7 +52,7 @@ if fe and wr:
     # every kernel that takes >= 0.5 % of the pass's kernel time (the PMC pass runs the steps un-pipelined: launches / steps = launches per step), then the
     # HBM bytes per step of the decoder's kernels (the channels-last family) and of everything
     total_us = sum(F[k][0] * F[k][1] for k in F)
-    dec = lambda k: any(t in k for t in ("conv_clx_kernel", "respair_clx_kernel", "respair_cl_kernel", "conv_cl_kernel", "conv_cl_small", "k_conv_post_tanh",
+    dec = lambda k: any(t in k for t in ("conv_clx_kernel", "respair_clx_kernel", "respair_cl_kernel", "resbranch_clx_kernel", "conv_cl_kernel", "conv_cl_small", "k_conv_post_tanh",
                                          "k_split_cl(", "k_clx_zero_halo", "k_add_segvec_cl", "k_transpose_out"))
     ffn = lambda k: "conv_clx_kernel<5," in k
     steps = int(os.environ.get("PMC_STEPS", "3"))   # bench.py --steps 1 --warmup 1 + its instrumented roofline step
@@ -75,7 +75,7 @@ if mf:
     names = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
     M = per_kernel(mf, names)
     rows = ["kernel,launches,avg_us,MFMA_busy_cycles_per_launch,GRBM_GUI_ACTIVE_per_launch,mfma_util(busy/(1024 SIMD * GUI_ACTIVE/8)),"
-            "SQ_WAIT_ANY/SQ_WAVE_CYCLES,LDS_bank_conflict/LDS_idx_active"]
+            "SQ_WAIT_ANY/SQ_WAVE_CYCLES,LDS_bank_conflict/LDS_idx_active,lds_util(LDS_idx_active/(256 CU * GUI_ACTIVE/8))"]
     total_us = sum(M[k][0] * M[k][1] for k in M)
     for k in sorted(M, key=lambda k: -M[k][0] * M[k][1]):
         n, us, c = M[k]
@@ -84,6 +84,6 @@ if mf:
         cyc = c["GRBM_GUI_ACTIVE"] / 8
         rows.append(f"\"{k[:110]}\",{n},{us:.1f},{c['SQ_VALU_MFMA_BUSY_CYCLES']:.3e},{c['GRBM_GUI_ACTIVE']:.3e},"
                     f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) if cyc else 0:.3f},{c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1):.3f},"
-                    f"{c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.3f}")
+                    f"{c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.3f},{c['SQ_LDS_IDX_ACTIVE'] / (256 * cyc) if cyc else 0:.3f}")
     open(P("pmc_mfma_util.csv"), "w").write("\n".join(rows) + "\n")
 print("wrote", sorted(os.path.basename(f) for f in glob.glob(P("*"))))
