@@ -841,8 +841,10 @@ __global__ __launch_bounds__(kFaThreads) __attribute__((amdgpu_waves_per_eu(2)))
 // waves per SIMD only interleave 1.3x.  Here
 //   * K / V tiles (64 keys, both parts) go L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double-buffered, no staging registers and no staging
 //     instructions; a tile image is [part][d][64 keys] with 128-byte rows, its 16-byte segments XOR-swizzled on the DMA's SOURCE address
-//     (K: segment ^ 2 ((d >> 1) & 3): the transposing reads of a 16-lane group touch 4 rows x 32 bytes on disjoint banks; V: segment ^ ((d >> 1) & 7): the
-//     16 rows a group of 8-byte reads touches fall on 16 distinct bank pairs);
+//     (K: segment ^ 4 ((d >> 1) & 1): ds_read_b64_tr_b16 banks over 32-LANE groups (MI355X_MICROARCH.md's LDS table), whose lanes touch rows d .. d + 3
+//     x four 16-byte segments: rows d, d + 2 share a bank half and take segments 0-3 / 4-7; rounds 4-5 swizzled by 2 ((d >> 1) & 3), right for 16-lane
+//     groups, and measured a conflict ratio of 0.37.  V: segment ^ ((d >> 1) & 7): the 16 rows a 16-lane group of 8-byte reads touches fall on 16 distinct
+//     bank pairs; over the 32 lanes of one k-half only 16 of a row pitch's 32 bank pairs are reachable: 2-way, which no segment swizzle removes);
 //   * the wave's program is pipelined by one key step: QK(t + 1)'s 18 MFMAs are issued with the softmax of step t dealt into their gaps (scale / max,
 //     exponentials, the split of P), then PV(t)'s 18 MFMAs, term-major over the three accumulators; fragment reads run two MFMA groups ahead;
 //   * one barrier per key step (K tile u + 1 is requested at the barrier of step 2u - 1 and needed at that of step 2u + 1; V tile u + 1 at 2u / 2u + 2).
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- DMA: instruction i of this wave moves block e = wave + NW i (part e / NB8, rows 8 (e % NB8) .. + 7); lane -> row lane / 8, LDS segment lane % 8
     const int drow = lane >> 3, dseg = lane & 7;
-    const int kgseg = dseg ^ (2 * ((drow >> 1) & 3)), vgseg = dseg ^ ((drow >> 1) & 3);   // the GLOBAL segment this lane's LDS segment holds (V: even blocks)
+    const int kgseg = dseg ^ (4 * ((drow >> 1) & 1)), vgseg = dseg ^ ((drow >> 1) & 3);   // the GLOBAL segment this lane's LDS segment holds (V: even blocks)
     const int nblk = dk >> 3;              // blocks that exist (dk is a multiple of 8); blocks beyond repeat the last one (their q / outputs are unused)
     // (V's swizzle takes bit 3 of the row as well: odd 8-row blocks hold global segment ^ 4.)  A DMA's address = a wave-uniform base (matrix, part,
     // block, tile: scalar registers, recomputed per request) + a 32-bit per-lane byte offset (row in the block, segment): no per-request 64-bit lane pointers
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             unsigned short v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (e < nv && d < dk) ? src[e] : (unsigned short)0;
-            const int swz = mat ? ((d >> 1) & 7) : 2 * ((d >> 1) & 3);
+            const int swz = mat ? ((d >> 1) & 7) : 4 * ((d >> 1) & 1);
             char* row = fq_smem + (mat ? 2 * IMG : 0) + (u & 1) * IMG + part * PART + d * 128;
             const uint4 o = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
                              (unsigned)v[6] | ((unsigned)v[7] << 16)};
@@ -1045,8 +1047,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // the address of (key half h2, sp, keys + 8) is ONE per-lane base XOR a constant: no per-(h2, sp) address registers
     const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
     const int krow = 8 * (g16 >> 1) + q4, ksegl = 2 * (g16 & 1) + (p4 >> 1);
-    const unsigned kb_lo = krow * 128 + ((ksegl ^ (2 * ((krow >> 1) & 3))) << 4) + (p4 & 1) * 8;                  // rows d .. d + 3 (h2 = 0; h2 = 1: ^ 64)
-    const unsigned kb_hi = (krow + 4) * 128 + ((ksegl ^ (2 * (((krow + 4) >> 1) & 3))) << 4) + (p4 & 1) * 8;      // rows d + 4 .. d + 7
+    const unsigned kb_lo = krow * 128 + ((ksegl ^ (4 * ((krow >> 1) & 1))) << 4) + (p4 & 1) * 8;                  // rows d .. d + 3 (h2 = 0; h2 = 1: ^ 64)
+    const unsigned kb_hi = (krow + 4) * 128 + ((ksegl ^ (4 * (((krow + 4) >> 1) & 1))) << 4) + (p4 & 1) * 8;      // rows d + 4 .. d + 7
     const unsigned vb = col * 128 + (((col >> 1) & 7) << 4) + 8 * kh;                                            // segment 0 (segment g: ^ (g << 4))
     // the wave's row of rk_s / band_s (+ rr * 128), and a dummy slot the band stores of elements outside the band go to
     const unsigned rk_a = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)&rk_s[wave][0][col]);

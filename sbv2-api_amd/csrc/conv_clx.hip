@@ -294,6 +294,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                 const unsigned aaddr = abase + wroff, b0 = clx_opaque(blane) + (unsigned)(tapb * shs32 + bufb * XBUF);
                 wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
                 const bool w3 = wwave && s0 + 2 * j + 3 < S, w4 = wwave && s0 + 2 * j + 4 < S;
+                // (PH, round 6: skipping the 16 cross-term MFMAs of a step whose tap is the phase's zero-padding tap - a uniform branch around each, the reads and
+                // DMAs between them kept - measured SLOWER: 1260 -> 1478 us at the 128-channel stage, 740 -> 801 at the 64-channel one,
+                // profiles/r06j_upsampler_zero_tap_skip_kernel_list.txt: the MFMAs are what paces the fragment reads and DMAs dealt between them)
                 clx_static_for<0, 16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     mfma_one(fe.a, fe.b, nc);

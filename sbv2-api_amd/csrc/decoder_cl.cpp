@@ -159,7 +159,19 @@ ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int 
     u.nph = s;
     u.cout = cout;
     u.alg_macs_per_pos = macs;
-    for (int r = 0; r < s; ++r) u.phase_off[r] = r;
+    for (int r = 0; r < s; ++r) {
+        u.phase_off[r] = r;
+        u.phase_ztap[r] = -1;
+        int nz = 0;
+        for (int ti = 0; ti < U; ++ti) {
+            const int j = s * (tmin + ti) + r + pad;
+            if (j < 0 || j >= k) {
+                u.phase_ztap[r] = ti;     // (conv_clx skips ONE such tap per phase; a phase with two keeps multiplying the second one's zeros)
+                ++nz;
+            }
+        }
+        (void)nz;
+    }
     return u;
 }
 

@@ -70,6 +70,7 @@ struct ClUpX {
     int M = 0, K = 0, ntaps = 0, shift0 = 0, nph = 0, cout = 0;
     double alg_macs_per_pos = 0;   // multiply-adds per input position that are not padding (the launch's algorithmic FLOP for the profile)
     int phase_off[kMaxPhases] = {0};
+    int phase_ztap[kMaxPhases] = {-1, -1, -1, -1, -1, -1, -1, -1};   // per phase: a tap that is zero padding for ALL of its rows and channels, or -1
 };
 ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s);
 void* pack_cl_pairs(WeightStore& ws, const float* w, int k);   // w [16][16][k] -> tap-pair fragments (split-bf16) for respair_clx's 16-channel kernel
