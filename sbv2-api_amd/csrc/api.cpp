@@ -926,8 +926,9 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
                          uint64_t* stamps, int64_t stamps_cap) {
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
-    SBV2_REQUIRE(x && w && bias && y && dilations && (C == 16 || C == 32 || C == 64) && N >= 1 && k >= 1 && k <= kMaxTaps && (k & 1) && mask_div >= 1 &&
+    SBV2_REQUIRE(x && w && bias && y && dilations && (C == 16 || C == 32 || C == 64 || C == 128) && N >= 1 && k >= 1 && k <= kMaxTaps && (k & 1) && mask_div >= 1 &&
                      (mask_div & (mask_div - 1)) == 0, "bad arguments");
+    SBV2_REQUIRE(variant != 0 || C <= 64, "the fused step exists for C <= 64 (variant 2 = the two-launch conv_cl path at any C)");
     const size_t wsz = (size_t)C * C * k;
     Blob b = one_conv_blob(w, bias, {C, C, k}, C);
     WeightStore ws(b);
@@ -937,7 +938,7 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
         cv[i] = pack_cl(ws, w + i * wsz, (int)C, (int)C, (int)k, 2, bias + (size_t)i * C);
         if (C == 16) wp[i] = pack_cl_pairs(ws, w + i * wsz, (int)k);
     }
-    DevBuf dx((size_t)N * C), dy((size_t)N * C), da((size_t)N * C), db((size_t)N * C);
+    DevBuf dx((size_t)N * C), dy((size_t)N * C), da((size_t)N * C), db((size_t)N * C), dt((size_t)N * C);
     HIP_CHECK(hipMemcpy(dx.p, x, sizeof(float) * N * C, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dy.p, y, sizeof(float) * N * C, hipMemcpyHostToDevice));   // (the previous contents matter when accumulate is set)
     DevBuf dy0((size_t)N * C);
@@ -951,7 +952,7 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
     int shift = 0;
     while ((1 << shift) < mask_div) ++shift;
     auto run = [&]() {
-        if (variant) {     // 1 = the fused branch (resbranch_clx.hip)
+        if (variant == 1) {     // 1 = the fused branch (resbranch_clx.hip)
             ResBranchParams rb;
             rb.X = dx.p;
             rb.Y = dy.p;
@@ -968,6 +969,41 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
             rb.mask = dm;
             rb.mask_shift = shift;
             launch_resbranch(rb, nullptr);
+        } else if (variant == 2) {   // 2 = six launches of conv_cl.hip (conv1 -> T, conv2 + residual): the unfused path, any C
+            const float* cur = dx.p;
+            for (int q = 0; q < kResBranchSteps; ++q) {
+                const bool last = q + 1 == kResBranchSteps;
+                float* yn = last ? dy.p : (q & 1 ? db.p : da.p);
+                auto conv = [&](const ClConv& c, const float* X, float* Y, int dil, const float* R, float bt, int accum) {
+                    ConvClParams p;
+                    p.X = X;
+                    p.ldx = (int)C;
+                    p.NB = (int)N;
+                    p.W = c.w;
+                    p.nmt = c.nmt;
+                    p.tm = c.tm;
+                    p.split = 1;
+                    p.M = (int)C;
+                    p.N = (int)N;
+                    p.K = (int)C;
+                    p.ntaps = (int)k;
+                    for (int t = 0; t < k; ++t) p.shift[t] = t * dil - dil * (int)(k - 1) / 2;
+                    p.Y = Y;
+                    p.ldy = (int)C;
+                    p.bias = c.bias;
+                    p.R = R;
+                    p.ldr = (int)C;
+                    p.pre_slope = 0.1f;
+                    p.beta = bt;
+                    p.accumulate = accum;
+                    p.mask = dm;
+                    p.mask_div = (int)mask_div;
+                    launch_conv_cl(p, nullptr);
+                };
+                conv(cv[2 * q], cur, dt.p, (int)dilations[q], nullptr, 1.0f, 0);
+                conv(cv[2 * q + 1], dt.p, yn, 1, cur, last ? beta : 1.0f, last ? accumulate : 0);
+                cur = yn;
+            }
         } else {           // 0 = three launches of the fused step (respair_clx.hip)
             const float* cur = dx.p;
             for (int q = 0; q < kResBranchSteps; ++q) {
@@ -1013,7 +1049,7 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
         }
-        if (stamps && stamps_cap >= 16 && variant) {   // one more launch of the stamped instantiation: 16 words per workgroup (resbranch_clx.hip)
+        if (stamps && stamps_cap >= 16 && variant == 1) {   // one more launch of the stamped instantiation: 16 words per workgroup (resbranch_clx.hip)
             unsigned long long* ds = nullptr;
             HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ds), sizeof(unsigned long long) * (size_t)stamps_cap));
             HIP_CHECK(hipMemset(ds, 0, sizeof(unsigned long long) * (size_t)stamps_cap));

@@ -44,27 +44,28 @@ __device__ __forceinline__ void rb_for(F&& f) {
         rb_for<I + 1, N>(f);
     }
 }
+// (LDS instructions take a 16-bit immediate offset: what lies beyond - the lo part of a 128-channel window - goes into the address, one add the compiler shares)
 template <int OFF>
 __device__ __forceinline__ rb_bf16x8 rb_read_b128(unsigned addr) {
     rb_bf16x8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + (unsigned)(OFF & ~0xFFFF)), "i"(OFF & 0xFFFF));
     return v;
 }
 template <int OFF>
 __device__ __forceinline__ rb_f32x4 rb_read_f128(unsigned addr) {
     rb_f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + (unsigned)(OFF & ~0xFFFF)), "i"(OFF & 0xFFFF));
     return v;
 }
 template <int OFF>
 __device__ __forceinline__ unsigned rb_read_u8(unsigned addr) {
     unsigned v;
-    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr + (unsigned)(OFF & ~0xFFFF)), "i"(OFF & 0xFFFF));
     return v;
 }
 template <int OFF>
 __device__ __forceinline__ void rb_write_b64(unsigned addr, rb_bf16x4 v) {
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "i"(OFF) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr + (unsigned)(OFF & ~0xFFFF)), "v"(v), "i"(OFF & 0xFFFF) : "memory");
 }
 __device__ __forceinline__ void rb_write_b32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void rb_write_b8(unsigned addr, unsigned v) { asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
@@ -75,7 +76,7 @@ template <int C, int NTAPS, int WNP, int GT, int NBUFP>
 struct RbCfg {
     static constexpr int NS = kResBranchSteps;         // steps of a branch
     static constexpr int NCH = C / 16;                 // 16-channel chunks (the K dimension of one MFMA)
-    static constexpr int NMT = C == 64 ? 2 : 1;        // 32-row tiles of the output channels (C = 16: one 16-row tile)
+    static constexpr int NMT = C >= 32 ? C / 32 : 1;   // 32-row tiles of the output channels (C = 16: one 16-row tile)
     static constexpr int WN = WNP;                     // 64-position groups
     static constexpr int NW = NMT * WN;                // waves
     static constexpr int T = 64 * NW;                  // threads
@@ -133,8 +134,8 @@ __global__ __launch_bounds__((RbCfg<C, NTAPS, WNP, GT, NBUFP>::T)) __attribute__
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = NMT == 2 ? wave / WN : 0;           // this wave's 32-row tile of the output channels
-    const int wn = NMT == 2 ? wave - wm * WN : wave;   // ... and its 64 rows of the window
+    const int wm = NMT >= 2 ? wave / WN : 0;           // this wave's 32-row tile of the output channels
+    const int wn = NMT >= 2 ? wave - wm * WN : wave;   // ... and its 64 rows of the window
     const int lcol = lane & 31, lh = lane >> 5;
     const int NB = p.N, halo = p.halo, nto = R - 2 * halo;
     const int ntiles = (NB + nto - 1) / nto;
@@ -579,8 +580,9 @@ __global__ __launch_bounds__((RbCfg<C, NTAPS, WNP, GT, NBUFP>::T)) __attribute__
             // written out here, so that the branch's last step keeps their bits)
             rb_f32x4 v;
             if (p.accumulate) {
+                // (C >= 128 replaces conv_cl / conv_clx launches, whose accumulate epilogue rounds the product before the sum)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(a[e], beta, rold[it][e]);
+                for (int e = 0; e < 4; ++e) v[e] = C >= 128 ? a[e] * beta + rold[it][e] : __builtin_fmaf(a[e], beta, rold[it][e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = a[e] * beta;
@@ -623,23 +625,19 @@ static void launch_rb(const ResBranchParams& p, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
     if (prof) {
         HIP_CHECK(hipEventRecord(e1, stream));
-        conv_prof_add(C == 64 ? 17 : 16, kResBranchSteps * 2.0 * 2.0 * p.C * (double)p.N * p.C * p.k, e0, e1);   // (the fused steps' buckets)
+        // (the fused steps' buckets; C = 128 replaces six conv_clx launches and is counted with them)
+        conv_prof_add(C >= 128 ? 26 : (C == 64 ? 17 : 16), kResBranchSteps * 2.0 * 2.0 * p.C * (double)p.N * p.C * p.k, e0, e1);
     }
 }
 
-// 0: three launches of the fused step; 1 (default): C <= 32; 2: C = 64 too.  (Measured, profiles/r06b_bench_resbranch_ab.json + r06d_decoder_kernel_list.txt:
-// at C = 64 the fused branch takes as long as its three steps in isolation (1.19 ms per half plane either way: both are bound by the L2 -> LDS weight stream
-// and LDS reads of a 32 x 64 wave tile, not by HBM) and 0.25 ms MORE inside the step; at C = 32 / 16 it is 21-29 % faster.)
+// 0: the unfused paths (three respair_clx launches; at C = 128 six conv_clx launches); 1 (default): the fused branch at C = 16 / 32 / 64 / 128
 static std::atomic<int> g_rb{getenv("SBV2_RESBRANCH") ? atoi(getenv("SBV2_RESBRANCH")) : 1};   // sbv2_debug_set_resbranch
 int set_resbranch(int on) { return g_rb.exchange(on); }
 bool resbranch_enabled() { return g_rb.load(std::memory_order_relaxed) != 0; }
-bool resbranch_wanted(int C) {
-    const int m = g_rb.load(std::memory_order_relaxed);
-    return m >= 2 || (m == 1 && C <= 32);
-}
+bool resbranch_wanted(int C) { return g_rb.load(std::memory_order_relaxed) != 0 && (C == 16 || C == 32 || C == 64 || C == 128); }
 
 bool resbranch_usable(const ResBranchParams& p) {
-    if (!(p.C == 16 || p.C == 32 || p.C == 64) || p.k != 3 || p.N < 1 || !(p.slope >= 0.f && p.slope <= 1.f) || (p.mask && p.mask_shift < 0)) return false;
+    if (!(p.C == 16 || p.C == 32 || p.C == 64 || p.C == 128) || p.k != 3 || p.N < 1 || !(p.slope >= 0.f && p.slope <= 1.f) || (p.mask && p.mask_shift < 0)) return false;
     int halo = 0;
     for (int q = 0; q < kResBranchSteps; ++q) {
         if (p.dil[q] < 1 || p.dil[q] * (p.k - 1) / 2 > kResBranchMargin) return false;
@@ -651,10 +649,16 @@ bool resbranch_usable(const ResBranchParams& p) {
 
 template <int DG>
 static void launch_rb_any(const ResBranchParams& p, hipStream_t stream) {
-    // window sizes / weight rings.  C = 64: 128 rows on 4 waves, one tap per weight group, four ring slots (54 KB: three workgroups per CU); C = 32 / 16: 256
-    // rows on 4 waves, weight groups = all taps of a chunk, three slots.  (The double buffer of respair_clx.hip, two slots, measured the same on all three:
-    // profiles/r06c_resbranch_probe_double_buffer.jsonl; what these launches wait for is not their weights.)
-    if (p.C == 64) return launch_rb<64, 3, 2, 1, 4, DG>(p, stream);
+    // Window sizes / weight rings, each the best of a same-box sweep (profiles/r06c, r06l, r06m, r06n *_probe*):
+    //   C = 128: 192 rows on 12 waves, a chunk's three taps per weight group, 2 ring slots: 155 KB, ONE workgroup per CU (1.84 ms per half plane; 128 rows
+    //            on 8 waves 2.14-2.28; the six conv_clx launches it replaces 2.2)
+    //   C = 64:  384 rows on 12 waves, three taps per group, 3 slots: 137 KB, one per CU (1.01 ms; 256 rows on 8 waves 1.13; 128 rows on 4 waves x three
+    //            workgroups per CU 1.25 = the three fused steps' 1.24)
+    //   C = 32 / 16: 256 rows on 4 waves, three per CU (0.61 / 0.49 ms; 512 rows 0.74 / 0.49, 768 / 1024 rows 0.70 / 0.55)
+    // The wide stages want ONE big workgroup (less recompute: 1.07-1.14x, a third of the weight bytes per output, 12 waves behind every barrier); the narrow
+    // ones, bound by their own instruction issue, want several small ones.
+    if (p.C == 128) return launch_rb<128, 3, 3, 3, 2, DG>(p, stream);
+    if (p.C == 64) return launch_rb<64, 3, 6, 3, 3, DG>(p, stream);
     if (p.C == 32) return launch_rb<32, 3, 4, 4, 3, DG>(p, stream);
     if (p.C == 16) return launch_rb<16, 3, 4, 4, 3, DG>(p, stream);
     SBV2_REQUIRE(false, "resbranch: shape not instantiated");

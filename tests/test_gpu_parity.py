@@ -123,18 +123,20 @@ def _resbranch(x, w, b, k, dils, mask, mask_div, beta, prev, variant):
     return y
 
 
-@pytest.mark.parametrize("C,N", [(16, 700), (16, 233), (16, 232 * 9 + 5), (32, 257), (32, 2000), (32, 232), (32, 31), (64, 130), (64, 1111), (64, 104 * 17 + 3), (64, 105)])
+@pytest.mark.parametrize("C,N", [(16, 700), (16, 233), (16, 232 * 9 + 5), (32, 257), (32, 2000), (32, 232), (32, 31), (64, 130), (64, 1111), (64, 104 * 17 + 3), (64, 105),
+                                 (128, 300), (128, 104 * 5 + 1)])
 def test_resbranch_kernel_same_bits_as_three_respair_steps(C, N):
     """resbranch_clx.hip (round 6): the three steps of a k = 3 ResBlock1 branch (dilations 1, 3, 5) in ONE launch, the residual stream in registers and the
     operand windows in LDS, gives the SAME bits as three launches of the fused step (respair_clx.hip): plain, with a column mask (edges of packed utterances:
     mask_div 4) and with beta + accumulate (the branch's last step), at lengths around the tile sizes (232 / 104 outputs per workgroup); and both agree with
     the numpy oracle's three resblock steps (O.conv1d_same: the checker)."""
     k, dils = 3, (1, 3, 5)
+    RV = 0 if C <= 64 else 2      # the reference chain: three fused steps (respair_clx, C <= 64) or six conv_cl launches (any C; same bits as the fused step)
     rng = np.random.default_rng(C * 1000 + N)
     x = rng.standard_normal((N, C)).astype(np.float32)
     w = (rng.standard_normal((6, C, C, k)) / np.sqrt(C * k)).astype(np.float32)
     b = rng.standard_normal((6, C)).astype(np.float32)
-    ref = _resbranch(x, w, b, k, dils, None, 1, 1.0, None, 0)
+    ref = _resbranch(x, w, b, k, dils, None, 1, 1.0, None, RV)
     got = _resbranch(x, w, b, k, dils, None, 1, 1.0, None, 1)
     np.testing.assert_array_equal(got, ref)
     y = x.T.copy()
@@ -145,15 +147,17 @@ def test_resbranch_kernel_same_bits_as_three_respair_steps(C, N):
     mask = (rng.random((N + 3) // 4) > 0.15).astype(np.uint8)
     xm = x * np.repeat(mask, 4)[:N, None]                      # (a masked column holds zeros in the real planes)
     prev = rng.standard_normal((N, C)).astype(np.float32) * np.repeat(mask, 4)[:N, None]
-    ref = _resbranch(xm, w, b, k, dils, mask, 4, 1.0 / 3, prev, 0)
+    ref = _resbranch(xm, w, b, k, dils, mask, 4, 1.0 / 3, prev, RV)
     got = _resbranch(xm, w, b, k, dils, mask, 4, 1.0 / 3, prev, 1)
     np.testing.assert_array_equal(got, ref)
-    ref = _resbranch(xm, w, b, k, dils, mask, 4, 1.0, None, 0)
+    ref = _resbranch(xm, w, b, k, dils, mask, 4, 1.0, None, RV)
     got = _resbranch(xm, w, b, k, dils, mask, 4, 1.0, None, 1)
     np.testing.assert_array_equal(got, ref)
     assert not np.any(got[np.repeat(mask, 4)[:N] == 0])
     got = _resbranch(x, w, b, k, (5, 1, 3), None, 1, 1.0, None, 1)      # (another order of the dilations: same halo, other per-step reach)
-    np.testing.assert_array_equal(got, _resbranch(x, w, b, k, (5, 1, 3), None, 1, 1.0, None, 0))
+    np.testing.assert_array_equal(got, _resbranch(x, w, b, k, (5, 1, 3), None, 1, 1.0, None, RV))
+    if C >= 32:   # ... and the six-launch conv_cl path (same fragments, same per-accumulator order)
+        np.testing.assert_array_equal(got, _resbranch(x, w, b, k, (5, 1, 3), None, 1, 1.0, None, 2))
 
 
 import contextlib
