@@ -656,7 +656,9 @@ static void launch_rb_any(const ResBranchParams& p, hipStream_t stream) {
     //            workgroups per CU 1.25 = the three fused steps' 1.24)
     //   C = 32 / 16: 256 rows on 4 waves, three per CU (0.61 / 0.49 ms; 512 rows 0.74 / 0.49, 768 / 1024 rows 0.70 / 0.55)
     // The wide stages want ONE big workgroup (less recompute: 1.07-1.14x, a third of the weight bytes per output, 12 waves behind every barrier); the narrow
-    // ones, bound by their own instruction issue, want several small ones.
+    // ones, bound by their own instruction issue, want several small ones.  (The same structure for ONE k = 7 / 11 step of the 64-channel stage - a 384-row
+    // window, both convolutions over all of it - measured against respair_clx.hip: same bits, the stage's bucket 10.9 -> 12.0 ms per step, the step
+    // +0.65 ms: profiles/r06p_one_step_big_workgroup_ab.txt.  A single MFMA-bound step has no plane pass to save and pays 1.03-1.19x recompute.  Not kept.)
     if (p.C == 128) return launch_rb<128, 3, 3, 3, 2, DG>(p, stream);
     if (p.C == 64) return launch_rb<64, 3, 6, 3, 3, DG>(p, stream);
     if (p.C == 32) return launch_rb<32, 3, 4, 4, 3, DG>(p, stream);
