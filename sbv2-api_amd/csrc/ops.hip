@@ -791,11 +791,17 @@ void add_segvec_cl(float* x, int L, int C, const float* vec, int vec_ld, const i
 // A workgroup stages its 256 + k - 1 rows (activated once) and the C x k weights in LDS; read straight from global memory every
 // sample re-read its k rows and issued C * k weight loads (0.8 ms for 786 MB = 1 TB/s).
 constexpr int kPostMaxC = 32, kPostMaxK = 12;
-__global__ __launch_bounds__(256) void k_conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope,
+// CT / KT > 0: channel and tap counts known at compile time (JP-Extra: 16 channels, 7 taps): the loops unroll, the C x k weights are wave-uniform scalar
+// loads used as SGPR operands of the fmas (no LDS reads for them: the generic form issued C * k broadcast ds_reads per sample beside its k * C / 4 row
+// reads and ran at 2.6 TB/s, LDS 50 % busy).  The compiler contracts the unrolled sums differently: f32 rounding apart from the generic form, which every
+// caller of one model takes or does not take alike (batch row == single call, streamed == whole-sequence keep their bits).
+template <int CT, int KT>
+__global__ __launch_bounds__(256) void k_conv_post_tanh_cl(const float* x, int C_, int64_t L, const float* w, int k_, float slope,
                                                             const int* seg_start, const int* seg_len, const int64_t* pcm_off, int up,
                                                             float* pcm) {
     __shared__ float xs[(256 + kPostMaxK) * (kPostMaxC + 4)];
     __shared__ float ws[kPostMaxC * kPostMaxK];
+    const int C = CT > 0 ? CT : C_, k = KT > 0 ? KT : k_;
     const int sg = blockIdx.y;
     const int64_t len = (int64_t)seg_len[sg] * up;
     const int64_t s0 = (int64_t)blockIdx.x * 256;
@@ -816,16 +822,30 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh_cl(const float* x, int C
         v.w = fmaxf(v.w, v.w * slope);
         *reinterpret_cast<float4*>(xs + r * pitch + c4 * 4) = v;
     }
-    for (int idx = tid; idx < C * k; idx += 256) ws[idx] = w[idx];   // [c][j]
+    if constexpr (CT == 0) {
+        for (int idx = tid; idx < C * k; idx += 256) ws[idx] = w[idx];   // [c][j]
+    }
     __syncthreads();
     const int64_t sidx = s0 + tid;
     if (sidx >= len) return;
     float a = 0.f;
-    for (int j = 0; j < k; ++j) {
-        const float* r = xs + (tid + j) * pitch;
-        for (int c = 0; c < C; c += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(r + c);
-            a += ws[c * k + j] * v.x + ws[(c + 1) * k + j] * v.y + ws[(c + 2) * k + j] * v.z + ws[(c + 3) * k + j] * v.w;
+    if constexpr (CT > 0) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const float* r = xs + (tid + j) * (CT + 4);
+#pragma unroll
+            for (int c = 0; c < CT; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(r + c);
+                a += w[c * KT + j] * v.x + w[(c + 1) * KT + j] * v.y + w[(c + 2) * KT + j] * v.z + w[(c + 3) * KT + j] * v.w;
+            }
+        }
+    } else {
+        for (int j = 0; j < k; ++j) {
+            const float* r = xs + (tid + j) * pitch;
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(r + c);
+                a += ws[c * k + j] * v.x + ws[(c + 1) * k + j] * v.y + ws[(c + 2) * k + j] * v.z + ws[(c + 3) * k + j] * v.w;
+            }
         }
     }
     pcm[pcm_off[sg] + sidx] = tanhf(a);
@@ -833,8 +853,9 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh_cl(const float* x, int C
 void conv_post_tanh_cl(const float* x, int C, int64_t L, const float* w, int k, float slope, const int* seg_start, const int* seg_len,
                        const int64_t* pcm_off, int nseg, int up, int64_t max_samples, float* pcm, hipStream_t s) {
     SBV2_REQUIRE(C <= kPostMaxC && (C & 3) == 0 && k <= kPostMaxK, "conv_post: more than 32 channels or 12 taps");
-    hipLaunchKernelGGL(k_conv_post_tanh_cl, dim3((unsigned)((max_samples + 255) / 256), nseg), dim3(256), 0, s, x, C, L, w, k, slope,
-                       seg_start, seg_len, pcm_off, up, pcm);
+    const dim3 grid((unsigned)((max_samples + 255) / 256), nseg);
+    if (C == 16 && k == 7) hipLaunchKernelGGL((k_conv_post_tanh_cl<16, 7>), grid, dim3(256), 0, s, x, C, L, w, k, slope, seg_start, seg_len, pcm_off, up, pcm);
+    else hipLaunchKernelGGL((k_conv_post_tanh_cl<0, 0>), grid, dim3(256), 0, s, x, C, L, w, k, slope, seg_start, seg_len, pcm_off, up, pcm);
 }
 
 void fill_zero(void* p, size_t bytes, hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
