@@ -266,8 +266,9 @@ int sbv2_debug_set_respair_clx(int on);
    null), channels-last x / y [N][C], w [C][C][k], split-bf16, through respair_cl.hip (variant 0) or respair_clx.hip (variant 1).  Test hook. */
 int sbv2_debug_respair(int device, const float* x, const float* w1, const float* w2, const float* b1, const float* b2, int64_t C, int64_t N, int64_t k,
                        int64_t dilation, const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, float* y);
-/* 1 (default; SBV2_RESBRANCH=0): the k = 3 branches of the <= 64-channel decoder stages run their three steps in ONE launch (resbranch_clx.hip: y_1, y_2 stay
-   on the chip, 2 plane passes through HBM per branch instead of 6); 0: three respair_clx launches (same bits).  Returns the previous value. */
+/* 1 (default; SBV2_RESBRANCH=0): the k = 3 branches of the 128- / 64- / 32- / 16-channel decoder stages run their three steps in ONE launch
+   (resbranch_clx.hip: y_1, y_2 stay on the chip, 2 plane passes through HBM per branch instead of 6); 0: three respair_clx launches (same bits; at 128
+   channels six conv_clx launches: f32 rounding apart).  Returns the previous value. */
 int sbv2_debug_set_resbranch(int on);
 /* 1 (default; SBV2_UPX=0): the ConvTranspose1d of the wide decoder stages (large launches) runs as ONE phased conv_clx.hip launch on pre-split operands
    (rows = (phase, cout), taps = the union of the phases' input taps padded to an odd count); 0: conv_cl.hip's phase groups.  f32 rounding apart (another
@@ -282,7 +283,8 @@ int sbv2_debug_conv_transpose1d_clx(int device, const float* x, const float* w, 
 /* A whole ResBlock1 branch (HifiGanResidualBlock.forward, modeling_vits.py:455-463; the graph of scripts/convert/convert_model.py:97-110): three steps
    y_q = conv2_q(lrelu(conv1_q(lrelu(y_{q-1}), dilations[q]) + b1_q)) + b2_q + y_{q-1}, result beta * y_3 [+ y when accumulate], masked by mask[n / mask_div]
    (a power of two; mask may be null) at every layer; channels-last x / y [N][C], w [6][C][C][k] and bias [6][C] in the order conv1_0, conv2_0, conv1_1, ...,
-   split-bf16; variant 0 = three launches of the fused step (respair_clx.hip), 1 = one launch (resbranch_clx.hip).  iters > 0: *ms = average duration of
+   split-bf16, C in {16, 32, 64, 128}; variant 0 = three launches of the fused step (respair_clx.hip, C <= 64), 1 = one launch (resbranch_clx.hip), 2 = six
+   launches of conv_cl.hip (any C).  iters > 0: *ms = average duration of
    `iters` further runs; stamps (variant 1, may be null): 16 words per workgroup of one more, stamped launch (s_memtime at entry [0], window converted [1], end
    of step 1 / 2 / 3 [2 .. 4], stores issued [6]; s_memrealtime at entry / exit [14, 15]).  Test / measurement hook. */
 int sbv2_debug_resbranch(int device, const float* x, const float* w, const float* bias, int64_t C, int64_t N, int64_t k, const int64_t* dilations,
