@@ -672,10 +672,10 @@ void launch_gemm_bfs(const GemmBfsParams& p, hipStream_t stream) {
         // 64 x 128 on 3 / 6 slots, 128 x 64, two chunks per barrier, 64 x 64 for the 1024-row products, 4 / 12 / 16 slots for small grids: all slower
         // or equal; profiles/HISTORY.md.)
         if (big) {
-            // (Round 6 measured the cross-workgroup K split at this shape too, two workgroups per 64 x 128 tile of DeBERTa's K = 4096 product, 272 -> 544
-            // workgroups on 768 slots: 90.2 -> 86.9-88.0 us per launch, profiles/r06g_bfs_batch_ksplit_probe.txt; at K = 1024 26.8 -> 35.9.  These launches
-            // are not waiting for empty slots: 272 tiles x 256 chunks x 12 KB of operand tiles = 835 MB through the L2 -> LDS path in 88 us = 9.5 TB/s,
-            // i.e. 21.8 algorithmic FLOP per staged byte x 9.5 TB/s = the 207 TFLOP/s they reach whatever the number of workgroups.  Not kept.)
+            // (Round 6 measured two more shapes here, profiles/r06g_bfs_batch_ksplit_probe.txt: the cross-workgroup K split, two workgroups per 64 x 128 tile of
+            // DeBERTa's K = 4096 product, 272 -> 544 workgroups on 768 slots: 90.2 -> 86.9-88.0 us, and 26.8 -> 35.9 at K = 1024; and 128 x 128 tiles on 8 waves
+            // of 32 x 64, two workgroups per CU: 26.9 / 63.2 / 86.5 / 92.3 -> 28.7 / 58.0 / 84.3 / 92.1 us on the four DeBERTa shapes.  Neither the slot count nor
+            // 1.5x fewer staged bytes per FLOP moves these launches: ~0.35 us per 16-deep chunk and workgroup at every occupancy.  Not kept.)
             launch_bfs_cfg<2, 1, 2, 2, 2, 1, 4, true>(kp, stream);
         } else {
             // Small grids with a long K loop and scratch from the caller (DeBERTa's FFN down projection in a single-utterance call, K = 4096: 30.1 -> 12-18 us):
