@@ -652,8 +652,8 @@ static void launch_rb_any(const ResBranchParams& p, hipStream_t stream) {
     // Window sizes / weight rings, each the best of a same-box sweep (profiles/r06c, r06l, r06m, r06n *_probe*):
     //   C = 128: 192 rows on 12 waves, a chunk's three taps per weight group, 2 ring slots: 155 KB, ONE workgroup per CU (1.84 ms per half plane; 128 rows
     //            on 8 waves 2.14-2.28; the six conv_clx launches it replaces 2.2)
-    //   C = 64:  384 rows on 12 waves, three taps per group, 3 slots: 137 KB, one per CU (1.01 ms; 256 rows on 8 waves 1.13; 128 rows on 4 waves x three
-    //            workgroups per CU 1.25 = the three fused steps' 1.24)
+    //   C = 64:  384 rows on 12 waves, three taps per group, 3 slots: 137 KB, one per CU (1.01 ms; 512 rows on 16 waves 1.00-1.03; 256 rows on 8 waves 1.13;
+    //            192 rows on 6 waves x TWO workgroups per CU 1.32; 128 rows on 4 waves x three per CU 1.25 = the three fused steps' 1.24)
     //   C = 32 / 16: 256 rows on 4 waves, three per CU (0.61 / 0.49 ms; 512 rows 0.74 / 0.49, 768 / 1024 rows 0.70 / 0.55)
     // The wide stages want ONE big workgroup (less recompute: 1.07-1.14x, a third of the weight bytes per output, 12 waves behind every barrier); the narrow
     // ones, bound by their own instruction issue, want several small ones.  (The same structure for ONE k = 7 / 11 step of the 64-channel stage - a 384-row
