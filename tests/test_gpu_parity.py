@@ -713,6 +713,36 @@ def test_decoder_respair_clx_path_same_bits_as_respair_cl_path():
     s.close()
 
 
+def test_decoder_fused_branch_and_phased_upsampler_paths_agree_with_the_unfused_ones():
+    """Full JP-Extra shape, a batch large enough for the wide stages' big-launch dispatch (conv_clx, the phased transposed convolutions, the fused branch
+    at 128 channels): the k = 3 branches fused into one launch per stage (resbranch_clx.hip, the default) against three fused steps / six conv_clx launches
+    (sbv2_debug_set_resbranch(0)), and the phased conv_clx transposed convolutions against conv_cl's phase groups (sbv2_debug_set_upx(0)).  The narrow
+    stages' fused branch gives the bits of the steps it replaces; the 128-channel one and the upsamplers replace launches that sum in another order: the
+    waveforms agree to 2e-6 (peak ~0.1; the oracle tolerance of the decoder tests is 5e-5)."""
+    cfg, W = weights("vits", "full")
+    s = model.load_model(blob("vits", "full"), False)
+    utts = make_utts([40, 64, 25, 51], O.DEBERTA_FULL, cfg, seed0=91)      # 1 264 frames: 316 tiles at the 256-channel stage
+    lib = _lib.lib()
+    prev_rb, prev_up = lib.sbv2_debug_set_resbranch(1), lib.sbv2_debug_set_upx(1)
+    try:
+        a = model.synthesize_batch(s, utts, forced=True)
+        lib.sbv2_debug_set_resbranch(0)
+        b = model.synthesize_batch(s, utts, forced=True)
+        lib.sbv2_debug_set_upx(0)
+        c = model.synthesize_batch(s, utts, forced=True)
+    finally:
+        lib.sbv2_debug_set_resbranch(prev_rb)
+        lib.sbv2_debug_set_upx(prev_up)
+    worst = 0.0
+    for x, y, z in zip(a, b, c):
+        assert np.isfinite(x).all()
+        np.testing.assert_allclose(x, y, atol=2e-6, rtol=0)
+        np.testing.assert_allclose(y, z, atol=2e-6, rtol=0)
+        worst = max(worst, float(np.abs(x - z).max()))
+    print(f"fused branches + phased upsamplers vs the unfused decoder: worst max-abs {worst:.2e}")
+    s.close()
+
+
 def test_flow_attention_on_presplit_keys_values_same_bits():
     """The flow's split-bf16 attention on keys / values pre-split by the q | k | v product's epilogue (attn_flash.hip k_vits_flash_x3q: LDS-DMA tiles,
     software-pipelined steps; and k_vits_flash_x3p: 64-key staged tiles; the default from 4096 frames and for launches of <= 64 workgroups) against
