@@ -388,36 +388,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     // ---- k-major result (the flow's second FFN convolution: Y[m][n] = (conv + b + R[m][n]) * mask): one accumulator register of a 16-lane group is 16
     // consecutive positions of one channel = a 64-byte run of the plane; bias, mask and residual of a row tile are requested before its first store
     if constexpr (EPI == 2) {
-        int nn[4];
-        bool nok[4], keepn[4];
+        // Round 6: through a wave-private LDS tile [32 rows][64 positions (+4)], so that a lane leaves with FOUR consecutive positions of one channel: 16-byte
+        // residual loads and stores, 4 rows x 256 bytes per instruction (the direct form moved one 4-byte element per lane: 64 loads + 64 stores per wave
+        // in runs of 64 bytes).  Same arithmetic per element in the same order: same bits.  Every residual row of a half is requested before its first store.
+        float* tileT = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+        const int prow = lane >> 4, pq = (lane & 15) * 4;
+        const int nq = n0 + wq * NPW + pq;                 // first of this lane's four positions
+        bool keep4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            nn[j] = n0 + wq * NPW + j * 16 + l16;
-            nok[j] = nn[j] < N;
-            const int nc = min(nn[j], N - 1);
-            keepn[j] = !p.mask || p.mask[nc >> p.mask_shift] != 0;
-        }
-        clx_static_for<0, 4>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            float brow[4], rr[4][4];
+        for (int e = 0; e < 4; ++e) keep4[e] = nq + e < N && (!p.mask || p.mask[min(nq + e, N - 1) >> p.mask_shift] != 0);
+        const bool whole4 = nq + 4 <= N;
+        const int nqc = whole4 ? nq : max(min(nq, N - 4), 0);   // (a clamped, valid address for the residual rows of a ragged tail: their values are not used)
+        clx_static_for<0, 2>([&](auto hc) {
+            constexpr int i2 = decltype(hc)::value;        // rows 32 i2 .. + 31 of the wave's 64
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mc = min(m0 + i * 16 + 4 * lg + r, M - 1);
-                brow[r] = p.bias ? p.bias[mc] : 0.f;
+            for (int it2 = 0; it2 < 2; ++it2)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rr[r][j] = p.Rkm ? p.Rkm[(int64_t)mc * p.ldrkm + min(nn[j], N - 1)] : 0.f;
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tileT[(it2 * 16 + 4 * lg + r) * 68 + jt * 16 + l16] = acc[2 * i2 + it2][jt][r];
+            f32x4v rr[8];
+            float brow[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int mc = min(m0 + i2 * 32 + it * 4 + prow, M - 1);
+                brow[it] = p.bias ? p.bias[mc] : 0.f;
+                if (p.Rkm) {
+                    if (whole4) rr[it] = *reinterpret_cast<const f32x4v*>(p.Rkm + (int64_t)mc * p.ldrkm + nqc);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rr[it][e] = p.Rkm[(int64_t)mc * p.ldrkm + min(nq + e, N - 1)];
+                } else {
+                    rr[it] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + i * 16 + 4 * lg + r;
+            for (int it = 0; it < 8; ++it) {
+                const int m = m0 + i2 * 32 + it * 4 + prow;
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(tileT + (it * 4 + prow) * 68 + pq);
                 if (m >= M) continue;
+                f32x4v v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!nok[j]) continue;
-                    float v = acc[i][j][r] + brow[r];
-                    if (p.Rkm) v += rr[r][j];
-                    v *= p.beta;
-                    p.Ykm[(int64_t)m * p.ldykm + nn[j]] = keepn[j] ? v : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    float x = a[e] + brow[it];
+                    if (p.Rkm) x += rr[it][e];
+                    x *= p.beta;
+                    v[e] = keep4[e] ? x : 0.f;
+                }
+                if (whole4) {
+                    *reinterpret_cast<f32x4v*>(p.Ykm + (int64_t)m * p.ldykm + nq) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (nq + e < N) p.Ykm[(int64_t)m * p.ldykm + nq + e] = v[e];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
