@@ -544,7 +544,7 @@ struct ResBranchParams {
 };
 bool resbranch_usable(const ResBranchParams& p);
 bool resbranch_enabled();
-bool resbranch_wanted(int C);   // the default fuses C <= 32 (mode 2: C = 64 too)
+bool resbranch_wanted(int C, int k);   // mode 1 (default): every shape resbranch_clx.hip instantiates; 2: its k = 3 branches only
 int set_resbranch(int on);      // returns the previous setting (default 1; SBV2_RESBRANCH=0)
 void launch_resbranch(const ResBranchParams& p, hipStream_t stream);
 

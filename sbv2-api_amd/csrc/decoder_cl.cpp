@@ -457,7 +457,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             // operands in LDS; 2 plane passes through HBM instead of 6; same bits as the three fused steps below)
             // (the same at C = 128, where it replaces the branch's six conv_clx launches: f32 XU in, f32 XS out, no parts planes; C = 256 does not fit: its
             // window alone is 143 KB at 128 rows)
-            if (((!clx && C <= 64) || (clx && C == 128)) && fuse_pairs_ && resbranch_wanted(C) && st.mode == 1 && nd == kResBranchSteps && (U & (U - 1)) == 0 &&
+            if (((!clx && C <= 64) || (clx && C == 128)) && fuse_pairs_ && resbranch_wanted(C, rb.k) && st.mode == 1 && nd == kResBranchSteps && (U & (U - 1)) == 0 &&
                 !(next_upx && j + 1 == nk)) {
                 ResBranchParams bp;
                 bp.X = XU;

@@ -1,4 +1,5 @@
-// A whole HiFi-GAN ResBlock1 BRANCH (its three conv1 -> conv2 steps) of the decoder stages with C <= 64 channels in ONE launch, split-bf16 (round 6).
+// A whole HiFi-GAN ResBlock1 BRANCH (its three conv1 -> conv2 steps) in ONE launch, split-bf16 (round 6): the k = 3 branches of the decoder stages with
+// C <= 128 channels and the k = 7 / 11 branches of the 16-channel stage.
 //
 //     y_0 = y;   y_q = keep * ( conv2_q( lrelu( conv1_q( lrelu(y_{q-1}), dilation d_q ) + b1_q ) * keep ) + b2_q + y_{q-1} ),  q = 1 .. 3
 //     result = beta * y_3  [+ previous contents]
@@ -71,6 +72,9 @@ __device__ __forceinline__ void rb_write_b32(unsigned addr, float v) { asm volat
 __device__ __forceinline__ void rb_write_b8(unsigned addr, unsigned v) { asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
 constexpr int rb_max(int a, int b) { return a > b ? a : b; }
+// rows in front of / behind the window that a tap may reach: k = 3 with dilation <= 6 keeps the layout the sweeps below were measured on; the wider kernels
+// (C = 16 only) cover dilation <= 5: 15 -> 16 rows at k = 7, 25 -> 26 at k = 11
+constexpr int rb_margin(int k) { return k <= 3 ? kResBranchMargin : ((5 * (k - 1) / 2 + 1) & ~1); }
 
 template <int C, int NTAPS, int WNP, int GT, int NBUFP>
 struct RbCfg {
@@ -89,7 +93,7 @@ struct RbCfg {
     static constexpr int NBUF = NBUFP;                 // ring of weight buffers: group gs lives in slot gs % NBUF and is requested NBUF - 1 groups ahead
     static constexpr int WREG = NBUF * WSLOT;
     static constexpr int NP = NMT * G * 2;             // 1 KB pieces of a full group, dealt round-robin over the waves
-    static constexpr int MARG = kResBranchMargin;      // rows in front of / behind the window that a tap may reach (contents: don't care)
+    static constexpr int MARG = rb_margin(NTAPS);      // rows in front of / behind the window that a tap may reach (contents: don't care)
     static constexpr int XROWS = R + 2 * MARG;
     // 16x16x32 (C = 16): a fragment read touches BOTH channel halves: they must be a multiple of 256 bytes apart (respair_clx.hip has the measurement)
     static constexpr int XHALF = TWOTAP ? (XROWS * 16 + 255) / 256 * 256 : XROWS * 16;
@@ -630,21 +634,34 @@ static void launch_rb(const ResBranchParams& p, hipStream_t stream) {
     }
 }
 
-// 0: the unfused paths (three respair_clx launches; at C = 128 six conv_clx launches); 1 (default): the fused branch at C = 16 / 32 / 64 / 128
+// 0: the unfused paths (three respair_clx launches; at C = 128 six conv_clx launches); 1 (default): the fused branch at C = 16 / 32 / 64 / 128 (k = 3) and
+// at C = 16 (k = 7 / 11); 2: the k = 3 branches only
 static std::atomic<int> g_rb{getenv("SBV2_RESBRANCH") ? atoi(getenv("SBV2_RESBRANCH")) : 1};   // sbv2_debug_set_resbranch
 int set_resbranch(int on) { return g_rb.exchange(on); }
 bool resbranch_enabled() { return g_rb.load(std::memory_order_relaxed) != 0; }
-bool resbranch_wanted(int C) { return g_rb.load(std::memory_order_relaxed) != 0 && (C == 16 || C == 32 || C == 64 || C == 128); }
+bool resbranch_wanted(int C, int k) {
+    const int mode = g_rb.load(std::memory_order_relaxed);
+    if (mode == 0 || !(C == 16 || C == 32 || C == 64 || C == 128)) return false;
+    return k == 3 || mode == 1;
+}
+
+// rows of the window of the instance launch_rb_any picks (0: none)
+static int rb_rows(int C, int k) {
+    if (k == 3) return C == 128 ? 192 : (C == 64 ? 384 : ((C == 32 || C == 16) ? 256 : 0));
+    if (C == 16 && (k == 7 || k == 11)) return 512;
+    return 0;
+}
 
 bool resbranch_usable(const ResBranchParams& p) {
-    if (!(p.C == 16 || p.C == 32 || p.C == 64 || p.C == 128) || p.k != 3 || p.N < 1 || !(p.slope >= 0.f && p.slope <= 1.f) || (p.mask && p.mask_shift < 0)) return false;
+    const int R = rb_rows(p.C, p.k);
+    if (R == 0 || p.N < 1 || !(p.slope >= 0.f && p.slope <= 1.f) || (p.mask && p.mask_shift < 0)) return false;
     int halo = 0;
     for (int q = 0; q < kResBranchSteps; ++q) {
-        if (p.dil[q] < 1 || p.dil[q] * (p.k - 1) / 2 > kResBranchMargin) return false;
+        if (p.dil[q] < 1 || p.dil[q] * (p.k - 1) / 2 > rb_margin(p.k)) return false;
         if (!p.W[2 * q] || !p.W[2 * q + 1] || !p.b[2 * q] || !p.b[2 * q + 1]) return false;
         halo += (p.dil[q] + 1) * (p.k - 1) / 2;
     }
-    return halo * 2 <= 64;   // (leaves >= half of the smallest window as output)
+    return halo * 4 <= R;   // (leaves >= half of the window as output)
 }
 
 template <int DG>
@@ -659,10 +676,22 @@ static void launch_rb_any(const ResBranchParams& p, hipStream_t stream) {
     // ones, bound by their own instruction issue, want several small ones.  (The same structure for ONE k = 7 / 11 step of the 64-channel stage - a 384-row
     // window, both convolutions over all of it - measured against respair_clx.hip: same bits, the stage's bucket 10.9 -> 12.0 ms per step, the step
     // +0.65 ms: profiles/r06p_one_step_big_workgroup_ab.txt.  A single MFMA-bound step has no plane pass to save and pays 1.03-1.19x recompute.  Not kept.)
-    if (p.C == 128) return launch_rb<128, 3, 3, 3, 2, DG>(p, stream);
-    if (p.C == 64) return launch_rb<64, 3, 6, 3, 3, DG>(p, stream);
-    if (p.C == 32) return launch_rb<32, 3, 4, 4, 3, DG>(p, stream);
-    if (p.C == 16) return launch_rb<16, 3, 4, 4, 3, DG>(p, stream);
+    // The k = 7 / 11 branches of the 16-channel stage (halo 36 / 60 rows per side: 512-row windows on 8 waves, 59 / 74 KB, two workgroups per CU; C = 16 is
+    // the one width whose fused STEP is HBM bound at these kernel sizes: 0.92 -> 0.76 and 1.11 -> 1.07 ms per half plane, same bits).  In the pipelined step
+    // the window size matters beyond the isolated time: 1024-row windows on 16 waves (94 KB, one 1024-thread workgroup per CU) measure the same in isolation
+    // (0.77 / 1.01 ms) and cost the step +0.7 ms, because the other context's kernels no longer fit beside them; 512-row windows: -0.25 ms.  C = 32 (k = 7 / 11
+    // on 512 / 768 / 1024 rows: 1.25 -> 1.15 and 1.66 -> 1.62 ms isolated at 1024 rows, equal at 512) gains nothing in the step: not instantiated.
+    // (profiles/r06w_resbranch_k_probe*.jsonl, r06x_bench_resbranch_k_ab*.txt)
+    if (p.k == 3) {
+        if (p.C == 128) return launch_rb<128, 3, 3, 3, 2, DG>(p, stream);
+        if (p.C == 64) return launch_rb<64, 3, 6, 3, 3, DG>(p, stream);
+        if (p.C == 32) return launch_rb<32, 3, 4, 4, 3, DG>(p, stream);
+        if (p.C == 16) return launch_rb<16, 3, 4, 4, 3, DG>(p, stream);
+    } else if (p.C == 16 && p.k == 7) {
+        return launch_rb<16, 7, 8, 4, 3, DG>(p, stream);
+    } else if (p.C == 16 && p.k == 11) {
+        return launch_rb<16, 11, 8, 6, 3, DG>(p, stream);
+    }
     SBV2_REQUIRE(false, "resbranch: shape not instantiated");
 }
 

@@ -123,16 +123,18 @@ def _resbranch(x, w, b, k, dils, mask, mask_div, beta, prev, variant):
     return y
 
 
-@pytest.mark.parametrize("C,N", [(16, 700), (16, 233), (16, 232 * 9 + 5), (32, 257), (32, 2000), (32, 232), (32, 31), (64, 130), (64, 1111), (64, 104 * 17 + 3), (64, 105),
-                                 (128, 300), (128, 104 * 5 + 1)])
-def test_resbranch_kernel_same_bits_as_three_respair_steps(C, N):
+@pytest.mark.parametrize("C,N,k", [(16, 700, 3), (16, 233, 3), (16, 232 * 9 + 5, 3), (32, 257, 3), (32, 2000, 3), (32, 232, 3), (32, 31, 3), (64, 130, 3), (64, 1111, 3),
+                                   (64, 104 * 17 + 3, 3), (64, 105, 3), (128, 300, 3), (128, 104 * 5 + 1, 3),
+                                   # the wide kernels of the 16-channel stage: 512-row windows, 440 (k = 7) / 392 (k = 11) outputs per workgroup
+                                   (16, 440 * 3 + 1, 7), (16, 441, 7), (16, 90, 7), (16, 392 * 2, 11), (16, 393, 11), (16, 3000, 11)])
+def test_resbranch_kernel_same_bits_as_three_respair_steps(C, N, k):
     """resbranch_clx.hip (round 6): the three steps of a k = 3 ResBlock1 branch (dilations 1, 3, 5) in ONE launch, the residual stream in registers and the
     operand windows in LDS, gives the SAME bits as three launches of the fused step (respair_clx.hip): plain, with a column mask (edges of packed utterances:
     mask_div 4) and with beta + accumulate (the branch's last step), at lengths around the tile sizes (232 / 104 outputs per workgroup); and both agree with
-    the numpy oracle's three resblock steps (O.conv1d_same: the checker)."""
-    k, dils = 3, (1, 3, 5)
+    the numpy oracle's three resblock steps (O.conv1d_same: the checker).  The 16-channel stage's k = 7 / 11 branches run the same kernel on 512-row windows."""
+    dils = (1, 3, 5)
     RV = 0 if C <= 64 else 2      # the reference chain: three fused steps (respair_clx, C <= 64) or six conv_cl launches (any C; same bits as the fused step)
-    rng = np.random.default_rng(C * 1000 + N)
+    rng = np.random.default_rng(C * 1000 + N + k)
     x = rng.standard_normal((N, C)).astype(np.float32)
     w = (rng.standard_normal((6, C, C, k)) / np.sqrt(C * k)).astype(np.float32)
     b = rng.standard_normal((6, C)).astype(np.float32)
