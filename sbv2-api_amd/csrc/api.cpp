@@ -413,7 +413,7 @@ int sbv2_debug_conv_transpose1d_clx(int device, const float* x, const float* w, 
     SBV2_REQUIRE(x && w && bias && y && mask_div >= 1 && (mask_div & (mask_div - 1)) == 0, "bad arguments");
     Blob b = one_conv_blob(w, bias, {cin, cout, k}, cout);
     WeightStore ws(b);
-    ClUpX u = build_upx(ws, w, bias, (int)cin, (int)cout, (int)k, (int)stride);
+    ClUpX u = build_upx(ws, w, bias, (int)cin, (int)cout, (int)k, (int)stride, /*parts_out=*/ys_sum != nullptr);   // (sbv2_debug_set_upx(2): plain row order)
     SBV2_REQUIRE(u.wx, "shape not supported by the phased conv_clx transposed convolution");
     const int64_t Lo = L * stride;
     std::vector<float> xt((size_t)L * cin), yt((size_t)Lo * cout);
@@ -454,6 +454,7 @@ int sbv2_debug_conv_transpose1d_clx(int device, const float* x, const float* w, 
     p.mask_shift = shift;
     p.out_stride = (int)stride;
     p.phase_rows = (int)cout;
+    p.phase_group = u.group;
     for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = u.phase_off[q];
     try {
         SBV2_REQUIRE(conv_clx_usable(p), "shape not supported by conv_clx");

@@ -479,13 +479,19 @@ struct ConvClxParams {
     // No residual, no accumulate, whole-tile launches (N >= 256).
     int out_stride = 1, phase_rows = 0;    // phase_rows 0: not phased
     int phase_off[kMaxPhases] = {0};
+    // phase_group 2: the rows come in 32-row blocks of (two consecutive phases) x (16 channels): block = (phase / 2) * (phase_rows / 16) + channel / 16, row
+    // in block = (phase & 1) * 16 + channel % 16; phase_off[2 j + 1] == phase_off[2 j] + 1.  Four lanes of the epilogue then write the 16-channel parts rows
+    // of two ADJACENT output rows = 64 contiguous bytes, where the plain order writes 32-byte pieces out_stride rows apart (partial HBM writes: measured 2x
+    // the write bytes plus the read-modify-write fetches, profiles/r06q_pmc_hbm_traffic.csv); the f32 rows leave as 64-byte halves of a line.
+    int phase_group = 1;
     double prof_flops = 0.0;               // > 0: the launch's algorithmic FLOP for sbv2_prof_* (a phased launch multiplies zero padding taps too)
 };
 int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv_clx starts for p
 bool conv_clx_usable(const ConvClxParams& p);
 bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
 int set_clx(int on);  // returns the previous setting
-int set_upx(int on);  // the wide stages' transposed convolutions as phased conv_clx launches (default 1); returns the previous setting
+int set_upx(int on);  // the wide stages' transposed convolutions as phased conv_clx launches (default 1; 2: their rows in plain (phase, channel) order, read when the weights are packed); returns the previous setting
+int upx_mode();
 // gemm_bfs: small grids split their K loop over groups of waves (another summation order than the batch's tiles; 0 = the unsplit, batch-order dispatch)
 bool ksplit_enabled();
 int set_ksplit(int on);  // returns the previous setting

@@ -528,14 +528,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                     load_rows(1, p.Y, p.ldy, m);
                 }
             }
-            // PH: this workgroup's 64 rows are channels mo .. mo + 63 of ONE phase; its position n is output row n * out_stride + phase_off[phase]
+            // PH: this workgroup's 64 rows are channels mo .. mo + 63 of ONE phase (or, phase_group 2, 32 channels of two adjacent phases); position n of a
+            // phase is output row n * out_stride + phase_off[phase]
             int ostride = 1, mch = m;
             int64_t orow = nf16;
             if constexpr (PH) {
-                const int ph = m0 / p.phase_rows;
                 ostride = p.out_stride;
-                mch = m - ph * p.phase_rows;
-                orow = (int64_t)nf16 * ostride + p.phase_off[ph];
+                if (p.phase_group == 2) {   // (uniform) 32-row blocks of two adjacent phases x 16 channels: lanes 0, 1 of a quad hold one phase, lanes 2, 3 the next
+                    const int blk = (m0 >> 5) + i, nb = p.phase_rows >> 4;
+                    const int pg = blk / nb;
+                    mch = (blk - pg * nb) * 16 + (c8 & 15);
+                    orow = (int64_t)nf16 * ostride + p.phase_off[2 * pg] + (c8 >> 4);
+                } else {
+                    const int ph = m0 / p.phase_rows;
+                    mch = m - ph * p.phase_rows;
+                    orow = (int64_t)nf16 * ostride + p.phase_off[ph];
+                }
             }
             float* yp = p.Y ? p.Y + orow * p.ldy + mch : nullptr;
             const int64_t ystep = (int64_t)16 * ostride * p.ldy;
@@ -735,6 +743,11 @@ bool conv_clx_usable(const ConvClxParams& p) {
         if (p.Ys.p && (p.Ys.C != p.phase_rows || p.Ys.N != (int64_t)p.N * p.out_stride)) return false;
         for (int q = 0; q < p.M / p.phase_rows; ++q)
             if (p.phase_off[q] < 0 || p.phase_off[q] >= p.out_stride) return false;
+        if (p.phase_group == 2) {
+            if ((p.M / p.phase_rows) & 1) return false;
+            for (int q = 0; q < p.M / p.phase_rows; q += 2)
+                if (p.phase_off[q + 1] != p.phase_off[q] + 1) return false;
+        } else if (p.phase_group != 1) return false;
     } else if (p.Ys.p && (p.Ys.C != p.M || p.Ys.N != p.N)) return false;
     return p.N >= 1 && p.X.N == p.N;
 }

@@ -121,7 +121,7 @@ void* pack_cl_pairs(WeightStore& ws, const float* w, int k) {
     return ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
 }
 
-ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s) {
+ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s, bool parts_out) {
     ClUpX u;
     const int pad = (k - s) / 2;
     if (k - 2 * pad != s || s < 1 || s > kMaxPhases || (cout & 63) || (cin & 31)) return u;
@@ -138,16 +138,19 @@ ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int 
     if ((U & 1) == 0) ++U;                       // a zero tap behind the last one
     if (!(U == 3 || U == 5)) return u;
     const int M = s * cout;
+    // a launch that also writes the next stage's operand parts packs its rows as (phase pair, 16 channels, phase in pair, channel): common.h, phase_group
+    const int group = parts_out && (s & 1) == 0 && upx_mode() != 2 ? 2 : 1;
+    auto row_of = [&](int r, int co) { return group == 2 ? (((r >> 1) * (cout >> 4) + (co >> 4)) * 2 + (r & 1)) * 16 + (co & 15) : r * cout + co; };
     std::vector<float> w((size_t)M * cin * U, 0.f), bias((size_t)M);
     double macs = 0;
     for (int r = 0; r < s; ++r)
         for (int co = 0; co < cout; ++co) {
-            bias[(size_t)r * cout + co] = ub ? ub[co] : 0.f;
+            bias[(size_t)row_of(r, co)] = ub ? ub[co] : 0.f;
             for (int ti = 0; ti < U; ++ti) {
                 const int j = s * (tmin + ti) + r + pad;
                 if (j < 0 || j >= k) continue;
                 if (co == 0) macs += (double)cin * cout;
-                for (int ci = 0; ci < cin; ++ci) w[((size_t)(r * cout + co) * cin + ci) * U + ti] = wt[((size_t)ci * cout + co) * k + j];
+                for (int ci = 0; ci < cin; ++ci) w[((size_t)row_of(r, co) * cin + ci) * U + ti] = wt[((size_t)ci * cout + co) * k + j];
             }
         }
     u.wx = pack_clx16(ws, w.data(), M, cin, U);
@@ -158,6 +161,7 @@ ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int 
     u.shift0 = -tmin;                            // tap ti reads input position n - (tmin + ti)
     u.nph = s;
     u.cout = cout;
+    u.group = group;
     u.alg_macs_per_pos = macs;
     for (int r = 0; r < s; ++r) {
         u.phase_off[r] = r;
@@ -251,7 +255,7 @@ void VitsModel::load_decoder_cl(const Blob& blob) {
             g.c = pack_cl(*ws_, w.data(), M, cin, g.ntaps, cl_parts_of(st.mode), bias.data());
             st.up.push_back(g);
         }
-        if (st.mode == 1 && st.ch >= 64) st.upx = build_upx(*ws_, t.data, ub, cin, cout, k, s);
+        if (st.mode == 1 && st.ch >= 64) st.upx = build_upx(*ws_, t.data, ub, cin, cout, k, s, /*parts_out=*/st.ch >= 128);   // (the <= 64-channel stages read f32 planes)
         for (int j = 0; j < nk; ++j) {
             ClBranch rb;
             rb.k = cfg_.res_kernels[j];
@@ -283,6 +287,7 @@ int set_clx(int on) { return g_clx.exchange(on); }
 // the transposed convolutions of the wide stages as phased conv_clx launches (round 6; SBV2_UPX=0 / sbv2_debug_set_upx(0): conv_cl's phase groups, for A/B runs)
 static std::atomic<int> g_upx{getenv("SBV2_UPX") ? atoi(getenv("SBV2_UPX")) : 1};
 int set_upx(int on) { return g_upx.exchange(on); }
+int upx_mode() { return g_upx.load(std::memory_order_relaxed); }
 
 void VitsModel::conv_cl(const ClConv& c, const float* X, int ldx, int NB, float* Y, int ldy, int N, int dil, int pad_l,
                         const unsigned char* mask, int mask_div, float pre_slope, const float* R, int ldr, float beta, int accumulate) {
@@ -407,6 +412,7 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             pu.mask_shift = ushift_in;      // (the mask is per frame: output row >> ushift == input position >> ushift_in)
             pu.out_stride = st.rate;
             pu.phase_rows = C;
+            pu.phase_group = st.upx.group;
             for (int q = 0; q < kMaxPhases; ++q) pu.phase_off[q] = st.upx.phase_off[q];
             pu.prof_flops = 2.0 * st.upx.alg_macs_per_pos * (double)Lcur;
             SBV2_REQUIRE(conv_clx_usable(pu), "decoder: the phased transposed convolution does not fit conv_clx");

@@ -68,11 +68,12 @@ struct ClUpX {
     void* wx = nullptr;
     float* bias = nullptr;      // per row (phase, cout)
     int M = 0, K = 0, ntaps = 0, shift0 = 0, nph = 0, cout = 0;
+    int group = 1;              // ConvClxParams::phase_group of the row order the weights and the bias were packed in
     double alg_macs_per_pos = 0;   // multiply-adds per input position that are not padding (the launch's algorithmic FLOP for the profile)
     int phase_off[kMaxPhases] = {0};
     int phase_ztap[kMaxPhases] = {-1, -1, -1, -1, -1, -1, -1, -1};   // per phase: a tap that is zero padding for ALL of its rows and channels, or -1
 };
-ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s);
+ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s, bool parts_out);
 void* pack_cl_pairs(WeightStore& ws, const float* w, int k);   // w [16][16][k] -> tap-pair fragments (split-bf16) for respair_clx's 16-channel kernel
 // w is [M][K] (Linear / 1x1 conv): bf16 parts (2 = hi + lo, 3 = hi + mid + lo) as MFMA A fragments; K must be a multiple of 16
 BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts);
