@@ -892,6 +892,8 @@ int sbv2_debug_respair(int device, const float* x, const float* w1, const float*
     rp.Y = dy.p;
     rp.W1 = c1.w;
     rp.W2 = c2.w;
+    rp.W1x = c1.wxp;
+    rp.W2x = c2.wxp;
     if (C == 16) {
         rp.W1p = pack_cl_pairs(ws, w1, (int)k);
         rp.W2p = pack_cl_pairs(ws, w2, (int)k);
@@ -907,7 +909,7 @@ int sbv2_debug_respair(int device, const float* x, const float* w1, const float*
     rp.accumulate = accumulate;
     rp.mask = dm;
     rp.mask_div = (int)mask_div;
-    const int prev = set_respair_clx(variant ? 1 : 0);   // 0 = respair_cl, 1 = respair_clx
+    const int prev = set_respair_clx(variant == 0 ? 0 : (variant == 2 ? 2 : 1));   // 0 = respair_cl, 1 = the default dispatch (respair_clx / respair_x16), 2 = respair_clx at every shape
     try {
         launch_respair_cl(rp, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
@@ -1016,6 +1018,8 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
                 rp.W2 = cv[2 * q + 1].w;
                 rp.W1p = wp[2 * q];
                 rp.W2p = wp[2 * q + 1];
+                rp.W1x = cv[2 * q].wxp;
+                rp.W2x = cv[2 * q + 1].wxp;
                 rp.b1 = cv[2 * q].bias;
                 rp.b2 = cv[2 * q + 1].bias;
                 rp.C = (int)C;
@@ -1111,6 +1115,8 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
     rp.Y = dy.p;
     rp.W1 = c1.w;
     rp.W2 = c2.w;
+    rp.W1x = c1.wxp;
+    rp.W2x = c2.wxp;
     if (C == 16) {
         rp.W1p = pack_cl_pairs(ws, w1.data(), (int)k);
         rp.W2p = pack_cl_pairs(ws, w2.data(), (int)k);
@@ -1133,6 +1139,7 @@ int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation,
     auto launch = [&]() {
         if (variant == 0) launch_respair_cl_diag(rp, nullptr);
         else if (variant == 2) launch_respair_clx_diag(rp, nullptr);
+        else if (variant == 4) launch_respair_x16_diag(rp, nullptr);   // respair_x16.hip, stamped
         else launch_respair_cl(rp, nullptr);   // the product kernels (no stamps: clock and phases read 0): 1 = respair_cl, 3 = respair_clx
     };
     hipEvent_t e0, e1;

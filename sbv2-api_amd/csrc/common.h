@@ -506,6 +506,8 @@ struct ResPairParams {
     const void* W2 = nullptr;
     const void* W1p = nullptr;  // C = 16 only: the same weights packed as tap pairs for v_mfma_f32_16x16x32_bf16 (pack_cl_pairs; respair_clx.hip)
     const void* W2p = nullptr;
+    const void* W1x = nullptr;  // C = 32 / 64: the same weights packed as step pairs for v_mfma_f32_16x16x32_bf16 (pack_step_pairs; respair_x16.hip)
+    const void* W2x = nullptr;
     const float* b1 = nullptr;
     const float* b2 = nullptr;
     int C = 0, N = 0, k = 1, dil = 1, split = 1, f16 = 0;
@@ -527,7 +529,11 @@ void launch_respair_cl_diag(const ResPairParams& p, hipStream_t stream);
 bool respair_clx_usable(const ResPairParams& p);          // p.mask_shift set
 void launch_respair_clx(const ResPairParams& p, hipStream_t stream);
 void launch_respair_clx_diag(const ResPairParams& p, hipStream_t stream);
-int set_respair_clx(int on);   // returns the previous setting (default 1)
+int set_respair_clx(int on);   // returns the previous setting (default 1; 2: respair_clx.hip at every shape, none on respair_x16.hip)
+// respair_x16.hip (round 6): the step at C = 32 / 64, k = 7 / 11 on v_mfma_f32_16x16x32_bf16 (conv_clx.hip's operand scheme); f32 rounding apart from respair_clx
+bool respair_x16_usable(const ResPairParams& p);          // p.mask_shift set
+void launch_respair_x16(const ResPairParams& p, hipStream_t stream);
+void launch_respair_x16_diag(const ResPairParams& p, hipStream_t stream);
 
 // resbranch_clx.hip (round 6): the THREE steps of a ResBlock1 branch in one launch (k = 3, C in {16, 32, 64}): y_1 and y_2 never leave the chip, 2 plane passes
 // through HBM per branch instead of 6; bit-identical to three respair_clx launches

@@ -11,6 +11,7 @@ namespace sbv2 {
 // A convolution packed for conv_cl.hip (bf16 MFMA fragment blocks); parts = 2 keeps a bf16 hi and a bf16 lo copy.
 struct ClConv {
     void* w = nullptr;
+    void* wxp = nullptr;   // split-bf16, M == K in {32, 64}: the same weights as step-pair fragments of the 16x16x32 MFMA (pack_step_pairs; respair_x16.hip), else null
     void* wx = nullptr;    // split-bf16, M % 64 == 0, K % 32 == 0: the same weights as [hi | lo] fragments of the 16x16x32 MFMA (pack_clx16; conv_clx.hip), else null
     void* wp = nullptr;    // 16 x 16 convolutions of the fused ResBlock step: tap-pair fragments [pair][part][64 lanes][8] (pack_cl_pairs), else null
     float* bias = nullptr;
@@ -74,6 +75,7 @@ struct ClUpX {
     int phase_ztap[kMaxPhases] = {-1, -1, -1, -1, -1, -1, -1, -1};   // per phase: a tap that is zero padding for ALL of its rows and channels, or -1
 };
 ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s, bool parts_out);
+void* pack_step_pairs(WeightStore& ws, const float* w, int C, int k);   // w [C][C][k], C in {32, 64} -> step-pair fragments (split-bf16) for respair_x16.hip
 void* pack_cl_pairs(WeightStore& ws, const float* w, int k);   // w [16][16][k] -> tap-pair fragments (split-bf16) for respair_clx's 16-channel kernel
 // w is [M][K] (Linear / 1x1 conv): bf16 parts (2 = hi + lo, 3 = hi + mid + lo) as MFMA A fragments; K must be a multiple of 16
 BfsWeights pack_bfs(WeightStore& ws, const float* w, int M, int K, int parts);

@@ -465,7 +465,8 @@ void launch_respair_cl_diag(const ResPairParams& p0, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
-static std::atomic<int> g_rpx{1};   // sbv2_debug_set_respair_clx
+// 0: respair_cl.hip; 1 (default): respair_clx.hip, and respair_x16.hip where it exists (C = 32 / 64, k = 7 / 11); 2 (SBV2_RESPAIR_X16=0): respair_clx.hip only
+static std::atomic<int> g_rpx{getenv("SBV2_RESPAIR_X16") && atoi(getenv("SBV2_RESPAIR_X16")) == 0 ? 2 : 1};   // sbv2_debug_set_respair_clx
 int set_respair_clx(int on) { return g_rpx.exchange(on); }
 
 void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
@@ -481,6 +482,7 @@ void launch_respair_cl(const ResPairParams& p0, hipStream_t stream) {
     SBV2_REQUIRE(p.k >= 1 && p.k <= kMaxTaps && (p.k & 1) == 1, "respair: odd kernel sizes only");
     SBV2_REQUIRE(p.dil * (p.k - 1) <= 64, "respair: tap span too large");
     if (p.N <= 0) return;
+    if (g_rpx.load(std::memory_order_relaxed) == 1 && respair_x16_usable(p)) return launch_respair_x16(p, stream);   // round 6: the 16x16x32 operand scheme
     if (g_rpx.load(std::memory_order_relaxed) && respair_clx_usable(p)) return launch_respair_clx(p, stream);   // the round-4 kernel (same bits at C = 32 / 64; C = 16 sums two taps per MFMA: f32 rounding apart)
     SBV2_REQUIRE(!(p.split && p.f16), "respair: split and f16 are exclusive");
     if (p.C == 64) {

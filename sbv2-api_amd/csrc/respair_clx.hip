@@ -29,6 +29,12 @@
 
 #include "common.h"
 
+// RPX_PROBE16 (diagnostic builds only, tools/respair_shape_probe.sh; results WRONG): every v_mfma_f32_32x32x16_bf16 of the C >= 32 kernels issued as two
+// v_mfma_f32_16x16x32_bf16 from the same fragment registers: what the instruction shape alone is worth at the managed clock
+#ifndef RPX_PROBE16
+#define RPX_PROBE16 0
+#endif
+
 namespace sbv2 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -245,7 +251,16 @@ __global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdg
     const unsigned b1last = b1base - (lg >> 1) * d * 16, b2last = b2base - (lg >> 1) * 16;
     f32x16 acc[TWOTAP ? 1 : 2];
     f32x4v acc4[TWOTAP ? 4 : 1];
+#if RPX_PROBE16
+    f32x4v accq[2][4];     // (shape probe: the 32x32 tiles as four 16x16x32 accumulators each; results are WRONG)
+#endif
     auto zero_acc = [&]() {
+#if RPX_PROBE16
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accq[j][q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#endif
         if constexpr (TWOTAP) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc4[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -302,15 +317,39 @@ __global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdg
     auto mfma_one = [&](const Frags& f, auto nc) {   // term-major; per accumulator: lo*hi, hi*lo, hi*hi (conv_cl's order)
         constexpr int n = decltype(nc)::value;
         constexpr int t = n / NB_, j = n % NB_;
+#if RPX_PROBE16
+        auto& aq = accq;   // (named outside the discarded branch: the generic lambda captures it)
+#endif
         if constexpr (TWOTAP) {
             if constexpr (t == 0) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al, f.bh[j], acc4[j], 0, 0, 0);
             else if constexpr (t == 1) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah, f.bl[j], acc4[j], 0, 0, 0);
             else acc4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah, f.bh[j], acc4[j], 0, 0, 0);
         } else {
+#if RPX_PROBE16
+            // the same FLOP from the same fragment registers as two v_mfma_f32_16x16x32_bf16 per 32x32x16 instruction (timing only)
+            constexpr int sl = (t & 1) * 2;
+            const bf16x8& a = t == 0 ? f.al : f.ah;
+            const bf16x8& b = t == 1 ? f.bl[j] : f.bh[j];
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(aq[j & 1][sl]) : "v"(a), "v"(b));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(aq[j & 1][sl + 1]) : "v"(a), "v"(b));
+#else
             if constexpr (t == 0) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[j], 0, 0, 0);
             else if constexpr (t == 1) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[j], 0, 0, 0);
             else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[j], 0, 0, 0);
+#endif
         }
+    };
+    auto probe_fold = [&]() {   // (shape probe) the 16x16 accumulators -> the registers the epilogues read
+#if RPX_PROBE16
+        if constexpr (!TWOTAP) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = accq[j][q][e];
+        }
+#endif
     };
     // one weight group: its steps; the fragment reads of step t + 1 are dealt one per gap between the MFMAs of step t (a burst of reads in front of
     // the MFMAs fills the LDS command queue and leaves the matrix pipe idle while it drains)
@@ -421,6 +460,7 @@ __global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdg
     // ---- intermediate: + b1, lrelu, keep flag, hi / lo -> the window conv2 reads (aliases the conv1 window: behind a barrier) -------------
     constexpr int S2 = NCH * NG;   // first group of conv2
     group_barrier(std::integral_constant<int, S2>{});
+    probe_fold();
     if constexpr (TWOTAP) {
         // accumulator tile jt: lane (column l16 = position, k group lg) holds channels 4 lg .. 4 lg + 3 of position wn * 64 + 16 jt + l16
         f32x4v bq = rpx_read_f128<0>(lds0 + K::BIAS_OFF + lg * 16);
@@ -498,6 +538,7 @@ __global__ __launch_bounds__((RpxCfg<C, NTAPS, GT, WNP>::T)) __attribute__((amdg
         run_group(sc);
     });
     RPX_STAMP(5);
+    probe_fold();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();   // the transpose tiles overlay the weight buffers and the window
 
