@@ -15,15 +15,16 @@
 // Round 5: v_mfma_f32_16x16x32_bf16 instead of 32x32x16.  These launches are POWER bound: the timeline of a workgroup's life (sbv2_debug_clx_timeline,
 // profiles/r05*_clx_timeline*.jsonl) shows the chip trading clock for every cycle a denser schedule saves (epilogue 30 -> 20 us: launch -2 %, loop clock
 // 1.70 -> 1.61 GHz, aggregate MFMA rate unchanged), and a probe build of this loop that issued the same FLOP from the same fragment registers as 16x16x32
-// instructions ran 11-12.5 % faster at k = 7 / 11 (profiles/r05d_clx_shape_probe.jsonl; MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.14x).  The 32-deep
-// K dimension of the new shape carries, for one (chunk, tap):
-//     M1:  A = [W_hi | W_lo] (k groups 0, 1 | 2, 3),  B = [X_lo ; X_hi]      ->  W_hi X_lo + W_lo X_hi   (both cross terms in ONE instruction)
-// and for a PAIR of consecutive steps s, s + 1 (any two: the pairing runs over the global step sequence, across chunk boundaries):
-//     M2:  A = [W_hi(s) | W_hi(s+1)],  B = [X_hi(s) ; X_hi(s+1)]             ->  the two hi x hi terms
-// M2's operands are not read from LDS: one v_permlane32_swap per register turns the two M1 fragments of a pair into them (A: the low halves of both, B:
-// the high halves of both).  So LDS reads, weight bytes and window bytes per FLOP are those of the 32x32x16 kernel, the LDS images are the same size (52 KB:
-// three workgroups per CU), and 3 K-products are issued per algorithmic product as before.  The summation order differs from conv_cl's (32 products per
-// instruction, cross terms together): results agree with conv_cl to f32 rounding (tests hold 1e-5 kernel against kernel), not bit for bit.
+// instructions ran 11-12.5 % faster at k = 7 / 11 (profiles/r05d_clx_shape_probe.jsonl; MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.14x).
+// Round 6: the 32-deep K dimension of that shape carries a PAIR of consecutive steps a, b (any two: the pairing runs over the global step sequence, across
+// chunk boundaries), as respair_x16.hip:
+//     A_part = [W_part(a) | W_part(b)] (k groups 0, 1 | 2, 3; packed at load: pack_clx16),   B_part = [X_part(a) ; X_part(b)] (k groups 0, 1 read step a's row
+//     of its window, 2, 3 step b's),   and per accumulator   A_lo B_hi,  A_hi B_lo,  A_hi B_hi
+// 16 fragment reads and no operand shuffling per 48 MFMAs.  (Round 5 put both cross terms of ONE step into an instruction, A = [W_hi | W_lo], B = [X_lo ; X_hi],
+// and made a pair's hi x hi operands with 16 v_permlane32_swap + 4 more reads: same FLOP, 20 reads and 16 cross-lane VALU operations per pair; on one box the
+// decoder's bucket 28.4 -> 26.8 ms, the flow's FFN pair 6.17 -> 5.65 ms, the step 68.99 -> 67.06 ms: profiles/r06za_clx_steppair_ab.txt.)  The LDS images are
+// the same size (52 KB: three workgroups per CU), 3 K-products are issued per algorithmic product as before.  The summation order differs from conv_cl's (32
+// products per instruction): results agree with conv_cl to f32 rounding (tests hold 1e-5 kernel against kernel), not bit for bit.
 #include <atomic>
 #include <type_traits>
 
@@ -32,12 +33,6 @@
 // No floating-point contraction in this file: the epilogue's (sum) * beta + previous contents must round the same way whatever shape the surrounding
 // control flow has (an fma there moved the waveform by 9e-7 between two epilogue variants that promise the same bits)
 #pragma clang fp contract(off)
-
-// CLX_ABL (diagnostic builds only, tools/clx_ablate.sh; results WRONG for 1-3): 1 = the weight waves do not wait for their DMAs at a pair's TOP, 2 = no
-// v_permlane32_swap (M2 takes a's M1 fragments), 3 = both and the window waves never wait, 4 = M2's B fragments requested in M1(b)'s first gaps
-#ifndef CLX_ABL
-#define CLX_ABL 0
-#endif
 
 namespace sbv2 {
 
@@ -98,20 +93,6 @@ __device__ __forceinline__ unsigned clx_opaque(unsigned x) {
 __device__ __forceinline__ void clx_mfma16(f32x4v& c, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-// the two fragments of a step pair -> (the low halves of both, the high halves of both), one v_permlane32_swap per register
-__device__ __forceinline__ void clx_halves(const bf16x8& a, const bf16x8& b, bf16x8& lo, bf16x8& hi) {
-    const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
-    u32x4 l, h;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const auto s = __builtin_amdgcn_permlane32_swap(ua[r], ub[r], false, false);   // lanes 32-63 of the first <-> lanes 0-31 of the second
-        l[r] = s[0];
-        h[r] = s[1];
-    }
-    lo = __builtin_bit_cast(bf16x8, l);
-    hi = __builtin_bit_cast(bf16x8, h);
-}
-
 // 4 waves, 64 rows x 256 positions per workgroup (wave: 64 rows x 64 positions = 4 x 4 accumulator tiles of 16 x 16); kClxWR weight ring slots (4 KB: one
 // step), kClxXB window buffers of XR rows (both parts).  <= 53 KB of LDS and <= 168 registers: THREE workgroups per CU.
 // EDGE: the launch has a partial last position tile (N % 256 != 0): its guarded epilogue is compiled in.  (Compiled into every instance, that rarely taken
@@ -130,7 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     constexpr int NWW = 2;                     // weight-DMA waves (the others carry the window)
     constexpr int NXW = NW - NWW;
     constexpr int kClxPW = (2 * (XR / 32) + NXW - 1) / NXW;   // window DMA pieces per window wave and chunk (2 parts x XR / 32 pieces of 32 rows)
-    constexpr int WSLOT = 4096;                // one (chunk, tap): 4 row tiles of 16 x [hi | lo] fragment blocks of 1 KB
+    constexpr int WSLOT = 4096;                // half a pair of steps: 2 row tiles of 16 x (hi block, lo block) of 1 KB; a pair = two consecutive slots
     constexpr int WBYTES = kClxWR * WSLOT;
     constexpr int XPART = XR * 32, XBUF = 2 * XPART;   // (XR = window rows per buffer: 320 holds every tap span <= 64; 288 those <= 32); hi plane, then lo plane
     const ConvClxParams& p = kp.p;
@@ -161,20 +142,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     const bool wwave = wave < NWW;
     // Every DMA source is a wave-uniform pointer (scalar registers) + this lane's 16-byte piece of the 1 KB block: no per-lane 64-bit pointers.
     const unsigned lane16 = lane * 16;
-    // weight wave w: blocks 2 w, 2 w + 1 of the step's four (2 KB contiguous); fragment order [chunk][row tile of 64][tap][row tile of 16] (pack_clx16)
-    const char* wptr = static_cast<const char*>(p.W) + ((int64_t)by * NTAPS) * WSLOT + (wave & (NWW - 1)) * 2048;   // next weight blocks to fetch (uniform)
-    const int64_t wjump = (int64_t)(kp.gy - 1) * NTAPS * WSLOT;   // from a chunk's last tap to the next chunk's first
-    int wtap = 0;                                                   // tap of the block wptr points at
+    // weight wave w: 2 KB of each half pair (4 KB = two row tiles of 16 x [hi block, lo block]); block order [row tile of 64][pair][row tile of 16][part]
+    // (pack_clx16): a row tile's pairs are one contiguous run
+    const char* wptr = static_cast<const char*>(p.W) + ((int64_t)by * S) * WSLOT + (wave & (NWW - 1)) * 2048;   // next weight blocks to fetch (uniform)
     const unsigned wdst0 = lds0 + (wave & (NWW - 1)) * 2048;
-    unsigned wdoff = 0;                                             // ring offset the next weight block goes to
+    unsigned wdoff = 0;                                             // ring offset the next half pair goes to
     auto dma_w = [&]() {
         __builtin_amdgcn_global_load_lds((clx_gbl_t*)(wptr + lane16), (clx_lds_t*)(uintptr_t)(wdst0 + wdoff), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((clx_gbl_t*)(wptr + lane16), (clx_lds_t*)(uintptr_t)(wdst0 + wdoff), 16, 1024, 0);   // (the immediate offset applies to both addresses)
         wptr += WSLOT;
-        if (++wtap == NTAPS) {
-            wtap = 0;
-            wptr += wjump;
-        }
         wdoff = wdoff + WSLOT == WBYTES ? 0 : wdoff + WSLOT;
     };
     // window wave v = wave - NWW: pieces e = v, v + NXW, ... of the 2 * npc pieces of a chunk (piece = 32 rows of one part = 1 KB contiguous; this lane: row
@@ -205,23 +181,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     };
     auto next_window = [&]() { xdoff = xdoff + XBUF == kClxXB * XBUF ? 0 : xdoff + XBUF; };
 
-    // ---- fragments of one step (operands of M1): A[it] = rows 16 it .. 16 it + 15: lane (row l16, k group lg) holds [W_hi k 0-7 | W_hi k 8-15 | W_lo k 0-7 |
-    // W_lo k 8-15][lg]; B[jt] = positions 16 jt .. + 15 of the wave's 64: lane (column l16, k group lg) holds [X_lo | X_lo | X_hi | X_hi] likewise
+    // ---- fragments of one PAIR of steps a, b: A_part[it] = rows 16 it .. + 15: lane (row l16, k group lg) holds W_part of step a (lg < 2) or b (lg >= 2),
+    // channels 8 (lg & 1) .. + 7 of the step's chunk (pack_clx16: the pair's eight 1 KB blocks [row tile of 16][part]); B_part[jt] = positions 16 jt .. + 15 of
+    // the wave's 64: lane (column l16, k group lg) reads 16 bytes of the row of step a (lg < 2) or b (lg >= 2) in the part's plane
     struct Frags {
-        bf16x8 a[4], b[4];
+        bf16x8 ah[4], al[4], bh[4], bl[4];
+    };
+    struct Pend {
+        bf16x8 ah[4], bh[4];
     };
     const int l16 = lane & 15, lg = lane >> 4;
     const unsigned abase = lds0 + lane * 16;
-    // this lane's B-fragment address in the window of tap 0: k groups 0, 1 read the lo plane (XPART further), 2, 3 the hi plane; 16-byte half lg & 1 of
-    // the row; tap t is t * shs32 bytes further (wave-uniform: added per step)
-    const unsigned blane = lds0 + WBYTES + (lg < 2 ? XPART : 0) + (wq * NPW + l16 + kp.sh0) * 32 + ((lg & 1) << 4);
+    // this lane's B-fragment address in the hi plane of window buffer 0 at tap 0: 16-byte half lg & 1 of the row; a step's tap and buffer are added per pair
+    // (k groups 0, 1: step a's, 2, 3: step b's), the lo plane is an immediate (XPART) further
+    const unsigned bhlane = lds0 + WBYTES + (wq * NPW + l16 + kp.sh0) * 32 + ((lg & 1) << 4);
     const int shs32 = kp.sh_step * 32;
-    const unsigned bhlane = blane - (lg < 2 ? XPART : 0);   // the same row and half in the hi plane (the B operand of a pair's hi x hi product)
-    auto read_frag = [&](Frags& f, auto rc, unsigned aaddr, unsigned b0) {
-        constexpr int r = decltype(rc)::value;   // 0..3: A (row tile of 16); 4..7: B (position tile of 16 = 512 bytes of window)
-        if constexpr (r < 4) f.a[r] = clx_read_b128o<r * 1024>(aaddr);
-        else f.b[r - 4] = clx_read_b128o<(r - 4) * 512>(b0);
-    };
     f32x4v acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -231,41 +205,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
         constexpr int n = decltype(nc)::value;
         // (inline asm: the accumulator stays in ITS registers.  Given the builtin, hipcc wrote each result to another register quad and took the old one for
         // a fragment, then restored the mapping with ~200 v_mov per loop iteration.  An accumulate chain needs no wait states; the A / B operands were
-        // written by LDS reads waited for a barrier ago, or by the swaps at least three instructions earlier.)
+        // written by LDS reads waited for before the set.)
         clx_mfma16(acc[n >> 2][n & 3], a[n >> 2], b[n & 3]);
     };
+    // The operands of a set of MFMAs stay allocated until the set has been issued: the fragment reads dealt between the MFMAs return asynchronously, and the
+    // compiler (which sees neither: inline asm) may otherwise hand a read the registers of an operand whose last MFMA in program order is still queued in
+    // front of the matrix pipe (respair_x16.hip has the failure this produced)
+    auto keep4 = [&](const bf16x8 (&v)[4]) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); };
 
     // ---- The loop runs in PAIRS of consecutive steps a = 2 u, b = 2 u + 1 (step s = tap s % NTAPS of chunk s / NTAPS; NTAPS is odd and the chunk count even, so
-    // the pairing runs across chunk boundaries and every two chunks hold NTAPS pairs), ONE barrier per pair:
-    //   TOP    lgkmcnt(0) [fragments of a, requested during the previous pair] -> vmcnt -> barrier
-    //   M1(a)  16 MFMAs; the fragments of b are requested in their first 8 gaps; the weight waves fetch the blocks of steps 2 u + 3, 2 u + 4 (into the slots of
-    //          2 u - 1 and a, both read by every wave before this barrier)
-    //          lgkmcnt(0) [fragments of b]
-    //   M1(b)  16 MFMAs; the window waves fetch their share of the next window
-    //          32 v_permlane32_swap: the hi x hi operands of both steps
-    //   M2     16 MFMAs; the fragments of step 2 u + 2 are requested in their first 8 gaps
-    // What must have landed at TOP(u): the weight blocks of b and 2 u + 2 (all a weight wave has in flight: vmcnt(0)), and the window of a chunk whose first
-    // step is b or 2 u + 2.  With chunks c0 (even), c0 + 1 in pairs 0 .. NTAPS - 1 of an iteration and J0 = (NTAPS - 1) / 2: window c0 + 1 (first read: step
-    // NTAPS = the b of pair J0) is fetched during pairs 0 .. J0 - 1 (its buffer's previous window was last read in the previous iteration) and waited for at
-    // TOP(J0); window c0 + 2 (first read: the next iteration's first step, requested in the last pair's M2) during pairs J0 .. NTAPS - 2 (window c0 was last
-    // read during pair J0 - 1) and waited for at TOP(NTAPS - 1).  At those two points a window wave has nothing else in flight: vmcnt(0).
+    // the pairing runs across chunk boundaries and every two chunks hold NTAPS pairs), ONE barrier per pair, three sets of 16 MFMAs per pair whose 32-deep K
+    // dimension carries the two steps (round 6; rounds 5's scheme - both cross terms of ONE step per instruction, the pair's hi x hi operands by
+    // v_permlane32_swap + four more reads - cost 16 swaps and 4 reads per pair more):
+    //   TOP    lgkmcnt(0) -> vmcnt -> barrier
+    //   S0     A_hi B_hi of the PREVIOUS pair (its operands are registers): covers the reads of A_lo, B_hi of this pair, dealt in its first 8 gaps; the weight
+    //          waves fetch the blocks of pair u + 1 (into the pair slot of u - 1, read by every wave before this barrier)
+    //          lgkmcnt(0)
+    //   S1     A_lo B_hi; the reads of A_hi, B_lo in its first 8 gaps; the window waves fetch their share of the next window
+    //          lgkmcnt(0)
+    //   S2     A_hi B_lo
+    // What must have landed at TOP(u): the weight blocks of pair u (all a weight wave has in flight: vmcnt(0)), and the window of a chunk whose first step is
+    // in pair u.  With chunks c0 (even), c0 + 1 in pairs 0 .. NTAPS - 1 of an iteration and J0 = (NTAPS - 1) / 2: window c0 + 1 (first read: step b of pair J0)
+    // is fetched during pairs 0 .. J0 - 1 (its buffer's previous window was last read in the previous iteration) and waited for at TOP(J0); window c0 + 2 (first
+    // read: the next iteration's first pair) during pairs J0 + 1 .. NTAPS - 1 (window c0 is last read by pair J0) and waited for at the next iteration's TOP(0).
+    // At those two points a window wave has nothing else in flight: vmcnt(0).
     constexpr int J0 = (NTAPS - 1) / 2;
     constexpr int PPP = (kClxPW + J0 - 1) / J0;        // window pieces per window wave and pair
-    static_assert(PPP <= 16, "a pair's M1(b) gaps hold its window pieces");
-    static_assert(kClxWR == 4 && kClxXB == 2, "the pair schedule assumes a 4-slot weight ring");
+    static_assert(PPP <= 16, "a pair's S1 gaps hold its window pieces");
+    static_assert(kClxWR == 4 && kClxXB == 2, "the pair schedule assumes two pair slots of weights and two window buffers");
     if (wwave) {
         dma_w();
-        dma_w();
-        dma_w();               // steps 0, 1, 2 (S >= 6)
+        dma_w();               // pair 0
     } else {
         clx_static_for<0, kClxPW>([&](auto ic) { dma_x(ic); });
         next_window();
     }
-    clx_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    Frags fe, fo;              // the even / odd step of a pair
-    clx_static_for<0, 8>([&](auto rc) { read_frag(fe, rc, abase, blane); });
-    unsigned wroff = WSLOT;    // ring offset of the weight slot the NEXT fragment reads take
+    unsigned wroff = 0;        // ring offset of the pair slot the fragment reads take
+    Pend pend;                 // hi x hi operands of the previous pair (zeros in front of the first)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pend.ah[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        pend.bh[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 
     unsigned long long st_t0 = 0, st_r0 = 0;
     if (p.stamps) {
@@ -276,58 +257,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
         const int s0 = chunk * NTAPS;
         clx_static_for<0, NTAPS>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            constexpr int ra = 2 * j, rb = 2 * j + 1, rn = 2 * j + 2;         // steps a, b and the next a, relative to s0
-            constexpr int tapa = ra % NTAPS, bufa = (ra / NTAPS) & 1, tapb = rb % NTAPS, bufb = (rb / NTAPS) & 1, tapn = rn % NTAPS, bufn = (rn / NTAPS) & 1;
+            constexpr int ra = 2 * j, rb = 2 * j + 1;         // steps a, b relative to s0
+            constexpr int tapa = ra % NTAPS, bufa = (ra / NTAPS) & 1, tapb = rb % NTAPS, bufb = (rb / NTAPS) & 1;
             // ---- TOP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (wwave) {
-                if (CLX_ABL != 1 && CLX_ABL != 3) clx_wait_vm<0>();
-            } else if constexpr (j == J0 || j == NTAPS - 1) {
-                if (CLX_ABL != 3) clx_wait_vm<0>();
-            }
+            if (wwave) clx_wait_vm<0>();
+            else if constexpr (j == J0 || j == 0) clx_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---- M1(a); fragments of b
+            Frags f;
+            // (fragment addresses are formed where they are used, from opaque copies of the lane bases: hoisted out of the loop they took up to 33 registers)
+            const unsigned aaddr = clx_opaque(abase) + wroff;
+            const unsigned b0 = clx_opaque(bhlane) + (unsigned)(lg < 2 ? tapa * shs32 + bufa * XBUF : tapb * shs32 + bufb * XBUF);
+            wroff ^= 2 * WSLOT;
+            // ---- S0: the previous pair's hi x hi; A_lo, B_hi of this pair; the weight blocks of the next pair
             {
-                // (fragment addresses are formed where they are used, from an opaque copy of the lane base: hoisted out of the loop - they are loop
-                // invariant, three per pair - they took up to 33 registers and came back as scratch reloads + s_waitcnt vmcnt(0) between the MFMAs)
-                const unsigned aaddr = abase + wroff, b0 = clx_opaque(blane) + (unsigned)(tapb * shs32 + bufb * XBUF);
-                wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
-                const bool w3 = wwave && s0 + 2 * j + 3 < S, w4 = wwave && s0 + 2 * j + 4 < S;
-                // (PH, round 6: skipping the 16 cross-term MFMAs of a step whose tap is the phase's zero-padding tap - a uniform branch around each, the reads and
-                // DMAs between them kept - measured SLOWER: 1260 -> 1478 us at the 128-channel stage, 740 -> 801 at the 64-channel one,
-                // profiles/r06j_upsampler_zero_tap_skip_kernel_list.txt: the MFMAs are what paces the fragment reads and DMAs dealt between them)
+                const bool wn = wwave && s0 + 2 * j + 2 < S;
                 clx_static_for<0, 16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
-                    mfma_one(fe.a, fe.b, nc);
-                    if constexpr (n < 8) read_frag(fo, nc, aaddr, b0);
-                    if constexpr (n == 2) {
-                        if (w3) dma_w();
-                    }
-                    if constexpr (n == 6) {
-                        if (w4) dma_w();
+                    mfma_one(pend.ah, pend.bh, nc);
+                    if constexpr (n < 4) f.al[n] = clx_read_b128o<n * 2048 + 1024>(aaddr);
+                    else if constexpr (n < 8) f.bh[n - 4] = clx_read_b128o<(n - 4) * 512>(b0);
+                    if constexpr (n == 2 || n == 6) {
+                        if (wn) dma_w();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                keep4(pend.ah);
+                keep4(pend.bh);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.al[2]), "+v"(f.al[3]), "+v"(f.bh[0]), "+v"(f.bh[1]), "+v"(f.bh[2]), "+v"(f.bh[3]));
             __builtin_amdgcn_sched_barrier(0);
-            // ---- M1(b); window pieces: pairs 0 .. J0 - 1 carry window chunk + 1, pairs J0 .. NTAPS - 2 window chunk + 2
-            bf16x8 hb[4];
+            // ---- S1: lo x hi; A_hi, B_lo; window pieces: pairs 0 .. J0 - 1 carry window chunk + 1, pairs J0 + 1 .. NTAPS - 1 window chunk + 2
             {
                 constexpr bool first = j < J0;
-                constexpr int jj = first ? j : j - J0;
+                constexpr int jj = first ? j : j - J0 - 1;
                 const bool stx = !wwave && (first ? chunk + 1 < nchunks : chunk + 2 < nchunks);
-                // B operand of the pair's hi x hi product [X_hi(a) ; X_hi(b)]: k groups 0, 1 read the hi plane at tap a, 2, 3 at tap b (four more fragment
-                // reads per pair, into the registers of a's B fragments: swapped out of the M1 fragments like the A operand, they cost 16 more
-                // v_permlane32_swap per pair, and the pair's 32 swaps were a fifth of the loop's cycles)
-                const unsigned bh0 = clx_opaque(bhlane) + (unsigned)(lg < 2 ? tapa * shs32 + bufa * XBUF : tapb * shs32 + bufb * XBUF);
                 clx_static_for<0, 16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
-                    mfma_one(fo.a, fo.b, nc);
-                    constexpr int HB0 = CLX_ABL == 4 ? 0 : 10;
-                    if constexpr (j != J0 && n >= HB0 && n < HB0 + 4) hb[n - HB0] = clx_read_b128o<(n - HB0) * 512>(bh0);
-                    if constexpr (j < NTAPS - 1 && n < PPP) {
+                    mfma_one(f.al, f.bh, nc);
+                    if constexpr (n < 4) f.ah[n] = clx_read_b128o<n * 2048>(aaddr);
+                    else if constexpr (n < 8) f.bl[n - 4] = clx_read_b128o<XPART + (n - 4) * 512>(b0);
+                    if constexpr (j != J0 && n < PPP) {
                         constexpr int i = jj * PPP + n;
                         if constexpr (i < kClxPW) {
                             if (stx) dma_x(std::integral_constant<int, i>{});
@@ -338,40 +309,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                keep4(f.al);
             }
-            // ---- A operand of the pair's hi x hi product [W_hi(a) | W_hi(b)]: the low halves of both M1 fragments (one v_permlane32_swap per register)
-            bf16x8 ha[4], dump;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.ah[2]), "+v"(f.ah[3]), "+v"(f.bl[0]), "+v"(f.bl[1]), "+v"(f.bl[2]), "+v"(f.bl[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S2: hi x lo
+            clx_static_for<0, 16>([&](auto nc) {
+                mfma_one(f.ah, f.bl, nc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            keep4(f.bl);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if constexpr (CLX_ABL == 2 || CLX_ABL == 3) ha[i] = fe.a[i];
-                else clx_halves(fe.a[i], fo.a[i], ha[i], dump);
-            }
-            if constexpr (j == J0 && CLX_ABL != 2 && CLX_ABL != 3) {
-                // (the pair that spans the chunk boundary: window `chunk` is being overwritten by window chunk + 2 since this pair's TOP, so its B operand
-                // comes out of the M1 fragments, which were read before)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) clx_halves(fe.b[i], fo.b[i], dump, hb[i]);
-            }
-            if constexpr (j == J0 && (CLX_ABL == 2 || CLX_ABL == 3)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hb[i] = fo.b[i];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // hb
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- M2; fragments of the next pair's a (unconditional, also behind the last step, where they fetch a ring slot nobody uses: a conditional
-            // read would keep the old contents of `fe` alive across the swaps, and every swap would first copy its operand)
-            {
-                const unsigned aaddr = abase + wroff, b0 = clx_opaque(blane) + (unsigned)(tapn * shs32 + bufn * XBUF);
-                wroff = wroff + WSLOT == WBYTES ? 0 : wroff + WSLOT;
-                clx_static_for<0, 16>([&](auto nc) {
-                    constexpr int n = decltype(nc)::value;
-                    mfma_one(ha, hb, nc);
-                    if constexpr (n < 8) read_frag(fe, nc, aaddr, b0);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
+                pend.ah[i] = f.ah[i];
+                pend.bh[i] = f.bh[i];
             }
         });
     }
+    // the last pair's hi x hi
+    clx_static_for<0, 16>([&](auto nc) { mfma_one(pend.ah, pend.bh, nc); });
+    keep4(pend.ah);
+    keep4(pend.bh);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the accumulators are read by LDS writes next; the compiler does not see these MFMAs)
     if (p.stamps && tid == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * kClxStampWords;

@@ -80,26 +80,27 @@ ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, 
     return c;
 }
 
-// The same split-bf16 weights as A fragments of v_mfma_f32_16x16x32_bf16 whose 32-deep K dimension carries [hi | lo] of one 16-channel chunk (conv_clx.hip,
-// respair_x16.hip): 1 KB blocks [chunk][row tile of 64][tap][row tile of 16] (M = 32: [chunk][tap][2 row tiles]), lane l of a block (row l & 15, k group
-// g = l >> 4) holds hi (g < 2) or lo (g >= 2) of W[m = 64 mt + 16 rt + (l & 15)][k = 16 chunk + 8 (g & 1) + j][tap], j = 0 .. 7.
+// The same split-bf16 weights as A fragments of v_mfma_f32_16x16x32_bf16 whose 32-deep K dimension carries two consecutive STEPS (step s = tap s % k of chunk
+// s / k; K / 16 even: with an odd k the middle pair of two chunks spans them) for conv_clx.hip: 1 KB blocks [row tile of 64][pair][row tile of 16][part],
+// lane l of a block (row l & 15, k group g = l >> 4) holds W[m = 64 mt + 16 rt + (l & 15)][16 chunk(s) + 8 (g & 1) + j][tap(s)], s = 2 pair + (g >> 1),
+// j = 0 .. 7; part 0 = bf16 hi, 1 = lo.
 void* pack_clx16(WeightStore& ws, const float* w, int M, int K, int k) {
-    const int nchunks = K / 16, nmt = (M + 63) / 64, rts = M >= 64 ? 4 : M / 16;
-    std::vector<uint16_t> h((size_t)nchunks * nmt * k * rts * 512, 0);
-    for (int ch = 0; ch < nchunks; ++ch)
-        for (int mt = 0; mt < nmt; ++mt)
-            for (int t = 0; t < k; ++t)
-                for (int rt = 0; rt < rts; ++rt) {
-                    uint16_t* blk = h.data() + ((((size_t)ch * nmt + mt) * k + t) * rts + rt) * 512;
-                    for (int l = 0; l < 64; ++l) {
-                        const int m = mt * 64 + rt * 16 + (l & 15), g = l >> 4;
-                        for (int j = 0; j < 8; ++j) {
-                            const float v = w[((size_t)m * K + ch * 16 + 8 * (g & 1) + j) * k + t];
-                            const uint16_t hi = f32_to_bf16_rne(v);
-                            blk[l * 8 + j] = g < 2 ? hi : f32_to_bf16_rne(v - bf16_to_f32(hi));
-                        }
+    const int nsteps = (K / 16) * k, nmt = M / 64;
+    std::vector<uint16_t> h((size_t)nmt * (nsteps / 2) * 8 * 512, 0);
+    for (int mt = 0; mt < nmt; ++mt)
+        for (int u = 0; u < nsteps / 2; ++u)
+            for (int rt = 0; rt < 4; ++rt) {
+                uint16_t* blk = h.data() + ((((size_t)mt * (nsteps / 2) + u) * 4 + rt) * 2) * 512;
+                for (int l = 0; l < 64; ++l) {
+                    const int g = l >> 4, s = 2 * u + (g >> 1), ch = s / k, t = s % k, m = mt * 64 + rt * 16 + (l & 15);
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = w[((size_t)m * K + ch * 16 + 8 * (g & 1) + j) * k + t];
+                        const uint16_t hi = f32_to_bf16_rne(v);
+                        blk[l * 8 + j] = hi;
+                        blk[512 + l * 8 + j] = f32_to_bf16_rne(v - bf16_to_f32(hi));
                     }
                 }
+            }
     return ws.upload(reinterpret_cast<const float*>(h.data()), h.size() / 2);
 }
 
