@@ -455,7 +455,10 @@ int sbv2_debug_conv_transpose1d_clx(int device, const float* x, const float* w, 
     p.out_stride = (int)stride;
     p.phase_rows = (int)cout;
     p.phase_group = u.group;
-    for (int q = 0; q < kMaxPhases; ++q) p.phase_off[q] = u.phase_off[q];
+    for (int q = 0; q < kMaxPhases; ++q) {
+        p.phase_off[q] = u.phase_off[q];
+        p.phase_tap0[q] = u.phase_tap0[q];
+    }
     try {
         SBV2_REQUIRE(conv_clx_usable(p), "shape not supported by conv_clx");
         launch_conv_clx(p, nullptr);

@@ -484,13 +484,17 @@ struct ConvClxParams {
     // of two ADJACENT output rows = 64 contiguous bytes, where the plain order writes 32-byte pieces out_stride rows apart (partial HBM writes: measured 2x
     // the write bytes plus the read-modify-write fetches, profiles/r06q_pmc_hbm_traffic.csv); the f32 rows leave as 64-byte halves of a line.
     int phase_group = 1;
+    // phase_tap0[ph]: tap t of phase ph reads position n + shift0 + (phase_tap0[ph] + t) * shift_step: each phase multiplies ITS OWN ntaps input taps (a
+    // ConvTranspose1d(k 16, s 8) phase has two, the first four phases one position later than the last four; the union of all phases would be three: a third
+    // of the MFMAs on zero weights).  Equal inside a phase_group pair.
+    int phase_tap0[kMaxPhases] = {0};
     double prof_flops = 0.0;               // > 0: the launch's algorithmic FLOP for sbv2_prof_* (a phased launch multiplies zero padding taps too)
 };
 int64_t clx_grid_workgroups(const ConvClxParams& p);   // workgroups launch_conv_clx starts for p
 bool conv_clx_usable(const ConvClxParams& p);
 bool clx_enabled();   // decoder_cl.cpp: the wide decoder stages take conv_clx (default) or conv_cl
 int set_clx(int on);  // returns the previous setting
-int set_upx(int on);  // the wide stages' transposed convolutions as phased conv_clx launches (default 1; 2: their rows in plain (phase, channel) order, read when the weights are packed); returns the previous setting
+int set_upx(int on);  // the wide stages' transposed convolutions as phased conv_clx launches (default 1; read when the weights are packed: 2 = their rows in plain (phase, channel) order, 3 = odd tap counts, a zero tap behind the last one); returns the previous setting
 int upx_mode();
 // gemm_bfs: small grids split their K loop over groups of waves (another summation order than the batch's tiles; 0 = the unsplit, batch-order dispatch)
 bool ksplit_enabled();

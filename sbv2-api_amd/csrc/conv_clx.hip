@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     const unsigned abase = lds0 + lane * 16;
     // this lane's B-fragment address in the hi plane of window buffer 0 at tap 0: 16-byte half lg & 1 of the row; a step's tap and buffer are added per pair
     // (k groups 0, 1: step a's, 2, 3: step b's), the lo plane is an immediate (XPART) further
-    const unsigned bhlane = lds0 + WBYTES + (wq * NPW + l16 + kp.sh0) * 32 + ((lg & 1) << 4);
+    int sh0 = kp.sh0;
+    if constexpr (PH) sh0 += p.phase_tap0[p.phase_group == 2 ? 2 * ((m0 >> 5) / (p.phase_rows >> 4)) : m0 / p.phase_rows] * kp.sh_step;   // (uniform) this row tile's phase
+    const unsigned bhlane = lds0 + WBYTES + (wq * NPW + l16 + sh0) * 32 + ((lg & 1) << 4);
     const int shs32 = kp.sh_step * 32;
     f32x4v acc[4][4];
 #pragma unroll
@@ -229,7 +231,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
     // is fetched during pairs 0 .. J0 - 1 (its buffer's previous window was last read in the previous iteration) and waited for at TOP(J0); window c0 + 2 (first
     // read: the next iteration's first pair) during pairs J0 + 1 .. NTAPS - 1 (window c0 is last read by pair J0) and waited for at the next iteration's TOP(0).
     // At those two points a window wave has nothing else in flight: vmcnt(0).
-    constexpr int J0 = (NTAPS - 1) / 2;
+    // (An EVEN kernel size - the phased transposed convolutions, whose phases share 2 or 4 input taps - pairs the taps inside a chunk, NTAPS / 2 pairs each: no
+    // pair spans two chunks, window c0 + 1 is fetched during the pairs of chunk c0 and waited for at TOP(NTAPS / 2), window c0 + 2 during the pairs of c0 + 1.)
+    constexpr bool EVEN = (NTAPS & 1) == 0;
+    constexpr int J0 = EVEN ? NTAPS / 2 : (NTAPS - 1) / 2;   // the pair whose step b (even: both steps) opens chunk c0 + 1
     constexpr int PPP = (kClxPW + J0 - 1) / J0;        // window pieces per window wave and pair
     static_assert(PPP <= 16, "a pair's S1 gaps hold its window pieces");
     static_assert(kClxWR == 4 && kClxXB == 2, "the pair schedule assumes two pair slots of weights and two window buffers");
@@ -291,14 +296,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kClxWR * 40
             // ---- S1: lo x hi; A_hi, B_lo; window pieces: pairs 0 .. J0 - 1 carry window chunk + 1, pairs J0 + 1 .. NTAPS - 1 window chunk + 2
             {
                 constexpr bool first = j < J0;
-                constexpr int jj = first ? j : j - J0 - 1;
+                constexpr int jj = first ? j : j - J0 - (EVEN ? 0 : 1);
                 const bool stx = !wwave && (first ? chunk + 1 < nchunks : chunk + 2 < nchunks);
                 clx_static_for<0, 16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     mfma_one(f.al, f.bh, nc);
                     if constexpr (n < 4) f.ah[n] = clx_read_b128o<n * 2048>(aaddr);
                     else if constexpr (n < 8) f.bl[n - 4] = clx_read_b128o<XPART + (n - 4) * 512>(b0);
-                    if constexpr (j != J0 && n < PPP) {
+                    if constexpr ((EVEN || j != J0) && n < PPP) {
                         constexpr int i = jj * PPP + n;
                         if constexpr (i < kClxPW) {
                             if (stx) dma_x(std::integral_constant<int, i>{});
@@ -687,17 +692,20 @@ void split_cl_km(Plane x, float slope, const SplitClPlanes& out, hipStream_t str
 }
 
 bool conv_clx_usable(const ConvClxParams& p) {
-    if (!(p.ntaps == 3 || p.ntaps == 5 || p.ntaps == 7 || p.ntaps == 11)) return false;
+    if (!(p.ntaps == 3 || p.ntaps == 5 || p.ntaps == 7 || p.ntaps == 11 || (p.phase_rows && (p.ntaps == 2 || p.ntaps == 4)))) return false;
     if (p.Ykm && (p.Y || p.Ys.p || p.accumulate || p.R)) return false;   // the k-major epilogue writes Ykm only
     if ((p.K & 31) || (p.M & 63) || p.K != p.X.C) return false;            // K: pairs of 16-channel chunks (the step pairs of the 16x16x32 products)
-    const int span = (p.ntaps - 1) * std::abs(p.shift_step);
+    int tapmax = p.ntaps - 1;
+    if (p.phase_rows)
+        for (int q = 0; q < kMaxPhases && q < p.M / std::max(p.phase_rows, 1); ++q) tapmax = std::max(tapmax, p.ntaps - 1 + p.phase_tap0[q]);
+    const int span = tapmax * std::abs(p.shift_step);
     if (span > kClxXR - kClxNT || p.shift0 < -kClxFront || p.shift0 + span > 64) return false;
     if (p.mask && p.mask_shift < 0) return false;
     if (p.Y && (p.ldy & 3)) return false;
     if (p.R && (p.ldr & 3)) return false;
     if (p.phase_rows) {   // phased output (a polyphase transposed convolution)
         if ((p.phase_rows & 63) || p.M % p.phase_rows || p.M / p.phase_rows > kMaxPhases || p.out_stride < 1 || p.R || p.accumulate || p.Ykm || p.N < kClxNT ||
-            !(p.ntaps == 3 || p.ntaps == 5)) return false;
+            !(p.ntaps >= 2 && p.ntaps <= 5)) return false;
         if (p.Y && p.ldy < p.phase_rows) return false;
         if (p.Ys.p && (p.Ys.C != p.phase_rows || p.Ys.N != (int64_t)p.N * p.out_stride)) return false;
         for (int q = 0; q < p.M / p.phase_rows; ++q)
@@ -705,8 +713,10 @@ bool conv_clx_usable(const ConvClxParams& p) {
         if (p.phase_group == 2) {
             if ((p.M / p.phase_rows) & 1) return false;
             for (int q = 0; q < p.M / p.phase_rows; q += 2)
-                if (p.phase_off[q + 1] != p.phase_off[q] + 1) return false;
+                if (p.phase_off[q + 1] != p.phase_off[q] + 1 || p.phase_tap0[q + 1] != p.phase_tap0[q]) return false;
         } else if (p.phase_group != 1) return false;
+        for (int q = 0; q < p.M / p.phase_rows; ++q)
+            if (p.phase_tap0[q] < 0 || p.phase_tap0[q] > 8) return false;
     } else if (p.Ys.p && (p.Ys.C != p.M || p.Ys.N != p.N)) return false;
     return p.N >= 1 && p.X.N == p.N;
 }
@@ -718,13 +728,16 @@ static void launch_clx_e(ClxKernelParams kp, hipStream_t stream);
 
 template <int NTAPS, int WR, int XB, int XR>
 static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
-    if constexpr ((NTAPS == 3 || NTAPS == 5) && XR == 288) {
+    if constexpr (NTAPS <= 5 && XR == 288) {
         if (kp.p.phase_rows) {   // (conv_clx_usable: whole tiles, nothing accumulates)
             if ((int64_t)kp.p.N * kp.p.M * 4 >= ((int64_t)128 << 20)) return launch_clx_e<NTAPS, WR, XB, XR, 3, true>(kp, stream);
             return launch_clx_e<NTAPS, WR, XB, XR, 0, true>(kp, stream);
         }
     }
-    SBV2_REQUIRE(!kp.p.phase_rows, "conv_clx: phased output is instantiated for 3 / 5 taps on 288-row windows");
+    SBV2_REQUIRE(!kp.p.phase_rows, "conv_clx: phased output is instantiated for 2 .. 5 taps on 288-row windows");
+    if constexpr ((NTAPS & 1) == 0) {
+        SBV2_REQUIRE(false, "conv_clx: even kernel sizes are instantiated for phased output only");
+    } else {
     if (kp.p.Ykm) launch_clx_e<NTAPS, WR, XB, XR, 2>(kp, stream);
     else if (kp.p.N % kClxNT == 0 || (!kp.p.accumulate && kp.p.N >= kClxNT)) {
         // result planes of >= 128 MB (a batch's decoder stages; a long utterance) leave through non-temporal stores (EPI 3); smaller ones (a single utterance: 29 MB;
@@ -733,6 +746,7 @@ static void launch_clx(const ClxKernelParams& kp, hipStream_t stream) {
         else launch_clx_e<NTAPS, WR, XB, XR, 0>(kp, stream);
     }
     else launch_clx_e<NTAPS, WR, XB, XR, 1>(kp, stream);
+    }
 }
 
 template <int NTAPS, int WR, int XB, int XR, int EPI, bool PH>
@@ -783,8 +797,11 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     ClxKernelParams kp;
     kp.p = p;
     const int step = p.shift_step;
-    const int smin = step >= 0 ? p.shift0 : p.shift0 + (p.ntaps - 1) * step;
-    const int smax = step >= 0 ? p.shift0 + (p.ntaps - 1) * step : p.shift0;
+    int tapmax = p.ntaps - 1;          // the largest tap index any row tile reads (phased output: a phase's own taps start at phase_tap0)
+    if (p.phase_rows)
+        for (int q = 0; q < p.M / p.phase_rows; ++q) tapmax = std::max(tapmax, p.ntaps - 1 + p.phase_tap0[q]);
+    const int smin = step >= 0 ? p.shift0 : p.shift0 + tapmax * step;
+    const int smax = step >= 0 ? p.shift0 + tapmax * step : p.shift0;
     kp.wshift0 = smin;
     kp.xrows = kClxNT + (smax - smin);
     kp.sh0 = p.shift0 - smin;
@@ -793,11 +810,14 @@ void launch_conv_clx(const ConvClxParams& p, hipStream_t stream) {
     // runs on a 4-slot weight ring + two such buffers = 52 KB, THREE workgroups per CU; k = 11 at dilation 5 (span 50 rows) takes three 320-row buffers
     // (76 KB), two per CU.  (Round 4 measured the other ring shapes, 128-row workgroups and 128-position tiles: profiles/HISTORY.md.)
     if (kp.xrows <= 288) {
-        if (p.ntaps == 3) launch_clx<3, 4, 2, 288>(kp, stream);
+        if (p.ntaps == 2) launch_clx<2, 4, 2, 288>(kp, stream);
+        else if (p.ntaps == 4) launch_clx<4, 4, 2, 288>(kp, stream);
+        else if (p.ntaps == 3) launch_clx<3, 4, 2, 288>(kp, stream);
         else if (p.ntaps == 5) launch_clx<5, 4, 2, 288>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 4, 2, 288>(kp, stream);
         else launch_clx<11, 4, 2, 288>(kp, stream);
     } else {
+        SBV2_REQUIRE(p.ntaps & 1, "conv_clx: even kernel sizes run on 288-row windows");
         if (p.ntaps == 3) launch_clx<3, 4, 2, 320>(kp, stream);
         else if (p.ntaps == 5) launch_clx<5, 4, 2, 320>(kp, stream);
         else if (p.ntaps == 7) launch_clx<7, 4, 2, 320>(kp, stream);

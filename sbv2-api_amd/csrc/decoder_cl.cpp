@@ -157,12 +157,30 @@ ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int 
                 tmax = std::max(tmax, tt);
             }
         }
-    int U = tmax - tmin + 1;
-    if ((U & 1) == 0) ++U;                       // a zero tap behind the last one
-    if (!(U == 3 || U == 5)) return u;
+    // every phase multiplies its OWN input taps (k 16, s 8: two, one position later for the first four phases than for the last four; k 8, s 2: four);
+    // SBV2_UPX=3 (A/B runs): the first build's union of all phases' taps (three / five), zero weights where a phase has none
+    const bool uni = upx_mode() == 3;
+    int t0[kMaxPhases], U = 0;
+    for (int r = 0; r < s; ++r) {
+        int lo = 1 << 30, hi = -(1 << 30);
+        for (int tt = tmin; tt <= tmax; ++tt) {
+            const int j = s * tt + r + pad;
+            if (j >= 0 && j < k) {
+                lo = std::min(lo, tt);
+                hi = std::max(hi, tt);
+            }
+        }
+        t0[r] = uni ? tmin : lo;
+        U = std::max(U, uni ? tmax - tmin + 1 : hi - lo + 1);
+    }
+    if (uni && (U & 1) == 0) ++U;
+    if (U < 2 || U > 5) return u;
     const int M = s * cout;
     // a launch that also writes the next stage's operand parts packs its rows as (phase pair, 16 channels, phase in pair, channel): common.h, phase_group
-    const int group = parts_out && (s & 1) == 0 && upx_mode() != 2 ? 2 : 1;
+    int group = parts_out && (s & 1) == 0 && upx_mode() != 2 ? 2 : 1;
+    if (group == 2)
+        for (int r = 0; r < s; r += 2)
+            if (t0[r] != t0[r + 1]) group = 1;   // (the two phases of a pair share the window rows they read: s = 2 keeps the plain order)
     auto row_of = [&](int r, int co) { return group == 2 ? (((r >> 1) * (cout >> 4) + (co >> 4)) * 2 + (r & 1)) * 16 + (co & 15) : r * cout + co; };
     std::vector<float> w((size_t)M * cin * U, 0.f), bias((size_t)M);
     double macs = 0;
@@ -170,7 +188,7 @@ ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int 
         for (int co = 0; co < cout; ++co) {
             bias[(size_t)row_of(r, co)] = ub ? ub[co] : 0.f;
             for (int ti = 0; ti < U; ++ti) {
-                const int j = s * (tmin + ti) + r + pad;
+                const int j = s * (t0[r] + ti) + r + pad;
                 if (j < 0 || j >= k) continue;
                 if (co == 0) macs += (double)cin * cout;
                 for (int ci = 0; ci < cin; ++ci) w[((size_t)row_of(r, co) * cin + ci) * U + ti] = wt[((size_t)ci * cout + co) * k + j];
@@ -181,23 +199,14 @@ ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int 
     u.M = M;
     u.K = cin;
     u.ntaps = U;
-    u.shift0 = -tmin;                            // tap ti reads input position n - (tmin + ti)
+    u.shift0 = -tmin;                            // tap ti of phase r reads input position n - (tmin + phase_tap0[r] + ti)
     u.nph = s;
     u.cout = cout;
     u.group = group;
     u.alg_macs_per_pos = macs;
     for (int r = 0; r < s; ++r) {
         u.phase_off[r] = r;
-        u.phase_ztap[r] = -1;
-        int nz = 0;
-        for (int ti = 0; ti < U; ++ti) {
-            const int j = s * (tmin + ti) + r + pad;
-            if (j < 0 || j >= k) {
-                u.phase_ztap[r] = ti;     // (conv_clx skips ONE such tap per phase; a phase with two keeps multiplying the second one's zeros)
-                ++nz;
-            }
-        }
-        (void)nz;
+        u.phase_tap0[r] = t0[r] - tmin;
     }
     return u;
 }
@@ -436,7 +445,10 @@ void VitsModel::run_decoder_cl(Arena& ar, Plane z, const SegLayout& fl, const fl
             pu.out_stride = st.rate;
             pu.phase_rows = C;
             pu.phase_group = st.upx.group;
-            for (int q = 0; q < kMaxPhases; ++q) pu.phase_off[q] = st.upx.phase_off[q];
+            for (int q = 0; q < kMaxPhases; ++q) {
+                pu.phase_off[q] = st.upx.phase_off[q];
+                pu.phase_tap0[q] = st.upx.phase_tap0[q];
+            }
             pu.prof_flops = 2.0 * st.upx.alg_macs_per_pos * (double)Lcur;
             SBV2_REQUIRE(conv_clx_usable(pu), "decoder: the phased transposed convolution does not fit conv_clx");
             launch_conv_clx(pu, stream_);

@@ -63,7 +63,7 @@ class WeightStore;
 ClConv pack_cl(WeightStore& ws, const float* w, int M, int K, int k, int parts, const float* bias);
 void* pack_clx16(WeightStore& ws, const float* w, int M, int K, int k);
 // A ConvTranspose1d (weight [cin][cout][k], stride s, padding (k - s) / 2) as ONE phased product for conv_clx.hip (round 6): rows (phase, cout), taps = the
-// union of the phases' input taps (zero weights where a phase has none), padded to an odd count (conv_clx pairs its steps across chunks: 3 or 5 taps); tap t
+// union of the phases' input taps (zero weights where a phase has none; 2 .. 5 taps); tap t
 // reads input position n + shift0 - t.  wx == nullptr: the shape does not fit (decoder_cl.cpp falls back to conv_cl.hip's phase groups).
 struct ClUpX {
     void* wx = nullptr;
@@ -72,7 +72,7 @@ struct ClUpX {
     int group = 1;              // ConvClxParams::phase_group of the row order the weights and the bias were packed in
     double alg_macs_per_pos = 0;   // multiply-adds per input position that are not padding (the launch's algorithmic FLOP for the profile)
     int phase_off[kMaxPhases] = {0};
-    int phase_ztap[kMaxPhases] = {-1, -1, -1, -1, -1, -1, -1, -1};   // per phase: a tap that is zero padding for ALL of its rows and channels, or -1
+    int phase_tap0[kMaxPhases] = {0};   // ConvClxParams::phase_tap0: where each phase's own taps start in the union of all phases' taps
 };
 ClUpX build_upx(WeightStore& ws, const float* wt, const float* ub, int cin, int cout, int k, int s, bool parts_out);
 void* pack_step_pairs(WeightStore& ws, const float* w, int C, int k);   // w [C][C][k], C in {32, 64} -> step-pair fragments (split-bf16) for respair_x16.hip
