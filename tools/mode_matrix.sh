@@ -7,6 +7,7 @@ run SBV2_CLX=0
 run SBV2_CLX=2
 run SBV2_BERT_GEMM=f32 SBV2_FLOW_1X1=f32
 run SBV2_RESBRANCH=0 SBV2_UPX=0
+run SBV2_RESBRANCH=2 SBV2_UPX=3 SBV2_RESPAIR_X16=0
 fi
 SEL=(-k "not (deberta or predicted_durations or pipeline or config or smoke or orchestrator or holder or streaming or edge or cpp_host or node or comm)")
 run SBV2_BERT_GEMM=bf16x3 SBV2_FLOW_1X1=bf16x3

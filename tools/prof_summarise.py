@@ -52,7 +52,7 @@ if fe and wr:
     # every kernel that takes >= 0.5 % of the pass's kernel time (the PMC pass runs the steps un-pipelined: launches / steps = launches per step), then the
     # HBM bytes per step of the decoder's kernels (the channels-last family) and of everything
     total_us = sum(F[k][0] * F[k][1] for k in F)
-    dec = lambda k: any(t in k for t in ("conv_clx_kernel", "respair_clx_kernel", "respair_cl_kernel", "resbranch_clx_kernel", "conv_cl_kernel", "conv_cl_small", "k_conv_post_tanh",
+    dec = lambda k: any(t in k for t in ("conv_clx_kernel", "respair_clx_kernel", "respair_x16_kernel", "respair_cl_kernel", "resbranch_clx_kernel", "conv_cl_kernel", "conv_cl_small", "k_conv_post_tanh",
                                          "k_split_cl(", "k_clx_zero_halo", "k_add_segvec_cl", "k_transpose_out"))
     ffn = lambda k: "conv_clx_kernel<5," in k
     steps = int(os.environ.get("PMC_STEPS", "3"))   # bench.py --steps 1 --warmup 1 + its instrumented roofline step
