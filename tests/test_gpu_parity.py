@@ -402,14 +402,20 @@ def test_conv_transpose_clx_kernel(cin, cout, k, s, L):
     assert float(np.abs(ys - lr).max()) <= 2.0 ** -16 * float(np.abs(lr).max())
     # a launch that writes parts packs its rows as (phase pair, 16 channels, phase in pair, channel) so that the 32-byte parts rows of two adjacent output rows
     # leave together (ConvClxParams::phase_group); the plain (phase, channel) order (sbv2_debug_set_upx(2)) gives the same bits
-    y1, ys1 = np.empty_like(y), np.empty_like(ys)
-    prev = _lib.lib().sbv2_debug_set_upx(2)
+    y0, ys0, y1, ys1 = np.empty_like(y), np.empty_like(ys), np.empty_like(y), np.empty_like(ys)
+    prev = _lib.lib().sbv2_debug_set_upx(1)
     try:
+        _lib.check(_lib.lib().sbv2_debug_conv_transpose1d_clx(0, P(x), P(w), P(b), cin, cout, k, L, s, 0.1, None, 1, 0, P(y0), P(ys0), None))
+        _lib.lib().sbv2_debug_set_upx(2)
         _lib.check(_lib.lib().sbv2_debug_conv_transpose1d_clx(0, P(x), P(w), P(b), cin, cout, k, L, s, 0.1, None, 1, 0, P(y1), P(ys1), None))
+        _lib.lib().sbv2_debug_set_upx(3)    # the union of all phases' taps (a zero tap per phase): another pairing of the steps, f32 rounding apart
+        y3 = np.empty_like(y)
+        _lib.check(_lib.lib().sbv2_debug_conv_transpose1d_clx(0, P(x), P(w), P(b), cin, cout, k, L, s, 0.1, None, 1, 0, P(y3), P(ys1.copy()), None))
     finally:
         _lib.lib().sbv2_debug_set_upx(prev)
-    np.testing.assert_array_equal(y1, y)
-    np.testing.assert_array_equal(ys1, ys)
+    np.testing.assert_array_equal(y1, y0)
+    np.testing.assert_array_equal(ys1, ys0)
+    np.testing.assert_allclose(y3, y0, atol=1e-5, rtol=1e-5)
     mask = (rng.random((L + 3) // 4) > 0.2).astype(np.uint8)
     keep = np.repeat(mask, 4)[:L]
     xm = x * keep[None, :]
