@@ -259,20 +259,22 @@ int sbv2_debug_clx_timeline(int device, int64_t C, int64_t k, int64_t dilation, 
    allocated from then on (-1: leave as is; the SBV2_F16X3_SATCOUNT=1 environment variable switches it on from the start); *count (optional) receives the
    number of clamped values since the last call, on `device`.  A non-zero count on a real checkpoint means: run with SBV2_BERT_GEMM=bf16x6. */
 int sbv2_debug_f16x3_saturation(int device, int enable, uint64_t* count);
-/* 1 (default): the fused ResBlock steps of the <= 64-channel decoder stages run on respair_clx.hip (split-bf16, k in {3, 7, 11});
-   0: on respair_cl.hip (same bits).  Returns the previous value. */
+/* 1 (default): the fused ResBlock steps of the <= 64-channel decoder stages run on respair_x16.hip where it exists (C = 32 / 64, k = 7 / 11: 16x16x32 MFMAs,
+   step pairs in the K dimension; f32 rounding apart) and on respair_clx.hip (split-bf16, k in {3, 7, 11}) otherwise; 2 (SBV2_RESPAIR_X16=0): respair_clx.hip
+   at every shape; 0: respair_cl.hip (the bits of mode 2).  Returns the previous value. */
 int sbv2_debug_set_respair_clx(int on);
 /* One fused ResBlock1 step y' = beta (conv2(lrelu(conv1(lrelu(x), dilation) + b1)) + b2 + x) [+ y when accumulate], masked by mask[n / mask_div] (may be
-   null), channels-last x / y [N][C], w [C][C][k], split-bf16, through respair_cl.hip (variant 0) or respair_clx.hip (variant 1).  Test hook. */
+   null), channels-last x / y [N][C], w [C][C][k], split-bf16, through respair_cl.hip (variant 0), the default dispatch (variant 1: respair_x16.hip /
+   respair_clx.hip) or respair_clx.hip at every shape (variant 2).  Test hook. */
 int sbv2_debug_respair(int device, const float* x, const float* w1, const float* w2, const float* b1, const float* b2, int64_t C, int64_t N, int64_t k,
                        int64_t dilation, const uint8_t* mask, int64_t mask_div, float beta, int accumulate, int variant, float* y);
-/* 1 (default; SBV2_RESBRANCH=0): the k = 3 branches of the 128- / 64- / 32- / 16-channel decoder stages run their three steps in ONE launch
-   (resbranch_clx.hip: y_1, y_2 stay on the chip, 2 plane passes through HBM per branch instead of 6); 0: three respair_clx launches (same bits; at 128
-   channels six conv_clx launches: f32 rounding apart).  Returns the previous value. */
+/* 1 (default; SBV2_RESBRANCH): the k = 3 branches of the 128- / 64- / 32- / 16-channel decoder stages and the k = 7 / 11 branches of the 16-channel stage
+   run their three steps in ONE launch (resbranch_clx.hip: y_1, y_2 stay on the chip, 2 plane passes through HBM per branch instead of 6); 2: the k = 3
+   branches only; 0: three fused-step launches (same bits; at 128 channels six conv_clx launches: f32 rounding apart).  Returns the previous value. */
 int sbv2_debug_set_resbranch(int on);
-/* 1 (default; SBV2_UPX=0): the ConvTranspose1d of the wide decoder stages (large launches) runs as ONE phased conv_clx.hip launch on pre-split operands
-   (rows = (phase, cout), taps = the union of the phases' input taps padded to an odd count); 0: conv_cl.hip's phase groups.  f32 rounding apart (another
-   summation order).  Returns the previous value. */
+/* 1 (default; SBV2_UPX): the ConvTranspose1d of the wide decoder stages (large launches) runs as ONE phased conv_clx.hip launch on pre-split operands
+   (rows = (phase, cout), every phase on its own input taps); read when the weights are packed: 2 = rows in plain (phase, channel) order (same bits), 3 = the
+   union of all phases' taps with a zero tap per phase (f32 rounding apart); 0: conv_cl.hip's phase groups (f32 rounding apart).  Returns the previous value. */
 int sbv2_debug_set_upx(int on);
 /* ConvTranspose1d(lrelu(x, pre_slope)) [cin][L] -> y [cout][L * stride] (weight [cin][cout][k], padding (k - stride) / 2) through the phased conv_clx launch;
    mask (may be null): input position n and its `stride` outputs are kept iff mask[n / mask_div]; ys_sum (may be null): hi + lo of the bf16 parts of
@@ -295,7 +297,8 @@ int sbv2_debug_resbranch(int device, const float* x, const float* w, const float
    cycles from a workgroup's entry to phase stamp i (1 = conv1 window staged, 7 / 8 / 9 / 10 = first chunk's MFMAs / barrier / next chunk staged /
    barrier, 2 = conv1 done, 3 = intermediate written, 4 = barrier, 5 = conv2 done, 6 = stores issued).  variant 0 = the stamped instantiation of
    respair_cl (abl bits: 1 cache-hot reads, 2 no stores, 4 no MFMAs, 8 no window conversion, 16 no intermediate epilogue), 1 = the product respair_cl
-   (time only), 2 = respair_clx stamped, 3 = the product respair_clx (time only). */
+   (time only), 2 = respair_clx stamped, 3 = the product respair_clx (time only), 4 = respair_x16 stamped (C = 32 / 64, k = 7 / 11; stamps 7 - 9: chunk
+   pair 0 done / chunk pair 1 converted / first pair done). */
 int sbv2_debug_respair_clock(int device, int64_t C, int64_t k, int64_t dilation, int64_t L, int variant, int abl, double seconds, double* out, int nout);
 /* y[M][N] = act(w[M][K] x[K][N] + bias) (+ res) through the split-bf16 1x1 GEMM (gemm_bfs.hip; parts 2 = bf16x3, 3 = bf16x6).  split_out != 0:
    the result is also emitted as that many bf16 parts and y returns their sum.  iters > 0: average launch time in *ms.  Test hook. */
